@@ -1,0 +1,499 @@
+// gs360_capi.hip -- C-ABI glue of libgs360hip.so (declared in include/gs360.h).
+// Host side only: context / streams / events / memory, per-view constant preparation (float64 -> one
+// rounding to float32) and launch batching.  No CPU compute path exists here on purpose: without a GPU
+// every entry point fails with GS360_ERR_NODEV / GS360_ERR_HIP.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "gs360_kernels.h"
+
+using namespace gs360;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(GS360_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kMaxSlots = 16;
+constexpr int kEventsPerSlot = 8;
+constexpr size_t kSlack = 64;
+constexpr double kPi = 3.14159265358979323846;
+
+struct Staging {  // per-slot device staging used by the *_host conveniences
+    void* d_src = nullptr; size_t src_cap = 0;
+    void* d_dst = nullptr; size_t dst_cap = 0;
+    void* d_aux = nullptr; size_t aux_cap = 0;
+};
+
+}  // namespace
+
+struct gs360_ctx {
+    int device = 0;
+    int n_slots = 0;
+    hipStream_t stream[kMaxSlots] = {};
+    hipEvent_t event[kMaxSlots][kEventsPerSlot] = {};
+    Staging stage[kMaxSlots];
+    hipDeviceProp_t prop;
+};
+
+namespace {
+
+int check_ctx_slot(gs360_ctx* ctx, int slot) {
+    if (!ctx) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (slot < 0 || slot >= ctx->n_slots) return fail(GS360_ERR_ARG, "slot %d out of range [0,%d)", slot, ctx->n_slots);
+    return 0;
+}
+
+int ensure(gs360_ctx* ctx, void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return 0;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    size_t want = need + need / 4 + kSlack;
+    HIP_TRY(hipMalloc(p, want));
+    *cap = want - kSlack;
+    (void)ctx;
+    return 0;
+}
+
+double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// EQ-SPEC v1 per-view constants.  Convention: gs360_GUI.py:377-395 / :419-424 of the reference.
+void make_eq_view(const gs360_view& v, int W, EqView* o) {
+    double hf = clampd(v.hfov_deg, 1e-3, 179.9) * kPi / 180.0;
+    double vf = clampd(v.vfov_deg, 1e-3, 179.9) * kPi / 180.0;
+    o->sxu = (float)(std::tan(hf * 0.5) / (double)v.width);
+    o->syv = (float)(std::tan(vf * 0.5) / (double)v.height);
+    double pitch = v.pitch_deg * kPi / 180.0;
+    o->sp = (float)std::sin(pitch);
+    o->cp = (float)std::cos(pitch);
+    double x0 = (v.yaw_deg / 360.0 + 0.5) * (double)W - 0.5;
+    double fl = std::floor(x0);
+    o->x0f32 = (float)(32.0 * (x0 - fl));
+    long xi = (long)fl % (long)W;
+    if (xi < 0) xi += W;
+    o->x0i32 = (int32_t)(32 * xi);
+    o->out_w = v.width;
+    o->out_h = v.height;
+    o->tiles_x = (v.width + 31) / 32;
+    o->tiles_y = (v.height + 31) / 32;
+}
+
+void make_fe_view(const gs360_calib& cal, const gs360_view& v, double lens_fov_deg, FeView* o) {
+    double hf = clampd(v.hfov_deg, 1e-3, 179.9) * kPi / 180.0;
+    double vf = clampd(v.vfov_deg, 1e-3, 179.9) * kPi / 180.0;
+    o->sxu = (float)(std::tan(hf * 0.5) / (double)v.width);
+    o->syv = (float)(std::tan(vf * 0.5) / (double)v.height);
+    double pitch = v.pitch_deg * kPi / 180.0, yaw = v.yaw_deg * kPi / 180.0;
+    o->sp = (float)std::sin(pitch); o->cp = (float)std::cos(pitch);
+    o->sy = (float)std::sin(yaw); o->cy = (float)std::cos(yaw);
+    o->k1 = (float)cal.k1; o->k2 = (float)cal.k2; o->k3 = (float)cal.k3; o->k4 = (float)cal.k4;
+    o->p1 = (float)cal.p1; o->p2 = (float)cal.p2;
+    o->tp1 = (float)(2.0 * cal.p1); o->tp2 = (float)(2.0 * cal.p2);
+    o->b1 = (float)cal.b1; o->b2 = (float)cal.b2; o->f = (float)cal.f;
+    o->cx0 = (float)((cal.width * 0.5) + cal.cx);   // DF:1812-1813
+    o->cy0 = (float)((cal.height * 0.5) + cal.cy);
+    o->wmax = (float)(cal.width - 1); o->hmax = (float)(cal.height - 1);
+    o->cos_tmax = (float)std::cos(clampd(lens_fov_deg, 1.0, 360.0) * 0.5 * kPi / 180.0);  // DF:1800
+    o->tang = (cal.p1 != 0.0 || cal.p2 != 0.0) ? 1 : 0;
+    o->W = cal.width; o->H = cal.height;
+    o->out_w = v.width; o->out_h = v.height;
+    o->tiles_x = (v.width + 31) / 32;
+    o->tiles_y = (v.height + 31) / 32;
+}
+
+uint8_t sat_u8(double v) {  // cv::saturate_cast<uchar>(double)
+    long r = std::lrint(v);
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs360_abi_version(void) { return GS360_ABI_VERSION; }
+
+int gs360_last_error(char* buf, size_t n) {
+    size_t len = std::strlen(g_err);
+    if (buf && n) {
+        size_t c = len < n - 1 ? len : n - 1;
+        std::memcpy(buf, g_err, c);
+        buf[c] = 0;
+    }
+    return (int)len;
+}
+
+int gs360_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail(GS360_ERR_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+        return 0;
+    }
+    return n;
+}
+
+int gs360_ctx_create(int device, int n_slots, gs360_ctx** out) {
+    if (!out) return fail(GS360_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_slots < 1 || n_slots > kMaxSlots) return fail(GS360_ERR_ARG, "n_slots must be in [1,%d]", kMaxSlots);
+    int n = gs360_device_count();
+    if (n <= 0) return fail(GS360_ERR_NODEV, "no HIP device visible (libgs360hip has no CPU path)");
+    if (device < 0 || device >= n) return fail(GS360_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    gs360_ctx* c = new (std::nothrow) gs360_ctx();
+    if (!c) return fail(GS360_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->n_slots = n_slots;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device);
+    for (int s = 0; s < n_slots && e == hipSuccess; ++s) {
+        e = hipStreamCreateWithFlags(&c->stream[s], hipStreamNonBlocking);
+        for (int k = 0; k < kEventsPerSlot && e == hipSuccess; ++k) e = hipEventCreate(&c->event[s][k]);
+    }
+    if (e != hipSuccess) {
+        int rc = fail(GS360_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+        gs360_ctx_destroy(c);
+        return rc;
+    }
+    if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(GS360_ERR_NODEV, "device %d is %s; this library carries gfx950 code objects only", device,
+                      c->prop.gcnArchName);
+        gs360_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return GS360_OK;
+}
+
+int gs360_ctx_destroy(gs360_ctx* c) {
+    if (!c) return GS360_OK;
+    (void)hipSetDevice(c->device);
+    for (int s = 0; s < c->n_slots; ++s) {
+        if (c->stream[s]) (void)hipStreamSynchronize(c->stream[s]);
+        for (int k = 0; k < kEventsPerSlot; ++k)
+            if (c->event[s][k]) (void)hipEventDestroy(c->event[s][k]);
+        if (c->stage[s].d_src) (void)hipFree(c->stage[s].d_src);
+        if (c->stage[s].d_dst) (void)hipFree(c->stage[s].d_dst);
+        if (c->stage[s].d_aux) (void)hipFree(c->stage[s].d_aux);
+        if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
+    }
+    delete c;
+    return GS360_OK;
+}
+
+int gs360_device_info(gs360_ctx* c, char* name, size_t n, int32_t* cu_count, uint64_t* hbm_bytes) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (name && n) snprintf(name, n, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (cu_count) *cu_count = c->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)c->prop.totalGlobalMem;
+    return GS360_OK;
+}
+
+// ---- memory ------------------------------------------------------------------------------------
+int gs360_dev_alloc(gs360_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) return fail(GS360_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(dptr, bytes + kSlack));
+    return GS360_OK;
+}
+int gs360_dev_free(gs360_ctx* c, void* dptr) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (!dptr) return GS360_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipFree(dptr));
+    return GS360_OK;
+}
+int gs360_host_alloc(gs360_ctx* c, size_t bytes, void** hptr) {
+    if (!c || !hptr) return fail(GS360_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return GS360_OK;
+}
+int gs360_host_free(gs360_ctx* c, void* hptr) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (!hptr) return GS360_OK;
+    HIP_TRY(hipHostFree(hptr));
+    return GS360_OK;
+}
+int gs360_upload(gs360_ctx* c, void* dst_dev, const void* src_host, size_t bytes, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!dst_dev || !src_host) return fail(GS360_ERR_ARG, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream[slot]));
+    return GS360_OK;
+}
+int gs360_download(gs360_ctx* c, void* dst_host, const void* src_dev, size_t bytes, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!dst_host || !src_dev) return fail(GS360_ERR_ARG, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream[slot]));
+    return GS360_OK;
+}
+int gs360_dev_memset(gs360_ctx* c, void* dst_dev, int value, size_t bytes, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!dst_dev) return fail(GS360_ERR_ARG, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(dst_dev, value, bytes, c->stream[slot]));
+    return GS360_OK;
+}
+int gs360_sync(gs360_ctx* c, int slot) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot < 0) {
+        for (int s = 0; s < c->n_slots; ++s) HIP_TRY(hipStreamSynchronize(c->stream[s]));
+        return GS360_OK;
+    }
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream[slot]));
+    return GS360_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int gs360_event_record(gs360_ctx* c, int slot, int idx) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (idx < 0 || idx >= kEventsPerSlot) return fail(GS360_ERR_ARG, "event index %d out of range", idx);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->event[slot][idx], c->stream[slot]));
+    return GS360_OK;
+}
+int gs360_event_elapsed_ms(gs360_ctx* c, int slot, int from, int to, float* ms) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!ms || from < 0 || to < 0 || from >= kEventsPerSlot || to >= kEventsPerSlot)
+        return fail(GS360_ERR_ARG, "bad event arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->event[slot][to]));
+    HIP_TRY(hipEventElapsedTime(ms, c->event[slot][from], c->event[slot][to]));
+    return GS360_OK;
+}
+
+// ---- equirect -> views -------------------------------------------------------------------------
+int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_frames, int W, int H, int C,
+                            size_t src_stride, const gs360_view* views, int n_views, void* const* dst,
+                            size_t dst_stride, int interp, uint32_t flags, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!src_frames || !views || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (n_frames < 0 || n_views < 0) return fail(GS360_ERR_ARG, "negative count");
+    if (n_frames == 0 || n_views == 0) return GS360_OK;  // empty batch is a no-op
+    if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
+    if (W < 2 || H < 2 || W > (1 << 21) || H > (1 << 21)) return fail(GS360_ERR_ARG, "bad source size %dx%d", W, H);
+    if (interp != GS360_INTERP_LINEAR) return fail(GS360_ERR_UNSUPPORTED, "equirect path implements INTER_LINEAR only");
+    if (flags != 0) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
+    if (src_stride == 0) src_stride = (size_t)W * C;
+    if (src_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "src_stride smaller than a row");
+    for (int k = 0; k < n_views; ++k) {
+        if (views[k].width < 1 || views[k].height < 1 || views[k].width > 32768 || views[k].height > 32768)
+            return fail(GS360_ERR_ARG, "view %d has bad size %dx%d", k, views[k].width, views[k].height);
+        if (dst_stride && dst_stride < (size_t)views[k].width * C) return fail(GS360_ERR_ARG, "dst_stride smaller than a row");
+        if (!std::isfinite(views[k].yaw_deg) || !std::isfinite(views[k].pitch_deg) || !std::isfinite(views[k].hfov_deg) ||
+            !std::isfinite(views[k].vfov_deg))
+            return fail(GS360_ERR_ARG, "view %d has a non-finite angle", k);
+    }
+    for (int f = 0; f < n_frames; ++f)
+        if (!src_frames[f]) return fail(GS360_ERR_ARG, "src_frames[%d] is NULL", f);
+    for (int i = 0; i < n_frames * n_views; ++i)
+        if (!dst[i]) return fail(GS360_ERR_ARG, "dst[%d] is NULL", i);
+    HIP_TRY(hipSetDevice(c->device));
+
+    for (int v0 = 0; v0 < n_views; v0 += GS360_MAX_VIEWS) {
+        int nv = n_views - v0 < GS360_MAX_VIEWS ? n_views - v0 : GS360_MAX_VIEWS;
+        for (int f0 = 0; f0 < n_frames; f0 += GS360_MAX_FRAMES) {
+            int nf = n_frames - f0 < GS360_MAX_FRAMES ? n_frames - f0 : GS360_MAX_FRAMES;
+            EqLaunch L;
+            std::memset(&L, 0, sizeof(L));
+            int base = 0;
+            for (int k = 0; k < nv; ++k) {
+                make_eq_view(views[v0 + k], W, &L.view[k]);
+                L.view[k].tile_base = base;
+                base += L.view[k].tiles_x * L.view[k].tiles_y;
+            }
+            for (int f = 0; f < nf; ++f) {
+                L.src[f] = (const uint8_t*)src_frames[f0 + f];
+                for (int k = 0; k < nv; ++k) L.dst[f * nv + k] = (uint8_t*)dst[(size_t)(f0 + f) * n_views + v0 + k];
+            }
+            L.kx32 = (float)(32.0 * (double)W / (2.0 * kPi));
+            L.ky32 = (float)(32.0 * (double)H / kPi);
+            L.W = W; L.H = H;
+            L.y0i32 = 16 * H - 16;
+            L.n_views = nv; L.n_frames = nf;
+            L.tiles_per_frame = base;
+            L.total_tiles = base * nf;
+            L.chunk = (L.total_tiles + 7) / 8;
+            L.src_stride = (int64_t)src_stride;
+            L.dst_stride = (int64_t)dst_stride;
+            HIP_TRY(launch_equirect(L, C, c->stream[slot]));
+        }
+    }
+    return GS360_OK;
+}
+
+// ---- table remap -------------------------------------------------------------------------------
+int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                         const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                         const double* border_value, int fill_value, void* dst, size_t dst_stride, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!src || !map_x || !map_y || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
+    if (H < 1 || W < 1 || H >= 32767 || W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", W, H);
+    if (h < 0 || w < 0 || h >= 32767 || w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", w, h);
+    if (h == 0 || w == 0) return GS360_OK;
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST)
+        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1)", interp);
+    if (src_stride == 0) src_stride = (size_t)W * C;
+    if (dst_stride == 0) dst_stride = (size_t)w * C;
+    if (src_stride < (size_t)W * C || dst_stride < (size_t)w * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
+    HIP_TRY(hipSetDevice(c->device));
+    TableLaunch L;
+    std::memset(&L, 0, sizeof(L));
+    L.src = (const uint8_t*)src; L.map_x = map_x; L.map_y = map_y; L.valid = valid; L.dst = (uint8_t*)dst;
+    L.H = H; L.W = W; L.h = h; L.w = w;
+    L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
+    L.interp = interp;
+    L.fill = fill_value < 0 ? 0 : (fill_value > 255 ? 255 : fill_value);
+    for (int k = 0; k < 4; ++k) L.cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
+    HIP_TRY(launch_table(L, C, c->stream[slot]));
+    return GS360_OK;
+}
+
+// ---- fused fisheye -> views --------------------------------------------------------------------
+int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs360_calib* calibs, int C, size_t src_stride,
+                           const gs360_view* views, int n_views, double lens_fov_deg, int interp, int mask_outside,
+                           int mask_value, void* const* dst, size_t dst_stride, uint8_t* const* valid_out, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!src_lens || !calibs || !views || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (n_views < 0) return fail(GS360_ERR_ARG, "negative count");
+    if (n_views == 0) return GS360_OK;
+    if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST)
+        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1)", interp);
+    for (int k = 0; k < n_views; ++k) {
+        if (!src_lens[k] || !dst[k]) return fail(GS360_ERR_ARG, "NULL image pointer for view %d", k);
+        if (calibs[k].width < 1 || calibs[k].height < 1 || calibs[k].width >= 32767 || calibs[k].height >= 32767)
+            return fail(GS360_ERR_ARG, "bad sensor size for view %d", k);
+        if (calibs[k].width != calibs[0].width && src_stride != 0)
+            return fail(GS360_ERR_ARG, "explicit src_stride needs equal sensor widths");
+        if (views[k].width < 1 || views[k].height < 1 || views[k].width > 32768 || views[k].height > 32768)
+            return fail(GS360_ERR_ARG, "view %d has bad size", k);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    mask_value = mask_value < 0 ? 0 : (mask_value > 255 ? 255 : mask_value);
+    for (int v0 = 0; v0 < n_views; v0 += GS360_MAX_VIEWS) {
+        int nv = n_views - v0 < GS360_MAX_VIEWS ? n_views - v0 : GS360_MAX_VIEWS;
+        // one launch per group of equal-width sensors keeps a single src_stride in the parameter block
+        FeLaunch L;
+        std::memset(&L, 0, sizeof(L));
+        int base = 0;
+        for (int k = 0; k < nv; ++k) {
+            make_fe_view(calibs[v0 + k], views[v0 + k], lens_fov_deg, &L.view[k]);
+            L.view[k].src = (const uint8_t*)src_lens[v0 + k];
+            L.view[k].dst = (uint8_t*)dst[v0 + k];
+            L.view[k].valid_out = valid_out ? valid_out[v0 + k] : nullptr;
+            L.view[k].tile_base = base;
+            base += L.view[k].tiles_x * L.view[k].tiles_y;
+            if (calibs[v0 + k].width != calibs[v0].width)
+                return fail(GS360_ERR_UNSUPPORTED, "views of one call must share the sensor width");
+        }
+        L.n_views = nv;
+        L.total_tiles = base;
+        L.chunk = (base + 7) / 8;
+        L.interp = interp; L.mask_outside = mask_outside ? 1 : 0; L.mask_value = mask_value;
+        L.src_stride = (int64_t)(src_stride ? src_stride : (size_t)calibs[v0].width * C);
+        L.dst_stride = (int64_t)dst_stride;
+        L.cval[0] = (uint8_t)mask_value;  // borderValue=float(mask_value) -> Scalar(v,0,0,0), DF:2007
+        HIP_TRY(launch_fisheye(L, C, c->stream[slot]));
+    }
+    return GS360_OK;
+}
+
+// ---- host-buffer conveniences ------------------------------------------------------------------
+int gs360_equirect_views_u8_host(gs360_ctx* c, const uint8_t* src, int W, int H, int C, size_t src_stride,
+                                 const gs360_view* views, int n_views, uint8_t* const* dst, size_t dst_stride,
+                                 int interp, uint32_t flags, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!src || !views || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (n_views <= 0) return n_views == 0 ? GS360_OK : fail(GS360_ERR_ARG, "negative count");
+    if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
+    if (W < 2 || H < 2) return fail(GS360_ERR_ARG, "bad source size");
+    if (src_stride == 0) src_stride = (size_t)W * C;
+    HIP_TRY(hipSetDevice(c->device));
+    Staging& S = c->stage[slot];
+    size_t src_bytes = src_stride * (size_t)H;
+    std::vector<size_t> off(n_views);
+    size_t total = 0;
+    for (int k = 0; k < n_views; ++k) {
+        if (views[k].width < 1 || views[k].height < 1) return fail(GS360_ERR_ARG, "view %d has bad size", k);
+        size_t ds = dst_stride ? dst_stride : (size_t)views[k].width * C;
+        off[k] = total;
+        total += (ds * (size_t)views[k].height + 255) & ~(size_t)255;
+    }
+    if (int rc = ensure(c, &S.d_src, &S.src_cap, src_bytes)) return rc;
+    if (int rc = ensure(c, &S.d_dst, &S.dst_cap, total)) return rc;
+    hipStream_t st = c->stream[slot];
+    HIP_TRY(hipMemcpyAsync(S.d_src, src, src_bytes, hipMemcpyHostToDevice, st));
+    std::vector<void*> dptr(n_views);
+    for (int k = 0; k < n_views; ++k) dptr[k] = (uint8_t*)S.d_dst + off[k];
+    const void* frames[1] = {S.d_src};
+    if (int rc = gs360_equirect_views_u8(c, frames, 1, W, H, C, src_stride, views, n_views, dptr.data(), dst_stride, interp,
+                                         flags, slot))
+        return rc;
+    for (int k = 0; k < n_views; ++k) {
+        if (!dst[k]) return fail(GS360_ERR_ARG, "dst[%d] is NULL", k);
+        size_t ds = dst_stride ? dst_stride : (size_t)views[k].width * C;
+        HIP_TRY(hipMemcpyAsync(dst[k], dptr[k], ds * (size_t)views[k].height, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return GS360_OK;
+}
+
+int gs360_remap_table_u8_host(gs360_ctx* c, const uint8_t* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                              const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                              const double* border_value, int fill_value, uint8_t* dst, size_t dst_stride, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!src || !map_x || !map_y || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
+    if (H < 1 || W < 1 || h < 0 || w < 0) return fail(GS360_ERR_ARG, "bad size");
+    if (h == 0 || w == 0) return GS360_OK;
+    if (src_stride == 0) src_stride = (size_t)W * C;
+    if (dst_stride == 0) dst_stride = (size_t)w * C;
+    HIP_TRY(hipSetDevice(c->device));
+    Staging& S = c->stage[slot];
+    size_t src_bytes = src_stride * (size_t)H, dst_bytes = dst_stride * (size_t)h;
+    size_t npx = (size_t)h * w, map_bytes = npx * sizeof(float);
+    size_t map_al = (map_bytes + 255) & ~(size_t)255;
+    if (int rc = ensure(c, &S.d_src, &S.src_cap, src_bytes)) return rc;
+    if (int rc = ensure(c, &S.d_dst, &S.dst_cap, dst_bytes)) return rc;
+    if (int rc = ensure(c, &S.d_aux, &S.aux_cap, 2 * map_al + npx)) return rc;
+    hipStream_t st = c->stream[slot];
+    float* dmx = (float*)S.d_aux;
+    float* dmy = (float*)((uint8_t*)S.d_aux + map_al);
+    uint8_t* dva = (uint8_t*)S.d_aux + 2 * map_al;
+    HIP_TRY(hipMemcpyAsync(S.d_src, src, src_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dmx, map_x, map_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dmy, map_y, map_bytes, hipMemcpyHostToDevice, st));
+    if (valid) HIP_TRY(hipMemcpyAsync(dva, valid, npx, hipMemcpyHostToDevice, st));
+    if (int rc = gs360_remap_table_u8(c, S.d_src, H, W, C, src_stride, dmx, dmy, valid ? dva : nullptr, h, w, interp,
+                                      border_value, fill_value, S.d_dst, dst_stride, slot))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dst, S.d_dst, dst_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GS360_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// gs360_kernels.h -- device-side parameter blocks shared by the kernels and the C-ABI glue.
+// gfx950 only; no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gs360.h"
+
+namespace gs360 {
+
+// ------------------------------------------------------------------------------------------------
+// EQ-SPEC v1 per-view constants.  Host computes them in float64 and rounds once.
+// ------------------------------------------------------------------------------------------------
+struct EqView {
+    float sxu, syv;      // tan(hfov/2)/out_w, tan(vfov/2)/out_h
+    float sp, cp;        // sin / cos of pitch
+    float x0f32;         // 32 * frac((yaw/360 + 1/2) * W - 1/2)
+    int32_t x0i32;       // 32 * (floor(...) mod W)
+    int32_t out_w, out_h;
+    int32_t tiles_x, tiles_y;
+    int32_t tile_base;   // first tile index of this view inside one frame
+};
+
+struct EqLaunch {
+    const uint8_t* src[GS360_MAX_FRAMES];
+    uint8_t* dst[GS360_MAX_FRAMES * GS360_MAX_VIEWS];
+    EqView view[GS360_MAX_VIEWS];
+    float kx32, ky32;    // 32*W/(2*pi), 32*H/pi
+    int32_t W, H;
+    int32_t y0i32;       // 16*H - 16
+    int32_t n_views, n_frames;
+    int32_t tiles_per_frame, total_tiles, chunk;  // chunk = ceil(total_tiles / 8) (XCD swizzle)
+    int64_t src_stride;
+    int64_t dst_stride;  // 0 = tight (out_w * C)
+};
+
+// ------------------------------------------------------------------------------------------------
+// table-mode remap (cv2.remap semantics)
+// ------------------------------------------------------------------------------------------------
+struct TableLaunch {
+    const uint8_t* src;
+    const float* map_x;
+    const float* map_y;
+    const uint8_t* valid;  // may be null
+    uint8_t* dst;
+    int32_t H, W, h, w;
+    int64_t src_stride, dst_stride;
+    int32_t interp;
+    int32_t fill;
+    uint8_t cval[4];
+};
+
+// ------------------------------------------------------------------------------------------------
+// FE-SPEC v1 (fused dual-fisheye -> perspective)
+// ------------------------------------------------------------------------------------------------
+struct FeView {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint8_t* valid_out;  // may be null
+    float sxu, syv, sp, cp, sy, cy;
+    float k1, k2, k3, k4, p1, p2, tp1, tp2, b1, b2, f, cx0, cy0, wmax, hmax, cos_tmax;
+    int32_t tang;
+    int32_t W, H;        // sensor size
+    int32_t out_w, out_h;
+    int32_t tiles_x, tiles_y, tile_base;
+};
+
+struct FeLaunch {
+    FeView view[GS360_MAX_VIEWS];
+    int32_t n_views, total_tiles, chunk;
+    int32_t interp, mask_outside, mask_value;
+    int64_t src_stride, dst_stride;
+    uint8_t cval[4];
+};
+
+// kernel launchers (gs360_kernels.hip)
+hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s);
+hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s);
+hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s);
+
+}  // namespace gs360

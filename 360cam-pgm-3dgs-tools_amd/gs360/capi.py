@@ -1,0 +1,304 @@
+"""ctypes binding of libgs360hip.so (C ABI declared in include/gs360.h).
+
+This is the only door from Python into the engine.  There is NO CPU fallback: if the shared
+library or a gfx950 device is missing every call raises Gs360Error.
+"""
+import ctypes as C
+import pathlib
+import threading
+
+import numpy as np
+
+PKG_DIR = pathlib.Path(__file__).resolve().parent.parent
+LIB_PATH = PKG_DIR / "lib" / "libgs360hip.so"
+
+INTERP_NEAREST = 0  # == cv2.INTER_NEAREST
+INTERP_LINEAR = 1   # == cv2.INTER_LINEAR
+MAX_VIEWS = 16
+MAX_FRAMES = 16
+
+EXPORTS = (
+    "gs360_abi_version", "gs360_device_count", "gs360_last_error", "gs360_ctx_create", "gs360_ctx_destroy",
+    "gs360_device_info", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
+    "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_sync", "gs360_event_record",
+    "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_remap_table_u8", "gs360_fisheye_views_u8",
+    "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
+)
+
+
+class Gs360Error(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"gs360 error {code}: {text}")
+        self.code = code
+        self.text = text
+
+
+class View(C.Structure):
+    """Numeric fields of the reference's ViewSpec (gs360_360PerspCut.py:32-45)."""
+    _fields_ = [("yaw_deg", C.c_double), ("pitch_deg", C.c_double), ("hfov_deg", C.c_double),
+                ("vfov_deg", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
+
+    @classmethod
+    def make(cls, yaw, pitch, hfov, vfov, width, height):
+        return cls(float(yaw), float(pitch), float(hfov), float(vfov), int(width), int(height))
+
+
+class Calib(C.Structure):
+    """Numeric fields of the reference's SensorCalibration (gs360_DualFisheyeDistortionCalibration.py:67-85)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32)] + [
+        (n, C.c_double) for n in ("f", "cx", "cy", "k1", "k2", "k3", "k4", "p1", "p2", "b1", "b2")]
+
+    @classmethod
+    def make(cls, width, height, f, cx=0.0, cy=0.0, k1=0.0, k2=0.0, k3=0.0, k4=0.0, p1=0.0, p2=0.0, b1=0.0, b2=0.0):
+        return cls(int(width), int(height), *[float(v) for v in (f, cx, cy, k1, k2, k3, k4, p1, p2, b1, b2)])
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path=None):
+    """Load libgs360hip.so and declare prototypes.  Raises Gs360Error if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = pathlib.Path(path) if path else LIB_PATH
+        if not p.exists():
+            raise Gs360Error(-3, f"{p} is missing -- build it with `python __graft_entry__.py` "
+                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(str(p))
+        vp, i, sz, u32 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint32
+        pvp = C.POINTER(C.c_void_p)
+        L.gs360_abi_version.argtypes = []
+        L.gs360_device_count.argtypes = []
+        L.gs360_last_error.argtypes = [C.c_char_p, sz]
+        L.gs360_ctx_create.argtypes = [i, i, pvp]
+        L.gs360_ctx_destroy.argtypes = [vp]
+        L.gs360_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.gs360_dev_alloc.argtypes = [vp, sz, pvp]
+        L.gs360_dev_free.argtypes = [vp, vp]
+        L.gs360_host_alloc.argtypes = [vp, sz, pvp]
+        L.gs360_host_free.argtypes = [vp, vp]
+        L.gs360_upload.argtypes = [vp, vp, vp, sz, i]
+        L.gs360_download.argtypes = [vp, vp, vp, sz, i]
+        L.gs360_dev_memset.argtypes = [vp, vp, i, sz, i]
+        L.gs360_sync.argtypes = [vp, i]
+        L.gs360_event_record.argtypes = [vp, i, i]
+        L.gs360_event_elapsed_ms.argtypes = [vp, i, i, i, C.POINTER(C.c_float)]
+        L.gs360_equirect_views_u8.argtypes = [vp, pvp, i, i, i, i, sz, C.POINTER(View), i, pvp, sz, i, u32, i]
+        L.gs360_remap_table_u8.argtypes = [vp, vp, i, i, i, sz, vp, vp, vp, i, i, i, C.POINTER(C.c_double), i, vp, sz, i]
+        L.gs360_fisheye_views_u8.argtypes = [vp, pvp, C.POINTER(Calib), i, sz, C.POINTER(View), i, C.c_double, i, i, i,
+                                             pvp, sz, pvp, i]
+        L.gs360_equirect_views_u8_host.argtypes = [vp, vp, i, i, i, sz, C.POINTER(View), i, pvp, sz, i, u32, i]
+        L.gs360_remap_table_u8_host.argtypes = [vp, vp, i, i, i, sz, vp, vp, vp, i, i, i, C.POINTER(C.c_double), i, vp,
+                                                sz, i]
+        for name in EXPORTS:
+            getattr(L, name).restype = C.c_int
+        if path is None:
+            _lib = L
+        return L
+
+
+def last_error(L=None):
+    L = L or load_library()
+    buf = C.create_string_buffer(512)
+    L.gs360_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def _check(rc, L):
+    if rc != 0:
+        raise Gs360Error(rc, last_error(L))
+
+
+def device_count():
+    return load_library().gs360_device_count()
+
+
+class DeviceBuffer:
+    """A device allocation owned by a Context (freed with the context or explicitly)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(ctx.L.gs360_dev_alloc(ctx.handle, self.nbytes, C.byref(p)), ctx.L)
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.gs360_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One engine context = one GPU + n_slots HIP streams.  Thread-safe per slot (a lock per slot)."""
+
+    def __init__(self, device=0, n_slots=2):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L.gs360_ctx_create(int(device), int(n_slots), C.byref(h)), self.L)
+        self.handle = h
+        self.device = int(device)
+        self.n_slots = int(n_slots)
+        self.slot_locks = [threading.Lock() for _ in range(n_slots)]
+        self._buffers = []
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if self.handle:
+            for b in self._buffers:
+                b.free()
+            self._buffers = []
+            self.L.gs360_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int32()
+        mem = C.c_uint64()
+        _check(self.L.gs360_device_info(self.handle, name, 256, C.byref(cu), C.byref(mem)), self.L)
+        return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    # -- memory -----------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        b = DeviceBuffer(self, nbytes)
+        self._buffers.append(b)
+        return b
+
+    def free(self, buf):
+        buf.free()
+        if buf in self._buffers:
+            self._buffers.remove(buf)
+
+    def upload(self, buf, array, slot=0, sync=True):
+        a = np.ascontiguousarray(array)
+        if a.nbytes > buf.nbytes:
+            raise ValueError("upload larger than buffer")
+        _check(self.L.gs360_upload(self.handle, buf.ptr, a.ctypes.data, a.nbytes, slot), self.L)
+        if sync:
+            self.sync(slot)
+        return buf
+
+    def to_device(self, array, slot=0):
+        a = np.ascontiguousarray(array)
+        return self.upload(self.alloc(a.nbytes), a, slot)
+
+    def download(self, buf, shape, dtype=np.uint8, slot=0):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > buf.nbytes:
+            raise ValueError("download larger than buffer")
+        _check(self.L.gs360_download(self.handle, out.ctypes.data, buf.ptr, out.nbytes, slot), self.L)
+        self.sync(slot)
+        return out
+
+    def memset(self, buf, value, slot=0):
+        _check(self.L.gs360_dev_memset(self.handle, buf.ptr, int(value), buf.nbytes, slot), self.L)
+
+    def sync(self, slot=-1):
+        _check(self.L.gs360_sync(self.handle, slot), self.L)
+
+    def event_record(self, slot, idx):
+        _check(self.L.gs360_event_record(self.handle, slot, idx), self.L)
+
+    def event_elapsed_ms(self, slot, i_from, i_to):
+        ms = C.c_float()
+        _check(self.L.gs360_event_elapsed_ms(self.handle, slot, i_from, i_to, C.byref(ms)), self.L)
+        return float(ms.value)
+
+    # -- hot path, device-resident ----------------------------------------------------------
+    def equirect_views_dev(self, frames, W, H, Cn, views, dsts, slot=0, src_stride=0, dst_stride=0,
+                           interp=INTERP_LINEAR):
+        """frames: list of DeviceBuffer (H x W x C); dsts: list (len frames*views) of DeviceBuffer."""
+        nf, nv = len(frames), len(views)
+        fp = (C.c_void_p * max(nf, 1))(*[b.ptr for b in frames])
+        dp = (C.c_void_p * max(nf * nv, 1))(*[b.ptr for b in dsts])
+        va = (View * max(nv, 1))(*views)
+        _check(self.L.gs360_equirect_views_u8(self.handle, fp, nf, W, H, Cn, src_stride, va, nv, dp, dst_stride,
+                                              interp, 0, slot), self.L)
+
+    def make_equirect_call(self, frames, W, H, Cn, views, dsts, slot=0, interp=INTERP_LINEAR):
+        """Pre-marshal one batched launch; returns a zero-argument callable (used by bench loops)."""
+        nf, nv = len(frames), len(views)
+        fp = (C.c_void_p * nf)(*[b.ptr for b in frames])
+        dp = (C.c_void_p * (nf * nv))(*[b.ptr for b in dsts])
+        va = (View * nv)(*views)
+        fn, h, L = self.L.gs360_equirect_views_u8, self.handle, self.L
+
+        def call():
+            rc = fn(h, fp, nf, W, H, Cn, 0, va, nv, dp, 0, interp, 0, slot)
+            if rc:
+                _check(rc, L)
+        call.keepalive = (fp, dp, va)
+        return call
+
+    def remap_table_dev(self, src, H, W, Cn, map_x, map_y, valid, h, w, dst, interp=INTERP_LINEAR,
+                        border_value=(0, 0, 0, 0), fill_value=0, slot=0):
+        bv = (C.c_double * 4)(*[float(x) for x in border_value])
+        _check(self.L.gs360_remap_table_u8(self.handle, src.ptr, H, W, Cn, 0, map_x.ptr, map_y.ptr,
+                                           valid.ptr if valid is not None else None, h, w, interp, bv,
+                                           int(fill_value), dst.ptr, 0, slot), self.L)
+
+    def fisheye_views_dev(self, lens_bufs, calibs, Cn, views, lens_fov_deg, dsts, valid_outs=None,
+                          interp=INTERP_LINEAR, mask_outside=True, mask_value=0, slot=0):
+        nv = len(views)
+        sp = (C.c_void_p * nv)(*[b.ptr for b in lens_bufs])
+        dp = (C.c_void_p * nv)(*[b.ptr for b in dsts])
+        vo = (C.c_void_p * nv)(*[(b.ptr if b is not None else None) for b in valid_outs]) if valid_outs else None
+        ca = (Calib * nv)(*calibs)
+        va = (View * nv)(*views)
+        _check(self.L.gs360_fisheye_views_u8(self.handle, sp, ca, Cn, 0, va, nv, float(lens_fov_deg), interp,
+                                             1 if mask_outside else 0, int(mask_value), dp, 0, vo, slot), self.L)
+
+    # -- hot path, host buffers (synchronous) -----------------------------------------------
+    def equirect_views(self, src, views, slot=0, interp=INTERP_LINEAR):
+        """src: H x W x C uint8 ndarray -> list of per-view ndarrays (height x width x C)."""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if src.ndim == 2:
+            src = src[:, :, None]
+        H, W, Cn = src.shape
+        outs = [np.empty((v.height, v.width, Cn), np.uint8) for v in views]
+        if not views:
+            return outs
+        va = (View * len(views))(*views)
+        dp = (C.c_void_p * len(views))(*[o.ctypes.data for o in outs])
+        with self.slot_locks[slot]:
+            _check(self.L.gs360_equirect_views_u8_host(self.handle, src.ctypes.data, W, H, Cn, src.strides[0], va,
+                                                       len(views), dp, 0, interp, 0, slot), self.L)
+        return outs
+
+    def remap(self, src, map_x, map_y, interpolation=INTERP_LINEAR, border_value=0.0, valid=None, fill_value=0,
+              slot=0):
+        """cv2.remap(src, map_x, map_y, interpolation, borderMode=BORDER_CONSTANT, borderValue=...) drop-in
+        (DF:2001-2008); `valid`/`fill_value` fuse the reference's `out[~valid] = mask_value` (DF:2009-2014)."""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        s3 = src if src.ndim == 3 else src[:, :, None]
+        H, W, Cn = s3.shape
+        mx = np.ascontiguousarray(map_x, dtype=np.float32)
+        my = np.ascontiguousarray(map_y, dtype=np.float32)
+        if mx.shape != my.shape or mx.ndim != 2:
+            raise ValueError("map_x / map_y must be 2-D arrays of equal shape")
+        h, w = mx.shape
+        if np.isscalar(border_value):
+            border_value = (float(border_value), 0.0, 0.0, 0.0)  # cv::Scalar(v)
+        bv = (C.c_double * 4)(*[float(b) for b in (list(border_value) + [0, 0, 0, 0])[:4]])
+        va = None
+        if valid is not None:
+            va = np.ascontiguousarray(valid, dtype=np.uint8)
+            if va.shape != (h, w):
+                raise ValueError("valid mask shape mismatch")
+        dst = np.empty((h, w, Cn), np.uint8)
+        with self.slot_locks[slot]:
+            _check(self.L.gs360_remap_table_u8_host(self.handle, s3.ctypes.data, H, W, Cn, s3.strides[0],
+                                                    mx.ctypes.data, my.ctypes.data,
+                                                    va.ctypes.data if va is not None else None, h, w,
+                                                    int(interpolation), bv, int(fill_value), dst.ctypes.data, 0, slot),
+                   self.L)
+        return dst if src.ndim == 3 else dst[:, :, 0]

@@ -1,0 +1,154 @@
+"""Process-wide execution engine behind run_one(): frames x views fanned out over the visible GPUs.
+
+Unit of work = (frame, view), exactly the reference's job granularity (PC:830-836).  Sharding is by FRAME:
+all views of one source image run on the same device, so the decoded frame is uploaded once and stays
+resident in HBM (an LRU of device frames per GPU); there is no exchange step and therefore no collective.
+Concurrency comes from the caller's thread pool (PC:1049 / gs360_GUI.py:19297): each call takes one of the
+device's stream slots.
+"""
+import collections
+import itertools
+import os
+import threading
+import zlib
+
+import numpy as np
+
+from . import capi, imageio
+from .jobspec import JobSpec
+
+_FRAME_CACHE_BYTES = int(os.environ.get("GS360_FRAME_CACHE_MB", "4096")) << 20
+_SLOTS_PER_DEVICE = 4
+
+
+class _DeviceState:
+    def __init__(self, device):
+        self.ctx = capi.Context(device=device, n_slots=_SLOTS_PER_DEVICE)
+        self.frames = collections.OrderedDict()   # key -> [DeviceBuffer, H, W, C, users]
+        self.frame_bytes = 0
+        self.lock = threading.Lock()              # guards the LRU bookkeeping
+        self.key_locks = {}                       # key -> lock: one decode+upload per frame
+        self.slot_cycle = itertools.cycle(range(_SLOTS_PER_DEVICE))
+
+
+class Engine:
+    def __init__(self, devices=None):
+        n = capi.device_count()
+        if n <= 0:
+            raise capi.Gs360Error(-3, "no MI355X visible: the gs360 engine has no CPU fallback "
+                                      "(use --engine ffmpeg to run the reference's ffmpeg path)")
+        want = os.environ.get("GS360_DEVICES")
+        if devices is None and want:
+            devices = [int(t) for t in want.split(",") if t.strip()]
+        self.devices = list(devices) if devices is not None else list(range(n))
+        self.states = [_DeviceState(d) for d in self.devices]
+        self._warned_cubic = False
+
+    def close(self):
+        for st in self.states:
+            st.ctx.close()
+        self.states = []
+
+    # -- sharding ---------------------------------------------------------------------------------
+    def device_for(self, src_path) -> int:
+        """frame -> device index (stable hash of the source path: all views of a frame share a device)."""
+        return zlib.crc32(os.fsencode(str(src_path))) % len(self.states)
+
+    # -- frame residency --------------------------------------------------------------------------
+    def _frame_key(self, path):
+        st = os.stat(path)
+        return (str(path), st.st_mtime_ns, st.st_size)
+
+    def resident_frame(self, st: _DeviceState, path):
+        key = self._frame_key(path)
+        with st.lock:
+            hit = st.frames.get(key)
+            if hit is not None:
+                st.frames.move_to_end(key)
+                hit[4] += 1
+                return hit
+            klock = st.key_locks.setdefault(key, threading.Lock())
+        with klock:
+            with st.lock:
+                hit = st.frames.get(key)
+                if hit is not None:
+                    hit[4] += 1
+                    return hit
+            img = imageio.read_image(path)
+            H, W, C = img.shape
+            if C not in (1, 3, 4):
+                raise capi.Gs360Error(-1, f"{path}: unsupported channel count {C}")
+            buf = st.ctx.alloc(img.nbytes)
+            st.ctx.upload(buf, img, slot=0, sync=True)
+            entry = [buf, H, W, C, 1]             # last field: users currently holding the frame
+            with st.lock:
+                st.frames[key] = entry
+                st.frame_bytes += img.nbytes
+                for k in list(st.frames):         # evict least-recently-used frames nobody is reading
+                    if st.frame_bytes <= _FRAME_CACHE_BYTES:
+                        break
+                    old = st.frames[k]
+                    if k == key or old[4] > 0:
+                        continue
+                    del st.frames[k]
+                    st.frame_bytes -= old[1] * old[2] * old[3]
+                    st.ctx.free(old[0])
+                st.key_locks.pop(key, None)
+            return entry
+
+    def release_frame(self, st: _DeviceState, entry):
+        with st.lock:
+            entry[4] -= 1
+
+    # -- one job ----------------------------------------------------------------------------------
+    def run_job(self, job: JobSpec):
+        """Execute one (frame, view) job; returns the output array after writing job.dst."""
+        if job.input_projection != "equirect" or job.output_projection != "rectilinear":
+            raise capi.Gs360Error(-4, f"v360 {job.input_projection}->{job.output_projection} is not implemented by "
+                                      "the HIP engine (only equirect->rectilinear); use --engine ffmpeg")
+        if abs(job.fnum("roll", 0.0)) > 1e-12:
+            raise capi.Gs360Error(-4, "roll != 0 is not implemented by the HIP engine")
+        if job.interp not in ("linear", "bilinear") and not self._warned_cubic:
+            self._warned_cubic = True
+            print(f"[INFO] gs360 engine: v360 interp={job.interp} requested; the HIP engine samples with 1/32-px "
+                  "fixed-point bilinear (cubic is not implemented yet)", flush=True)
+        view = capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"),
+                              job.width, job.height)
+        st = self.states[self.device_for(job.src)]
+        entry = self.resident_frame(st, job.src)
+        try:
+            buf, H, W, C = entry[:4]
+            with st.lock:
+                slot = next(st.slot_cycle)
+            out_bytes = view.height * view.width * C
+            with st.ctx.slot_locks[slot]:
+                dst = st.ctx.alloc(out_bytes)
+                try:
+                    st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot)
+                    out = st.ctx.download(dst, (view.height, view.width, C), slot=slot)
+                finally:
+                    st.ctx.free(dst)
+        finally:
+            self.release_frame(st, entry)
+        imageio.write_image(job.dst, out, jpeg_q=job.jpeg_q)
+        return out
+
+
+_engine = None
+_engine_lock = threading.Lock()
+
+
+def get_engine() -> Engine:
+    global _engine
+    with _engine_lock:
+        if _engine is None:
+            _engine = Engine()
+        return _engine
+
+
+def shutdown():
+    global _engine
+    with _engine_lock:
+        if _engine is not None:
+            _engine.close()
+            _engine = None

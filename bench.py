@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the 360PerspCut reprojection hot path on MI355X.
+
+Metric (BASELINE.json): MPix/s remapped, 8K equirect -> preset views; % of HBM roofline.
+Workload (BASELINE.json configs[1]): 7680x3840x3 uint8 equirect frames -> `--preset default --count 6
+--size 800` (6 x 800^2 views, f=12 mm -> hfov=vfov=112.62 deg), uint8 fixed-point bilinear.
+
+One "step" = ONE batched launch of gs360_equirect_views_u8 over `--frames` DISTINCT frames that are
+already resident in HBM (default 4 frames = 354 MB of source, more than the 256 MiB Infinity Cache, so
+successive steps cannot be served from it).  `value` = output pixels written by all ranks / wall time.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Frames x views shard with no exchange step, so every rank runs the same per-GPU workload (weak scaling)
+and no collective touches the data path; torch.distributed is used only for the barrier and the
+max-over-ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "360cam-pgm-3dgs-tools_amd"))
+
+W, H, C = 7680, 3840, 3
+N_VIEWS, SIZE = 6, 800
+HFOV = 112.61986494804043          # fov_from_focal_mm(12, 36)  (reference PC:77-78)
+# Algorithmic bytes of one frame of this workload:
+#   store 6*800*800*3 = 11,520,000 B  +  distinct source texels touched by the bilinear taps
+#   sum_v U_v = 14,325,324 texels * 3 B = 42,975,972 B   (counted by the oracle; tests/test_oracle_equirect.py)
+ALGO_BYTES_PER_FRAME = 11_520_000 + 14_325_324 * 3
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def norm_yaw(a):
+    a = ((a + 180.0) % 360.0) - 180.0
+    return 180.0 if abs(a + 180.0) < 1e-6 else a
+
+
+def view_table():
+    return [(norm_yaw(i * 360.0 / N_VIEWS), 0.0, HFOV, HFOV, SIZE, SIZE) for i in range(N_VIEWS)]
+
+
+_BASE = None
+
+
+def synth_frame(np, k):
+    """image B of SURVEY 8(d): smooth gradients + 64-px checker + per-pixel hash noise, rolled 13*k px."""
+    global _BASE
+    if _BASE is None:
+        x = np.arange(W, dtype=np.uint32)[None, :]
+        y = np.arange(H, dtype=np.uint32)[:, None]
+        img = np.empty((H, W, 3), np.uint8)
+        noise = (((x * np.uint32(2654435761)) ^ (y * np.uint32(40503))) >> np.uint32(27)).astype(np.uint8)
+        img[..., 0] = ((x * 255) // W).astype(np.uint8) + noise
+        img[..., 1] = ((y * 255) // H).astype(np.uint8) + noise
+        img[..., 2] = ((((x >> 6) + (y >> 6)) & 1) * 96).astype(np.uint8) + noise
+        _BASE = img
+    return np.ascontiguousarray(np.roll(_BASE, 13 * k, axis=1))
+
+
+def cpu_baseline(np, frame, budget_s=12.0):
+    """Oracle ("port" of the same arithmetic, oracle/gs360_oracle.c) on this box's host cores."""
+    from oracle import orc
+    orc.build()
+    views = [orc.make_view(*v) for v in view_table()]
+    cores = os.cpu_count() or 1
+    orc.equirect_views_u8(frame, views, threads=cores)          # warm (thread pool, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        outs = orc.equirect_views_u8(frame, views, threads=cores)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 400:
+            break
+    mpix = n * N_VIEWS * SIZE * SIZE / 1e6
+    return {"value": round(mpix / dt, 2), "unit": "MPix/s", "cores": cores, "kind": "port",
+            "sample": f"{n} passes of 1 frame x {N_VIEWS} views (same 8K->6x800^2 workload), {dt:.1f} s, "
+                      f"OpenMP over rows, {cores} threads"}, outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=4, help="distinct HBM-resident frames per step (one launch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or args.with_torch
+    dist = torch = None
+    if use_dist:
+        # torch first: its bundled HIP runtime has the same SONAME as the system one, so the engine
+        # library then binds to the runtime already in the process instead of loading a second copy.
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import gs360
+
+    ctx = gs360.Context(device=local_rank if use_dist else 0, n_slots=2)
+    info = ctx.info()
+    views = [gs360.View.make(*v) for v in view_table()]
+    nf = max(1, min(args.frames, gs360.capi.MAX_FRAMES))
+    frames_host = [synth_frame(np, k + 7 * rank) for k in range(nf)]
+    d_frames = [ctx.to_device(f) for f in frames_host]
+    d_out = [ctx.alloc(SIZE * SIZE * C) for _ in range(nf * N_VIEWS)]
+    step = ctx.make_equirect_call(d_frames, W, H, C, views, d_out, slot=0)
+
+    def barrier():
+        ctx.sync(-1)
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.event_record(0, 0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.event_record(0, 1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.event_elapsed_ms(0, 0, 1) / max(1, args.steps)   # HIP events on the launch stream
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness spot-check of what was timed (rank 0): frame 0 against the oracle, plus the CPU baseline
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu, want = cpu_baseline(np, frames_host[0])
+        got = [ctx.download(d_out[k], (SIZE, SIZE, C)) for k in range(N_VIEWS)]
+        parity = all(np.array_equal(g, w) for g, w in zip(got, want))
+        if not parity:
+            print("bench.py: GPU output differs from the oracle -- number is INVALID", file=sys.stderr)
+
+    if rank == 0:
+        px_per_step = nf * N_VIEWS * SIZE * SIZE
+        ms_per_step = elapsed * 1e3 / max(1, args.steps)
+        value = world * px_per_step * args.steps / elapsed / 1e6
+        algo_bytes = ALGO_BYTES_PER_FRAME * nf
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"        # written from rocprofv3 --pmc passes (see profiles/README.md)
+        if tf.exists():
+            try:
+                rec = json.loads(tf.read_text())
+                if rec.get("frames_per_launch") == nf:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MPix/s remapped, 8K equirect->preset views",
+            "value": round(value, 1), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "7680x3840x3 u8 equirect -> --preset default --count 6 --size 800 (6x800x800), "
+                                   "bilinear 1/32-px fixed point (BASELINE.json configs[1])",
+                       "frames_per_step": nf, "views": N_VIEWS, "out_px_per_step": px_per_step,
+                       "device": info["name"], "parallelism": f"frames sharded x{world}, no collective",
+                       "parity_vs_oracle": parity},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "eq_views_kernel<3>", "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": algo_bytes},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

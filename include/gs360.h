@@ -1,0 +1,150 @@
+/*
+ * gs360.h -- C ABI of libgs360hip.so, the MI355X (gfx950) reprojection engine.
+ *
+ * This is the drop-in boundary for the 360PerspCut hot path.  The reference is pure Python and has
+ * no FFI of its own; each entry point below replaces the native work the reference delegates to a
+ * third-party binary/wheel at the cited call site (paths are into the reference repository):
+ *
+ *   gs360_equirect_views_u8      one `ffmpeg -vf v360=input=equirect:output=rectilinear:...` process per
+ *                                (source, view): cli_tools/gs360_360PerspCut.py:310-314 (filter string),
+ *                                :569-590 (run_one -> Popen), :830-836 (one job per view).
+ *   gs360_remap_table_u8         cv2.remap(src, map_x, map_y, interp, borderMode=BORDER_CONSTANT,
+ *                                borderValue=float(mask_value)) followed by `out[~valid] = mask_value`:
+ *                                cli_tools/gs360_DualFisheyeDistortionCalibration.py:2001-2014 (image),
+ *                                :2031-2043 (mask, INTER_NEAREST), :1198-1212 (undistort).
+ *   gs360_fisheye_views_u8       the same call sites with the map of DF:1759-1823
+ *                                (build_direct_perspective_map_for_lens) evaluated in-kernel instead of
+ *                                being read from a table (FE-SPEC v1).
+ *
+ * Conventions: extern "C", plain pointers and sizes, POD structs, no exceptions across the boundary.
+ * Every function returns 0 on success or a negative gs360_status; gs360_last_error() returns the
+ * calling thread's last message.  The caller owns every buffer it passes in; the library never frees
+ * caller memory.  One ctx per device; calls on different ctx are fully concurrent; calls on one ctx
+ * are ordered per `slot` (each slot is a HIP stream) and are ASYNCHRONOUS unless stated otherwise --
+ * gs360_sync(ctx, slot) waits.  Images are interleaved HWC uint8, C in {1,3,4}.
+ */
+#ifndef GS360_H
+#define GS360_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS360_ABI_VERSION 1
+
+typedef enum gs360_status {
+    GS360_OK = 0,
+    GS360_ERR_ARG = -1,         /* bad argument (NULL, size, channels, slot ...) */
+    GS360_ERR_HIP = -2,         /* a HIP runtime call failed; text in gs360_last_error */
+    GS360_ERR_NODEV = -3,       /* no usable GPU */
+    GS360_ERR_UNSUPPORTED = -4, /* valid request this build does not implement */
+    GS360_ERR_NOMEM = -5
+} gs360_status;
+
+/* values equal cv2.INTER_NEAREST / cv2.INTER_LINEAR (DF:59-64) */
+#define GS360_INTERP_NEAREST 0
+#define GS360_INTERP_LINEAR 1
+
+/* limits of one batched launch (larger requests are split internally) */
+#define GS360_MAX_VIEWS 16
+#define GS360_MAX_FRAMES 16
+
+typedef struct gs360_ctx gs360_ctx;
+
+/* One output view: the numeric fields of ViewSpec (cli_tools/gs360_360PerspCut.py:32-45). */
+typedef struct gs360_view {
+    double yaw_deg;   /* + = look right */
+    double pitch_deg; /* + = look up */
+    double hfov_deg;
+    double vfov_deg;
+    int32_t width;
+    int32_t height;
+} gs360_view;
+
+/* SensorCalibration (cli_tools/gs360_DualFisheyeDistortionCalibration.py:67-85), numeric fields. */
+typedef struct gs360_calib {
+    int32_t width;
+    int32_t height;
+    double f, cx, cy, k1, k2, k3, k4, p1, p2, b1, b2;
+} gs360_calib;
+
+/* ---- library / device ---------------------------------------------------------------------- */
+int gs360_abi_version(void);
+int gs360_device_count(void);
+/* copies the calling thread's last error text (NUL terminated); returns its length */
+int gs360_last_error(char *buf, size_t buf_len);
+/* n_slots HIP streams are created (1..16) */
+int gs360_ctx_create(int device, int n_slots, gs360_ctx **out);
+int gs360_ctx_destroy(gs360_ctx *ctx);
+int gs360_device_info(gs360_ctx *ctx, char *name, size_t name_len, int32_t *cu_count, uint64_t *hbm_bytes);
+
+/* ---- memory (device buffers carry 64 B of readable slack after the requested size) --------- */
+int gs360_dev_alloc(gs360_ctx *ctx, size_t bytes, void **dptr);
+int gs360_dev_free(gs360_ctx *ctx, void *dptr);
+int gs360_host_alloc(gs360_ctx *ctx, size_t bytes, void **hptr); /* pinned */
+int gs360_host_free(gs360_ctx *ctx, void *hptr);
+int gs360_upload(gs360_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, int slot);
+int gs360_download(gs360_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, int slot);
+int gs360_dev_memset(gs360_ctx *ctx, void *dst_dev, int value, size_t bytes, int slot);
+int gs360_sync(gs360_ctx *ctx, int slot); /* slot < 0: every slot */
+
+/* ---- timing: HIP events recorded on the slot's own stream (8 events per slot) -------------- */
+int gs360_event_record(gs360_ctx *ctx, int slot, int event_idx);
+int gs360_event_elapsed_ms(gs360_ctx *ctx, int slot, int event_from, int event_to, float *ms); /* syncs on event_to */
+
+/* ---- hot path: device-resident buffers, asynchronous --------------------------------------- */
+
+/*
+ * Equirectangular -> rectilinear views.  For every frame f < n_frames and view k < n_views writes
+ * dst[f * n_views + k] (views[k].height x views[k].width x C, row stride dst_stride bytes, 0 = tight).
+ * src_frames[f]: H x W x C equirect image, row stride src_stride bytes (0 = tight).
+ * Geometry: EQ-SPEC v1: pinhole ray -> pitch about X -> yaw about Y -> lon/lat ->
+ * 1/32-px fixed-point bilinear; horizontal border wraps, vertical border clamps.
+ * interp must be GS360_INTERP_LINEAR.  flags: 0.
+ */
+int gs360_equirect_views_u8(gs360_ctx *ctx, const void *const *src_frames, int n_frames,
+                            int W, int H, int C, size_t src_stride,
+                            const gs360_view *views, int n_views,
+                            void *const *dst, size_t dst_stride,
+                            int interp, uint32_t flags, int slot);
+
+/*
+ * cv2.remap with float32 maps, BORDER_CONSTANT; then, if valid != NULL, dst[~valid] = fill_value
+ * on all channels.  src: H x W x C; map_x/map_y/valid: h x w (tight); dst: h x w x C.
+ * border_value: 4 doubles (cv::Scalar; Python's borderValue=float(v) is {v,0,0,0}).
+ * All pointers are device pointers.  H, W < 32767 (cv2.remap's own limit).
+ */
+int gs360_remap_table_u8(gs360_ctx *ctx, const void *src, int H, int W, int C, size_t src_stride,
+                         const float *map_x, const float *map_y, const uint8_t *valid, int h, int w,
+                         int interp, const double *border_value, int fill_value,
+                         void *dst, size_t dst_stride, int slot);
+
+/*
+ * Dual-fisheye -> perspective views with the map evaluated in-kernel (FE-SPEC v1).  View k samples
+ * src_lens[k] (H x W x C of calibs[k]) with views[k].yaw_deg measured RELATIVE to that lens
+ * (DF:1883).  Pixels outside the lens model / sensor get mask_value on all channels when
+ * mask_outside != 0 (DF:2009-2014); border taps use {mask_value,0,0,0} as cv2 does.
+ * valid_out[k] (h x w uint8, may be NULL / may contain NULLs) receives the validity mask.
+ */
+int gs360_fisheye_views_u8(gs360_ctx *ctx, const void *const *src_lens, const gs360_calib *calibs,
+                           int C, size_t src_stride,
+                           const gs360_view *views, int n_views, double lens_fov_deg,
+                           int interp, int mask_outside, int mask_value,
+                           void *const *dst, size_t dst_stride, uint8_t *const *valid_out, int slot);
+
+/* ---- host-buffer conveniences (synchronous: H2D -> kernel -> D2H on `slot`) ----------------- */
+int gs360_equirect_views_u8_host(gs360_ctx *ctx, const uint8_t *src, int W, int H, int C, size_t src_stride,
+                                 const gs360_view *views, int n_views,
+                                 uint8_t *const *dst, size_t dst_stride, int interp, uint32_t flags, int slot);
+int gs360_remap_table_u8_host(gs360_ctx *ctx, const uint8_t *src, int H, int W, int C, size_t src_stride,
+                              const float *map_x, const float *map_y, const uint8_t *valid, int h, int w,
+                              int interp, const double *border_value, int fill_value,
+                              uint8_t *dst, size_t dst_stride, int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS360_H */

@@ -1,0 +1,197 @@
+"""-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle, bit-exact uint8."""
+import numpy as np
+import pytest
+
+import gs360
+from util import (FULL_CALIB, HFOV_12MM, HFOV_14MM, HFOV_17MM, PRESET_FISHEYELIKE, PRESET_FULL360, TEMPLATE_CALIB,
+                  rand_image, ring_views)
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_both(ctx, orc, src, specs):
+    got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs])
+    want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], threads=0)
+    return got, want
+
+
+def _assert_same(got, want, what):
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape
+        if not np.array_equal(g, w):
+            bad = np.argwhere(g != w)
+            d = np.abs(g.astype(int) - w.astype(int))
+            raise AssertionError(f"{what}: view {k}: {len(bad)} mismatching bytes of {g.size}, max |d|={d.max()}, "
+                                 f"first at {bad[0].tolist()}")
+
+
+# ---- equirect ---------------------------------------------------------------------------------
+def test_equirect_cfg2_ring_small_source(ctx, orc):
+    src = rand_image(480, 960)
+    got, want = _eq_both(ctx, orc, src, ring_views(6, 200, HFOV_12MM))
+    _assert_same(got, want, "cfg2-shaped ring on 960x480")
+
+
+@pytest.mark.parametrize("name,layout,hfov", [("full360coverage", PRESET_FULL360, HFOV_14MM),
+                                              ("fisheyelike", PRESET_FISHEYELIKE, HFOV_17MM)])
+def test_equirect_presets_pitched(ctx, orc, name, layout, hfov):
+    src = rand_image(512, 1024, seed=7)
+    specs = [(y, p, hfov, hfov, 160, 160) for y, p in layout]
+    got, want = _eq_both(ctx, orc, src, specs)
+    _assert_same(got, want, name)
+
+
+def test_equirect_poles_seam_and_odd_shapes(ctx, orc):
+    src = rand_image(301, 602, seed=3)  # odd height, width not a multiple of 4
+    specs = [(0, 90, 100, 100, 96, 96), (0, -90, 100, 100, 96, 96), (180, 0, 120, 90, 130, 70),
+             (-179.9, 45, 60, 60, 33, 47), (37.3, -62.1, 150, 140, 101, 99), (12, 5, 1, 1, 16, 16),
+             (0, 0, 179.9, 179.9, 64, 64), (720.5, 0, 90, 90, 31, 5), (90, 89.999, 90, 90, 40, 40)]
+    got, want = _eq_both(ctx, orc, src, specs)
+    _assert_same(got, want, "poles/seam/odd")
+
+
+@pytest.mark.parametrize("channels", [1, 4])
+def test_equirect_channels(ctx, orc, channels):
+    src = rand_image(256, 512, c=channels, seed=11)
+    specs = [(30, 10, 100, 80, 120, 88), (-150, -40, 90, 90, 64, 64)]
+    got, want = _eq_both(ctx, orc, src, specs)
+    _assert_same(got, want, f"C={channels}")
+
+
+def test_equirect_full_size_8k_default6(ctx, orc):
+    """BASELINE cfg2 at full size: 7680x3840 -> 6 x 800^2, every byte."""
+    src = rand_image(3840, 7680)
+    got, want = _eq_both(ctx, orc, src, ring_views(6, 800, HFOV_12MM))
+    _assert_same(got, want, "cfg2 full size")
+
+
+def test_equirect_batched_frames_device_api(ctx, orc):
+    """n_frames x n_views in ONE launch through the device-pointer entry point."""
+    H, W = 300, 600
+    frames = [rand_image(H, W, seed=100 + f) for f in range(3)]
+    specs = ring_views(5, 96, 100.0) + [(10, 40, 100, 100, 96, 96)]
+    views = [gs360.View.make(*s) for s in specs]
+    dfr = [ctx.to_device(f) for f in frames]
+    dsts = [ctx.alloc(96 * 96 * 3) for _ in range(len(frames) * len(views))]
+    ctx.equirect_views_dev(dfr, W, H, 3, views, dsts, slot=1)
+    ctx.sync(1)
+    for f, fr in enumerate(frames):
+        want = orc.equirect_views_u8(fr, [orc.make_view(*s) for s in specs])
+        got = [ctx.download(dsts[f * len(views) + k], (96, 96, 3), slot=1) for k in range(len(views))]
+        _assert_same(got, want, f"frame {f}")
+    for b in dfr + dsts:
+        ctx.free(b)
+
+
+def test_equirect_many_views_split(ctx, orc):
+    """more than GS360_MAX_VIEWS views -> split into several launches internally"""
+    src = rand_image(200, 400, seed=5)
+    specs = ring_views(30, 40, 80.0)
+    got, want = _eq_both(ctx, orc, src, specs)
+    _assert_same(got, want, "30 views")
+
+
+def test_equirect_empty_and_errors(ctx):
+    src = rand_image(64, 128)
+    assert ctx.equirect_views(src, []) == []
+    with pytest.raises(gs360.Gs360Error):
+        ctx.equirect_views(src[:, :, :2], [gs360.View.make(0, 0, 90, 90, 8, 8)])  # C == 2
+    with pytest.raises(gs360.Gs360Error):
+        ctx.equirect_views(src, [gs360.View.make(0, 0, 90, 90, 0, 8)])
+    with pytest.raises(gs360.Gs360Error):
+        ctx.equirect_views(src, [gs360.View.make(float("nan"), 0, 90, 90, 8, 8)])
+    with pytest.raises(gs360.Gs360Error):
+        ctx.equirect_views(src, [gs360.View.make(0, 0, 90, 90, 8, 8)], interp=gs360.INTERP_NEAREST)
+
+
+# ---- table remap (cv2.remap semantics) ----------------------------------------------------------
+def _rand_maps(h, w, H, W, seed, spread=12.0):
+    rng = np.random.default_rng(seed)
+    mx = rng.uniform(-spread, W + spread, size=(h, w)).astype(np.float32)
+    my = rng.uniform(-spread, H + spread, size=(h, w)).astype(np.float32)
+    # exact half-bucket ties, integers, borders
+    mx[0, : min(w, 8)] = np.array([0.0, -1.0, W - 1.0, W - 0.5, 1 / 64, 3 / 64, -0.015625, W + 5.0], np.float32)[: min(w, 8)]
+    my[0, : min(w, 8)] = np.array([0.0, -1.0, H - 1.0, H - 0.5, 1 / 64, 3 / 64, -0.015625, 2.0], np.float32)[: min(w, 8)]
+    return mx, my
+
+
+@pytest.mark.parametrize("channels", [1, 3, 4])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_table_remap_random_maps(ctx, orc, channels, interp):
+    H, W, h, w = 97, 131, 75, 108
+    src = rand_image(H, W, c=channels, seed=21)
+    mx, my = _rand_maps(h, w, H, W, seed=22)
+    mx[3, 5] = np.nan
+    my[4, 6] = np.inf
+    mx[5, 7] = -3e9
+    my[6, 8] = 1e30
+    valid = np.random.default_rng(23).random((h, w)) > 0.1
+    bv = (37.0, 0.0, 0.0, 0.0)
+    got = ctx.remap(src, mx, my, interpolation=interp, border_value=bv, valid=valid, fill_value=200)
+    want = orc.remap_u8(src, mx, my, interp=interp, border_value=bv)
+    want = orc.valid_fill(want.copy(), valid, 200)
+    _assert_same([got.reshape(h, w, channels)], [want.reshape(h, w, channels)], f"table C={channels} interp={interp}")
+
+
+def test_table_remap_gray_2d_and_scalar_border(ctx, orc):
+    src = rand_image(64, 80, c=1, seed=31)[:, :, 0]
+    mx, my = _rand_maps(50, 44, 64, 80, seed=32)
+    got = ctx.remap(src, mx, my, interpolation=1, border_value=255.0)
+    want = orc.remap_u8(src, mx, my, interp=1, border_value=255.0)
+    assert got.shape == (50, 44)
+    assert np.array_equal(got, want)
+
+
+def test_table_remap_identity_and_shifts(ctx):
+    """hand-derivable known answers straight on the GPU path"""
+    src = rand_image(40, 64, seed=41)
+    yy, xx = np.meshgrid(np.arange(40, dtype=np.float32), np.arange(64, dtype=np.float32), indexing="ij")
+    assert np.array_equal(ctx.remap(src, xx, yy), src)
+    assert np.array_equal(ctx.remap(src, xx + np.float32(1 / 64), yy), src)          # 32x+0.5 -> even -> fx=0
+    half = ctx.remap(src, xx + np.float32(0.5), yy, border_value=(0, 0, 0, 0))
+    want = (src[:, :-1].astype(int) + src[:, 1:].astype(int) + 1) >> 1
+    assert np.array_equal(half[:, :-1], want)
+    assert np.array_equal(half[:, -1], (src[:, -1].astype(int) + 1) >> 1)             # right tap = border 0
+
+
+def test_table_remap_fisheye_maps_from_oracle(ctx, orc):
+    """cfg4-shaped: template calibration, oracle-built DF maps, 3 SFM10 views at reduced size"""
+    cal = orc.make_calib(**{**TEMPLATE_CALIB, "width": 960, "height": 960, "f": TEMPLATE_CALIB["f"] / 4})
+    src = rand_image(960, 960, seed=51)
+    for yaw, pitch in [(0, 0), (0, 40), (40, 0), (140, 0)]:
+        mx, my, valid = orc.fisheye_map(cal, yaw, pitch, HFOV_14MM, HFOV_14MM, 350, 350, 190.0)
+        got = ctx.remap(src, mx, my, interpolation=1, border_value=0.0, valid=valid, fill_value=0)
+        want = orc.valid_fill(orc.remap_u8(src, mx, my, interp=1, border_value=0.0), valid, 0)
+        _assert_same([got], [want], f"fisheye table yaw={yaw} pitch={pitch}")
+
+
+# ---- fused fisheye (FE-SPEC v1) ---------------------------------------------------------------
+@pytest.mark.parametrize("calib_kw,size", [(TEMPLATE_CALIB, 3840), (FULL_CALIB, None)])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_fisheye_fused_vs_oracle_spec(ctx, orc, calib_kw, size, interp):
+    kw = dict(calib_kw)
+    if size:  # shrink the template sensor 8x to keep the test light
+        kw.update(width=480, height=480, f=kw["f"] / 8)
+    ocal = orc.make_calib(**kw)
+    gcal = gs360.Calib.make(**kw)
+    H, W = kw["height"], kw["width"]
+    src = rand_image(H, W, seed=61)
+    specs = [(0, 0, HFOV_14MM, HFOV_14MM, 120, 120), (0, 40, HFOV_14MM, HFOV_14MM, 120, 120),
+             (40, 0, HFOV_14MM, HFOV_14MM, 120, 120), (140, 0, HFOV_14MM, HFOV_14MM, 120, 120),
+             (-72.5, 33.25, 75.0, 110.0, 130, 66), (10, 5, 30, 20, 47, 33)]
+    dsrc = ctx.to_device(src)
+    dsts = [ctx.alloc(s[4] * s[5] * 3) for s in specs]
+    vouts = [ctx.alloc(s[4] * s[5]) for s in specs]
+    ctx.fisheye_views_dev([dsrc] * len(specs), [gcal] * len(specs), 3, [gs360.View.make(*s) for s in specs], 190.0, dsts,
+                          valid_outs=vouts, interp=interp, mask_outside=True, mask_value=9)
+    ctx.sync(0)
+    for k, s in enumerate(specs):
+        mx, my, valid = orc.fisheye_spec_map(ocal, s[0], s[1], s[2], s[3], s[4], s[5], 190.0)
+        want = orc.valid_fill(orc.remap_u8(src, mx, my, interp=interp, border_value=9.0), valid, 9)
+        got = ctx.download(dsts[k], (s[5], s[4], 3))
+        gv = ctx.download(vouts[k], (s[5], s[4]))
+        assert np.array_equal(gv.astype(bool), valid), f"valid mask view {k}"
+        _assert_same([got], [want], f"fused fisheye view {k} interp={interp}")
+    for b in [dsrc] + dsts + vouts:
+        ctx.free(b)
