@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+# -*- coding: utf-8 -*-
+"""gs360_360PerspCut -- MI355X drop-in for the reference tool of the same name.
+
+Same module surface the GUI and the other tools bind to (reference gs360_GUI.py:54, :301, :2090, :18850,
+:19299; gs360_Video2Frames.py:26): create_arg_parser, build_view_jobs, run_one, stop_event, procs_lock,
+running_procs, parse_jobs, detect_input_bit_depth, EXTS, PROGRESS_INTERVAL, ViewSpec, BuildResult,
+fov_from_focal_mm, v_fov_from_hfov.  Same flags, preset names, stdout lines, exit codes and output layout
+(reference cli_tools/gs360_360PerspCut.py:417-532, :983-1087).
+
+What changed underneath: run_one() no longer spawns one single-threaded `ffmpeg -vf v360=...` process per
+(source, view) (reference :569-590).  It parses the ffmpeg-shaped job argv and executes still-image
+equirect->rectilinear jobs in-process on the GPU through libgs360hip.so (hand-written HIP, gfx950).  Jobs the
+engine does not cover (video inputs, the fisheyeXY equisolid output) and `--engine ffmpeg` /
+GS360_ENGINE=ffmpeg keep the reference's subprocess path.
+"""
+import argparse
+import json
+import os
+import pathlib
+import shlex
+import shutil
+import signal
+import subprocess
+import sys
+import threading
+from concurrent.futures import ThreadPoolExecutor, as_completed
+from typing import List, Tuple
+
+_HERE = pathlib.Path(__file__).resolve().parent
+if str(_HERE.parent) not in sys.path:
+    sys.path.insert(0, str(_HERE.parent))
+
+from gs360 import planner as _planner  # noqa: E402
+from gs360.jobspec import JobParseError, parse_job_argv  # noqa: E402
+from gs360.planner import (BuildResult, ViewSpec, build_ffmpeg_cmd, build_ffmpeg_equisolid_cmd,  # noqa: E402,F401
+                           clamp, extra_suffix, focal_from_hfov_deg, fov_from_focal_mm, letter_tag,
+                           letter_to_index1, map_interp_for_v360, normalize_angle_deg, parse_addcam_spec,
+                           parse_delcam_spec, parse_sensor, parse_sensor_dimensions, parse_setcam_spec,
+                           v_fov_from_hfov)
+
+EXTS = {".tif", ".tiff", ".jpg", ".jpeg", ".png"}
+PROGRESS_INTERVAL = 5
+
+
+class StoreWithFlag(argparse.Action):
+    """Stores the value and marks `<dest>_explicit` so presets only override untouched options (PC:24-29)."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        setattr(namespace, self.dest, values)
+        setattr(namespace, f"{self.dest}_explicit", True)
+
+
+def update_progress(label: str, completed: int, total: int, last_pct: int) -> int:
+    if total <= 0:
+        return last_pct
+    pct = int((completed * 100) / total)
+    if last_pct < 0 or pct >= 100 or (pct - last_pct) >= PROGRESS_INTERVAL:
+        sys.stdout.write(f"{label}... {pct:3d}% ({completed}/{total})\r")
+        sys.stdout.flush()
+        return pct
+    return last_pct
+
+
+_HIGH_DEPTH_TOKENS = ("p10", "p12", "p14", "p16", "p010", "p012", "p016", "gbrp10", "gbrp12", "gbrp14", "gbrp16",
+                      "rgb48", "rgba64")
+
+
+def detect_input_bit_depth(in_path: pathlib.Path) -> int:
+    """Nominal bit depth of a video's first stream via ffprobe; 8 when unknown (PC:111-149)."""
+    if not shutil.which("ffprobe"):
+        return 8
+    try:
+        res = subprocess.run(["ffprobe", "-v", "error", "-select_streams", "v:0", "-show_entries",
+                              "stream=bits_per_raw_sample,pix_fmt", "-of", "json", str(in_path)],
+                             check=True, capture_output=True, text=True)
+        stream = (json.loads(res.stdout or "{}").get("streams") or [{}])[0]
+        raw = stream.get("bits_per_raw_sample")
+        if isinstance(raw, str) and raw.isdigit():
+            return int(raw) if int(raw) >= 9 else 8
+        if any(tok in (stream.get("pix_fmt") or "") for tok in _HIGH_DEPTH_TOKENS):
+            return 10
+    except Exception:
+        pass
+    return 8
+
+
+def create_arg_parser() -> argparse.ArgumentParser:
+    """The reference's argument surface (PC:417-532) plus one additive option, --engine."""
+    ap = argparse.ArgumentParser(
+        description=("Batch convert equirectangular images with ffmpeg/v360, "
+                     "including optional virtual camera add/delete/set operations."),
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+        epilog=("Notes: presets can be overridden with --focal-mm / --size / --sensor-mm. "
+                "Priority: --hfov overrides --focal-mm. "
+                "Use --setcam to specify absolute or relative pitch values per camera."))
+    ap.add_argument("-i", "--in", dest="input_dir", required=True,
+                    help="Input folder (equirectangular images) or a video file containing equirectangular frames")
+    ap.add_argument("-o", "--out", dest="out_dir", default=None,
+                    help="Output folder. Defaults to <input>/_geometry if omitted")
+    ap.add_argument("--preset", choices=list(_planner.PRESET_NAMES), default="default",
+                    help=("default=8-view baseline / "
+                          "fisheyelike=10-view mix (auto focal 17mm, custom deletions/additions) / "
+                          "full360coverage=8-view wide cover (auto focal 14mm, del B,D,F,H add B,D,F,H) / "
+                          "2views=front/back only (6mm focal, 3600px) / "
+                          "evenMinus30=even slots pitch -30deg / "
+                          "evenPlus30=even slots pitch +30deg / "
+                          "fisheyeXY=fisheye X/Y pair only (Equisolid 3600px FOV180)"))
+    ap.add_argument("--count", type=int, default=8, help="Horizontal division count (4=90deg, 8=45deg)")
+    ap.add_argument("--addcam", default="",
+                    help="Add virtual cameras, e.g. 'B' (+/-default pitch), 'B:U', 'D:D20', 'F:U15' (comma separated)")
+    ap.add_argument("--addcam-deg", type=float, default=30.0,
+                    help="Default magnitude in degrees when 'U/D' in --addcam/--setcam omit a value (default 30)")
+    ap.add_argument("--add-top", action="store_true", help="Include cube-map style top view (pitch +90 deg)")
+    ap.add_argument("--add-bottom", action="store_true", help="Include cube-map style bottom view (pitch -90 deg)")
+    ap.add_argument("--add-topdown", action="store_true", dest="add_topdown", help=argparse.SUPPRESS)
+    ap.add_argument("--delcam", default="", help="Remove baseline cameras by letter, e.g. 'B,D'")
+    ap.add_argument("--setcam", default="",
+                    help="Override/adjust baseline pitch. Absolute: 'A=30','A=U','A=D20'. Relative: 'A:+10','B:-5'.")
+    ap.add_argument("--size", type=int, default=1600, action=StoreWithFlag, help="Square output size per view")
+    ap.add_argument("--ext", default="jpg", help="Output extension (jpg=high quality mjpeg)")
+    ap.add_argument("--jpeg-quality-95", action="store_true",
+                    help="When set with --ext jpg, encode outputs at approximately 95% JPEG quality instead of maximum.")
+    ap.add_argument("-f", "--fps", type=float, default=None,
+                    help="Frame extraction rate (fps) when input is a video file")
+    ap.add_argument("--start", type=float, default=None, help="Optional start time in seconds when input is a video file")
+    ap.add_argument("--end", type=float, default=None, help="Optional end time in seconds when input is a video file")
+    ap.add_argument("--keep-rec709", action="store_true",
+                    help="Keep Rec.709 transfer characteristics for video inputs (default: convert to sRGB)")
+    ap.add_argument("--hfov", type=float, default=None, action=StoreWithFlag,
+                    help="Horizontal FOV in degrees (overrides focal length)")
+    ap.add_argument("--focal-mm", type=float, default=12.0, action=StoreWithFlag,
+                    help="Focal length in millimetres when --hfov is not set")
+    ap.add_argument("--sensor-mm", default="36 36", help="Sensor width/height in millimetres, e.g. '36 36' or '36x24'")
+    ap.add_argument("-j", "--jobs", default="auto",
+                    help="Concurrent ffmpeg processes (number or 'auto'=physical cores/2)")
+    ap.add_argument("--print-cmd", choices=["once", "none", "all"], default="once",
+                    help="How many ffmpeg commands to print: once/none/all")
+    ap.add_argument("--ffmpeg", default="ffmpeg", help="Path to the ffmpeg executable")
+    ap.add_argument("--dry-run", action="store_true", help="Print all commands without executing them")
+    # additive: engine selection (default = GS360_ENGINE or the HIP engine)
+    ap.add_argument("--engine", choices=["hip", "ffmpeg"], default=None,
+                    help="Executor for the planned jobs: hip = in-process MI355X engine, ffmpeg = reference subprocess path")
+    return ap
+
+
+# ---- parallel execution and cancellation (PC:535-590) ------------------------------------------------
+stop_event = threading.Event()
+procs_lock = threading.Lock()
+running_procs = set()
+
+sig_hits = 0
+_engine_choice = None  # set by main(); None -> environment / default
+
+
+def on_signal(sig, frame):
+    global sig_hits
+    sig_hits += 1
+    if not stop_event.is_set():
+        print("\n[INFO] Cancel requested. Stopping new jobs and terminating running processes...", file=sys.stderr)
+        stop_event.set()
+    with procs_lock:
+        for p in list(running_procs):
+            try:
+                p.terminate() if sig_hits == 1 else p.kill()
+            except Exception:
+                pass
+    if sig_hits >= 2:
+        print("[INFO] Force exiting", file=sys.stderr)
+
+
+try:
+    if threading.current_thread() is threading.main_thread():
+        signal.signal(signal.SIGINT, on_signal)
+        signal.signal(signal.SIGTERM, on_signal)
+        if os.name == "nt" and hasattr(signal, "SIGBREAK"):
+            signal.signal(signal.SIGBREAK, on_signal)
+except Exception:
+    pass
+
+
+def parse_jobs(s: str) -> int:
+    if str(s).lower() == "auto":
+        return max(1, (os.cpu_count() or 1) // 2)
+    return max(1, int(s))
+
+
+def _selected_engine() -> str:
+    return (_engine_choice or os.environ.get("GS360_ENGINE") or "hip").lower()
+
+
+def _run_subprocess(cmd: List[str]) -> Tuple[int, str]:
+    """The reference's executor: one external process per job, polled so cancellation lands within 0.5 s."""
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    except OSError as exc:
+        return 127, f"{cmd[0]}: {exc}"
+    with procs_lock:
+        running_procs.add(proc)
+    try:
+        while True:
+            try:
+                rc = proc.wait(timeout=0.5)
+                break
+            except subprocess.TimeoutExpired:
+                if stop_event.is_set():
+                    try:
+                        proc.terminate()
+                    except Exception:
+                        pass
+        return rc, (proc.stderr.read() or b"").decode(errors="ignore")
+    finally:
+        with procs_lock:
+            running_procs.discard(proc)
+
+
+def run_one(cmd: List[str]) -> Tuple[int, str]:
+    """Execute one planned job.  Never raises: returns (rc, stderr_text); rc 0 ok, 130 cancelled (PC:569-590)."""
+    if stop_event.is_set():
+        return 130, ""
+    if _selected_engine() == "ffmpeg":
+        return _run_subprocess(cmd)
+    try:
+        job = parse_job_argv(list(cmd))
+    except JobParseError as exc:
+        return 2, f"gs360: cannot interpret job argv: {exc}"
+    if not job.is_still_image or job.output_projection != "rectilinear":
+        # video decode and the equisolid pair are outside the HIP engine's scope: reference path
+        return _run_subprocess(cmd)
+    try:
+        from gs360 import engine as _engine
+        _engine.get_engine().run_job(job)
+    except Exception as exc:  # noqa: BLE001  (boundary: HIP / IO errors become rc + text)
+        return 1, f"gs360: {type(exc).__name__}: {exc}"
+    if stop_event.is_set():
+        return 130, ""
+    return 0, ""
+
+
+def build_view_jobs(args, files: List[pathlib.Path], out_dir: pathlib.Path) -> BuildResult:
+    """Compose job definitions and view specifications (planning only, PC:593-980)."""
+    return _planner.build_view_jobs(args, files, out_dir, stop_event=stop_event)
+
+
+# ---- main (PC:983-1087) --------------------------------------------------------------------------------
+def _print_cmd(cmd):
+    print("$ " + " ".join(shlex.quote(c) for c in cmd))
+
+
+def main():
+    global _engine_choice
+    args = create_arg_parser().parse_args()
+    for attr in ("size", "hfov", "focal_mm"):
+        setattr(args, f"{attr}_explicit", getattr(args, f"{attr}_explicit", False))
+    _engine_choice = args.engine
+
+    input_path = pathlib.Path(args.input_dir).expanduser().resolve()
+    if input_path.is_dir():
+        args.input_is_video, args.video_bit_depth = False, 8
+        out_dir = pathlib.Path(args.out_dir).resolve() if args.out_dir else (input_path / "_geometry")
+        out_dir.mkdir(parents=True, exist_ok=True)
+        files = [p for p in sorted(input_path.iterdir()) if p.is_file() and p.suffix.lower() in EXTS]
+        if not files:
+            print("[WARN] No target images found (tif/jpg/png)", file=sys.stderr)
+            sys.exit(0)
+    elif input_path.is_file():
+        args.input_is_video = True
+        if args.fps is None or args.fps <= 0:
+            print("[ERR] -f/--fps must be specified for video inputs", file=sys.stderr)
+            sys.exit(1)
+        out_dir = pathlib.Path(args.out_dir).resolve() if args.out_dir else (
+            input_path.parent / f"{input_path.stem}_geometry")
+        out_dir.mkdir(parents=True, exist_ok=True)
+        args.video_bit_depth = detect_input_bit_depth(input_path)
+        files = [input_path]
+    else:
+        print("[ERR] Input path not found:", input_path, file=sys.stderr)
+        sys.exit(1)
+
+    result = build_view_jobs(args, files, out_dir)
+    jobs_list, total = result.jobs, result.total
+
+    if args.dry_run:
+        for cmd, _, _ in jobs_list:
+            _print_cmd(cmd)
+        print(f"\n[DRY] Exiting without execution (total {total} commands)")
+        return
+
+    if args.print_cmd == "all":
+        for cmd, _, _ in jobs_list:
+            _print_cmd(cmd)
+    elif args.print_cmd == "once" and jobs_list:
+        _print_cmd(jobs_list[0][0])
+
+    jobs = parse_jobs(args.jobs)
+    print(f"[INFO] parallel jobs: {jobs} / total: {total}")
+    if result.preview_views_line:
+        print(result.preview_views_line)
+        for line in (result.sensor_line, result.realityscan_line, result.metashape_line):
+            if line:
+                print(line)
+
+    ok = fail = done = 0
+    last_pct = -1
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        futures = [pool.submit(run_one, cmd) for cmd, _, _ in jobs_list]
+        for fut, (_, _src, dst) in zip(as_completed(futures), jobs_list):
+            rc, err = fut.result()
+            done += 1
+            if rc == 0:
+                ok += 1
+                last_pct = update_progress("Progress", done, total, last_pct)
+                continue
+            fail += 1
+            if stop_event.is_set():
+                continue
+            if total:
+                last_pct = update_progress("Progress", done, total, last_pct)
+                sys.stdout.write("\n")
+                sys.stdout.flush()
+            print(f"[{done}/{total}] {dst} {'canceled' if rc == 130 else 'failed'}", file=sys.stderr)
+            if err.strip():
+                print(err.strip(), file=sys.stderr)
+    if total and last_pct >= 0:
+        sys.stdout.write("\n")
+        sys.stdout.flush()
+
+    if stop_event.is_set():
+        print(f"[STOPPED] Interrupted: success={ok}, failed={fail}, total={total}")
+        sys.exit(130)
+    print(f"[OK] Completed: success={ok}, failed={fail}, total={total}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""Pins EQ-SPEC v1 (oracle side) against a float64 evaluation of the reference's own convention
+(gs360_GUI.py:377-395 direction_from_uv, :419-424 lonlat_to_xy).  Parity is UNPINNED against ffmpeg v360
+(absent, unpinned third-party binary); what is pinned is the geometry convention and the quantisation error."""
+import numpy as np
+import pytest
+
+from util import HFOV_12MM, PRESET_FULL360, HFOV_14MM, rand_image, ring_views
+
+
+def truth_xy(spec, W, H):
+    yaw, pitch, hfov, vfov, w, h = spec
+    i = np.arange(w)[None, :]
+    j = np.arange(h)[:, None]
+    u = ((i + 0.5) / w) * 2 - 1
+    v = ((j + 0.5) / h) * 2 - 1
+    hf = np.radians(min(max(hfov, 1e-3), 179.9))
+    vf = np.radians(min(max(vfov, 1e-3), 179.9))
+    x = np.tan(hf / 2) * u + 0 * v
+    y = np.tan(vf / 2) * (-v) + 0 * u
+    z = np.ones_like(x)
+    n = np.sqrt(x * x + y * y + z * z)
+    x, y, z = x / n, y / n, z / n
+    p, yw = np.radians(pitch), np.radians(yaw)
+    y1 = np.cos(p) * y + np.sin(p) * z
+    z1 = -np.sin(p) * y + np.cos(p) * z
+    x2 = np.cos(yw) * x + np.sin(yw) * z1
+    z2 = -np.sin(yw) * x + np.cos(yw) * z1
+    lon = np.arctan2(x2, z2)
+    lat = np.arcsin(np.clip(y1, -1, 1))
+    return (lon / (2 * np.pi) + 0.5) * W - 0.5, (0.5 - lat / np.pi) * H - 0.5, lat
+
+
+CASES = [(0, 0), (60, 0), (180, 0), (-120, 0), (45, 30), (135, -30), (-45, -30), (0, 90), (0, -90), (17.3, -62.1),
+         (359.5, 12.0)]
+
+
+@pytest.mark.parametrize("yaw,pitch", CASES)
+def test_quantised_map_is_the_rounded_truth(orc, yaw, pitch):
+    """sx/32, sy/32 must equal the float64 truth rounded to 1/32 px, except where the truth sits within
+    2e-4 px of a bucket boundary (float32 evaluation error; < 0.2 % of pixels)."""
+    W, H = 7680, 3840
+    spec = (yaw, pitch, HFOV_12MM, HFOV_12MM, 400, 400)
+    sx, sy = orc.equirect_map(orc.make_view(*spec), W, H)
+    X, Y, lat = truth_xy(spec, W, H)
+    assert sx.min() >= 0 and sx.max() < 32 * W
+    dx = (sx / 32.0 - X + W / 2) % W - W / 2
+    dy = sy / 32.0 - Y
+    away_from_pole = np.abs(lat) < np.radians(89.0)     # d(lon) is amplified by 1/cos(lat) at the poles
+    assert np.abs(dy).max() <= 1 / 64 + 2e-4
+    assert np.abs(dx[away_from_pole]).max() <= 1 / 64 + 2e-3
+    cosl = np.maximum(np.cos(lat), 1e-3)
+    assert (np.abs(dx) * cosl).max() <= 1 / 64 + 3e-4    # error measured on the sphere
+    flips = (np.abs(dx[away_from_pole]) > 1 / 64 + 1e-9).mean() + (np.abs(dy) > 1 / 64 + 1e-9).mean()
+    assert flips < 0.004
+
+
+def test_view_centre_lands_on_expected_texel(orc):
+    W, H = 2048, 1024
+    for yaw, pitch in [(0, 0), (90, 0), (-90, 0), (180, 0), (0, 45), (30, -20)]:
+        v = orc.make_view(yaw, pitch, 1, 1, 2, 2)        # 1-degree view: all 4 pixels hug the view centre
+        sx, sy = orc.equirect_map(v, W, H)
+        cx = ((sx / 32.0 - (((yaw + 180) % 360) / 360.0 * W - 0.5) + W / 2) % W) - W / 2
+        assert np.abs(cx).max() < 3.0
+        cy = (sy / 32.0).mean()
+        assert abs(cy - ((0.5 - pitch / 180.0) * H - 0.5)) < 0.05
+        # +yaw looks right (larger x), +pitch looks up (smaller y): SURVEY 8(c)
+    a = orc.equirect_map(orc.make_view(10, 0, 60, 60, 2, 2), W, H)[0].mean()
+    b = orc.equirect_map(orc.make_view(20, 0, 60, 60, 2, 2), W, H)[0].mean()
+    assert b > a
+    a = orc.equirect_map(orc.make_view(0, 10, 60, 60, 2, 2), W, H)[1].mean()
+    b = orc.equirect_map(orc.make_view(0, 20, 60, 60, 2, 2), W, H)[1].mean()
+    assert b < a
+
+
+def test_sampler_properties(orc):
+    """constant image -> constant output; horizontal roll of the source == yaw shift by whole texels"""
+    const = np.full((64, 128, 3), 77, np.uint8)
+    out = orc.equirect_views_u8(const, [orc.make_view(33, 21, 100, 80, 50, 40)])[0]
+    assert (out == 77).all()
+    src = rand_image(128, 256, seed=9)
+    W = 256
+    v0 = orc.make_view(0, 15, 90, 90, 64, 64)
+    v1 = orc.make_view(360.0 * 8 / W, 15, 90, 90, 64, 64)       # yaw by exactly 8 texels
+    a = orc.equirect_views_u8(np.roll(src, -8, axis=1), [v0])[0]
+    b = orc.equirect_views_u8(src, [v1])[0]
+    assert np.array_equal(a, b)
+    assert np.array_equal(orc.equirect_views_u8(src, [v0], threads=1)[0], orc.equirect_views_u8(src, [v0], threads=3)[0])
+
+
+def test_vertical_clamp_and_horizontal_wrap(orc):
+    H, W = 16, 32
+    src = np.zeros((H, W, 1), np.uint8)
+    src[0] = 200          # north pole row
+    src[-1] = 100         # south pole row
+    up = orc.equirect_views_u8(src, [orc.make_view(0, 90, 2, 2, 8, 8)])[0]
+    down = orc.equirect_views_u8(src, [orc.make_view(0, -90, 2, 2, 8, 8)])[0]
+    assert (up == 200).all() and (down == 100).all()
+    seam = np.zeros((H, W, 1), np.uint8)
+    seam[:, 0] = 255
+    seam[:, -1] = 255
+    back = orc.equirect_views_u8(seam, [orc.make_view(180, 0, 10, 10, 16, 16)])[0]
+    assert back.max() == 255 and back[:, 7:9].min() > 200     # the seam columns blend into a solid band
+
+
+def test_algorithmic_bytes_constant_of_bench(orc):
+    """bench.py's ALGO_BYTES_PER_FRAME: sum of distinct texels touched per view for BASELINE cfg2."""
+    import bench
+    W, H = 7680, 3840
+    union = np.zeros((H, W), np.uint8)
+    total = sum(orc.equirect_distinct_texels(orc.make_view(*s), W, H, union) for s in ring_views(6, 800, HFOV_12MM))
+    assert total == 14_325_324
+    assert int(union.sum()) == 11_685_864
+    assert bench.ALGO_BYTES_PER_FRAME == 6 * 800 * 800 * 3 + total * 3 == 54_495_972
+    assert [tuple(v) for v in bench.view_table()] == [tuple(s) for s in ring_views(6, 800, HFOV_12MM)]

@@ -1,0 +1,127 @@
+"""Pins the oracle's dual-fisheye map restatement against vectors captured by importing the reference's
+NumPy builders (tests/golden/make_df_goldens.py; NumPy 2.2.6)."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+G = np.load(GOLDEN / "df_goldens.npz")
+M = json.loads((GOLDEN / "df_goldens.json").read_text())
+ULP4K = float(np.spacing(np.float32(2048.0)))   # one float32 ULP of a map coordinate in [2048, 4096)
+
+
+def calib(orc, d):
+    return orc.make_calib(d["width"], d["height"], *[float(d[k]) for k in
+                                                     ("f", "cx", "cy", "k1", "k2", "k3", "k4", "p1", "p2", "b1", "b2")])
+
+
+@pytest.mark.parametrize("case", M["small_cases"], ids=[c[0] for c in M["small_cases"]])
+def test_direct_map_restatement_small(orc, case):
+    """DF:1759-1823 restated in C float32: same op order; libm vs NumPy-SIMD acos/sin differ by <= ~1 ULP of the
+    angle, which is <= 6 ULP (at magnitude 2048-4096) of the map coordinate.  valid masks must be identical."""
+    name, cname, yaw, pitch, hf, vf, w, h, lf = case
+    cal = calib(orc, M["template_calibration"] if cname == "tmpl" else M["synthetic_calibration"])
+    mx, my, valid = orc.fisheye_map(cal, yaw, pitch, hf, vf, w, h, lf, numpy2=True)
+    gx, gy, gv = G[name + "_mx"], G[name + "_my"], G[name + "_valid"]
+    assert np.array_equal(valid, gv)
+    scale = max(1.0, cal.width / 3840.0)
+    assert np.abs(mx - gx).max() <= 6 * ULP4K * scale
+    assert np.abs(my - gy).max() <= 6 * ULP4K * scale
+    assert (mx == gx).mean() > 0.7 and (my == gy).mean() > 0.7      # most values are bit-equal
+
+
+def test_direct_map_real_size_samples(orc):
+    cal = calib(orc, M["template_calibration"])
+    hf = float(M["sfm10_specs_default"][0]["hfov_deg"])
+    st = M["real_stride"]
+    for vid, yaw, pitch in M["real_views"]:
+        mx, my, valid = orc.fisheye_map(cal, yaw, pitch, hf, hf, 1750, 1750, 190.0, threads=0)
+        assert np.abs(mx[::st, ::st] - G[f"real_{vid}_mx_s"]).max() <= 6 * ULP4K
+        assert np.abs(my[::st, ::st] - G[f"real_{vid}_my_s"]).max() <= 6 * ULP4K
+        assert np.array_equal(valid[::st, ::st], G[f"real_{vid}_valid_s"])
+        rows = G[f"real_{vid}_rows"]
+        got = np.stack([mx[0], my[0], mx[875], my[875], mx[1749], my[1749]])
+        assert np.abs(got - rows).max() <= 6 * ULP4K
+        assert abs(float(valid.mean()) - float(M[f"real_{vid}_valid_ratio"])) < 1e-12
+        for (r, c), (ax, ay) in zip(M["real_anchor_rc"], G[f"real_{vid}_anchor"]):
+            assert abs(mx[r, c] - ax) <= 6 * ULP4K and abs(my[r, c] - ay) <= 6 * ULP4K
+
+
+def test_survey_appendix_d_anchors(orc):
+    """the literal anchor values quoted in SURVEY.md appendix D (view A)"""
+    cal = calib(orc, M["template_calibration"])
+    hf = 104.2500326978036
+    mx, my, valid = orc.fisheye_map(cal, 0.0, 0.0, hf, hf, 1750, 1750, 190.0, threads=0)
+    for (r, c), (ex, ey) in {(0, 0): (1084.23876953125, 1084.251708984375), (874, 874): (1919.2215576171875, 1919.234619140625),
+                             (1000, 300): (1168.76806640625, 2084.05517578125)}.items():
+        assert abs(mx[r, c] - ex) <= 6 * ULP4K and abs(my[r, c] - ey) <= 6 * ULP4K
+    assert valid.all()
+
+
+def test_undistort_map_restatement(orc):
+    cal = calib(orc, M["synthetic_calibration"])
+    mx, my, valid = orc.undistort_map(cal, float(M["undistort_zoom_full_explicit"]), 170.0)
+    gx, gy, gv = G["undist_full_mx"], G["undist_full_my"], G["undist_full_valid"]
+    far = np.abs(gx) > 1e5
+    assert np.abs(mx - gx)[~far].max() <= 2e-3 and np.abs(my - gy)[~far].max() <= 2e-3
+    assert (valid != gv).mean() < 1e-4      # asin differs by an ULP exactly on the lens-FOV rim at most
+    tc = calib(orc, M["template_calibration"])
+    mx, my, valid = orc.undistort_map(tc, float(M["undistort_zoom_template"]), 190.0, threads=0)
+    s = M["undistort_stride"]
+    gx = G["undist_tmpl_mx_s"]
+    near = np.abs(gx) < 1e5
+    assert np.abs(mx[::s, ::s] - gx)[near].max() <= 8 * ULP4K
+    assert np.array_equal(valid[::s, ::s], G["undist_tmpl_valid_s"])
+    assert abs(float(valid.mean()) - float(M["undistort_valid_fraction_template"])) < 1e-5
+    assert mx[1920, 1920] == 1920.0 and my[1920, 1920] == 1920.0
+
+
+@pytest.mark.parametrize("case", M["small_cases"], ids=[c[0] for c in M["small_cases"]])
+def test_fe_spec_tracks_reference_on_valid_pixels(orc, case):
+    """FE-SPEC v1 (transcendental-free, used by the fused kernel) vs the reference maps: <= 0.01 px on valid
+    pixels (the reference's own float32 acos path carries that much noise at small angles), masks equal except
+    on the rim where theta == theta_max to within rounding."""
+    name, cname, yaw, pitch, hf, vf, w, h, lf = case
+    cal = calib(orc, M["template_calibration"] if cname == "tmpl" else M["synthetic_calibration"])
+    sx, sy, sv = orc.fisheye_spec_map(cal, yaw, pitch, hf, vf, w, h, lf)
+    gx, gy, gv = G[name + "_mx"], G[name + "_my"], G[name + "_valid"]
+    assert (sv != gv).mean() <= 2e-3
+    both = sv & gv
+    if both.any():
+        assert np.abs(sx - gx)[both].max() <= 1e-2 and np.abs(sy - gy)[both].max() <= 1e-2
+
+
+def test_fe_spec_against_float64_truth(orc):
+    """FE-SPEC is closer to the float64 evaluation of DF:1759-1823 than the float32 reference path is."""
+    d = M["template_calibration"]
+    cal = calib(orc, d)
+    yaw, pitch, hf, w = 10.0, 5.0, 30.0, 64
+    sx, sy, _ = orc.fisheye_spec_map(cal, yaw, pitch, hf, hf, w, w, 190.0)
+    i = np.arange(w)
+    u = ((i + 0.5) / w) * 2 - 1
+    uu, vv = np.meshgrid(u, u)
+    t = np.tan(np.radians(hf) / 2)
+    x, y, z = t * uu, t * (-vv), np.ones_like(uu)
+    n = np.sqrt(x * x + y * y + z * z)
+    x, y, z = x / n, y / n, z / n
+    p, yw = np.radians(pitch), np.radians(yaw)
+    y1 = np.cos(p) * y + np.sin(p) * z
+    z1 = -np.sin(p) * y + np.cos(p) * z
+    rx, rz, ry = np.cos(yw) * x + np.sin(yw) * z1, -np.sin(yw) * x + np.cos(yw) * z1, y1
+    th = np.arccos(np.clip(rz, -1, 1))
+    sc = 2 * np.sin(th / 2) / np.sqrt(rx * rx + ry * ry)
+    xn, yn = rx * sc, -ry * sc
+    r2 = xn * xn + yn * yn
+    rad = 1 + float(d["k1"]) * r2 + float(d["k2"]) * r2 ** 2 + float(d["k3"]) * r2 ** 3
+    tx = 1920 + float(d["cx"]) + xn * rad * float(d["f"])
+    ty = 1920 + float(d["cy"]) + yn * rad * float(d["f"])
+    assert np.abs(sx - tx).max() <= 3 * ULP4K and np.abs(sy - ty).max() <= 3 * ULP4K
+
+
+def test_abi_struct_sizes_match_product(orc):
+    import gs360
+    import ctypes
+    assert orc.lib().orc_abi_sizes(0) == ctypes.sizeof(gs360.View) == ctypes.sizeof(orc.OrcView) == 40
+    assert orc.lib().orc_abi_sizes(1) == ctypes.sizeof(gs360.Calib) == ctypes.sizeof(orc.OrcCalib) == 96
