@@ -93,8 +93,8 @@ void make_eq_view(const gs360_view& v, int W, EqView* o) {
     o->x0i32 = (int32_t)(32 * xi);
     o->out_w = v.width;
     o->out_h = v.height;
-    o->tiles_x = (v.width + 31) / 32;
-    o->tiles_y = (v.height + 31) / 32;
+    o->tiles_x = (v.width + kTileW - 1) / kTileW;
+    o->tiles_y = (v.height + kTileH - 1) / kTileH;
 }
 
 void make_fe_view(const gs360_calib& cal, const gs360_view& v, double lens_fov_deg, FeView* o) {
@@ -116,8 +116,8 @@ void make_fe_view(const gs360_calib& cal, const gs360_view& v, double lens_fov_d
     o->tang = (cal.p1 != 0.0 || cal.p2 != 0.0) ? 1 : 0;
     o->W = cal.width; o->H = cal.height;
     o->out_w = v.width; o->out_h = v.height;
-    o->tiles_x = (v.width + 31) / 32;
-    o->tiles_y = (v.height + 31) / 32;
+    o->tiles_x = (v.width + kTileW - 1) / kTileW;
+    o->tiles_y = (v.height + kTileH - 1) / kTileH;
 }
 
 uint8_t sat_u8(double v) {  // cv::saturate_cast<uchar>(double)

@@ -8,6 +8,12 @@
 
 namespace gs360 {
 
+// Output tile of one 256-thread workgroup: 64 px wide (one wavefront = 64 consecutive pixels of a row),
+// 16 rows tall (4 wavefronts x 4 rows each).
+constexpr int kTileW = 64;
+constexpr int kRowsPerWave = 4;
+constexpr int kTileH = 4 * kRowsPerWave;
+
 // ------------------------------------------------------------------------------------------------
 // EQ-SPEC v1 per-view constants.  Host computes them in float64 and rounds once.
 // ------------------------------------------------------------------------------------------------

@@ -6,11 +6,14 @@
 //                        cli_tools/gs360_DualFisheyeDistortionCalibration.py:2001-2014 / :2031-2043.
 //   fe_views_kernel      fused dual-fisheye -> perspective (FE-SPEC v1), DF:1759-1823 evaluated in-kernel.
 //
-// All three are HBM/L2-bound byte gathers (no contraction -> no MFMA).  Work decomposition: one 32x32
-// output tile per 256-thread workgroup, each lane owns 4 horizontally adjacent pixels (12 B of RGB =
-// three dword stores), the 8 lanes of a tile row cover 32 px, a wavefront covers 8 tile rows.  Tiles are
-// numbered row-major per view and handed to XCDs in contiguous chunks (block b runs on XCD b % 8) so that
-// neighbouring tiles -- which share source cache lines -- hit the same per-XCD L2.
+// All three are HBM/L2-bound byte gathers (no contraction -> no MFMA).  Work decomposition: one 64x16
+// output tile per 256-thread workgroup; a wavefront owns 4 rows of the tile and its 64 lanes are 64
+// CONSECUTIVE pixels of one output row, so one gather instruction walks a short arc of one or two
+// source rows (few cache lines per instruction -- the texture-address path processes lines, not bytes).
+// Each lane packs its RGB result into a dword and the row is written as whole dwords after a two-shuffle
+// (ds_bpermute) repack, i.e. 192 contiguous bytes per wavefront row.  Tiles are numbered row-major per
+// view and handed to XCDs in contiguous chunks (block b runs on XCD b % 8) so that neighbouring tiles --
+// which share source cache lines -- hit the same per-XCD L2.
 //
 // Compile with -ffp-contract=off: the float32 specs are defined operation by operation and must match the
 // CPU oracle bit for bit; only explicit __builtin_fmaf may fuse.
@@ -39,31 +42,34 @@ __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s
     return (s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + 512u) >> 10;
 }
 
-// store 4 pixels x C channels held as px[p][c] to a row pointer; packed dword stores when possible
+// Store one wavefront row: lane l holds pixel l (channels in px[0..C-1]); n_px pixels are valid.
+// C == 3: pixels are packed to 24 bits and re-sliced into dwords with two cross-lane shuffles so that the
+// row leaves as 4-byte stores (lane j writes bytes 4j..4j+3 = tail of pixel 4j/3 + head of the next one).
 template <int C>
-__device__ __forceinline__ void store_px4(uint8_t* d, const uint32_t (&px)[4][4], int n_valid, bool aligned4) {
-    if (n_valid == 4 && aligned4) {
-        if constexpr (C == 3) {
-            uint32_t* q = reinterpret_cast<uint32_t*>(d);
-            q[0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
-            q[1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
-            q[2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
-            return;
-        } else if constexpr (C == 4) {
-            uint4 v;
-            v.x = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[0][3] << 24);
-            v.y = px[1][0] | (px[1][1] << 8) | (px[1][2] << 16) | (px[1][3] << 24);
-            v.z = px[2][0] | (px[2][1] << 8) | (px[2][2] << 16) | (px[2][3] << 24);
-            v.w = px[3][0] | (px[3][1] << 8) | (px[3][2] << 16) | (px[3][3] << 24);
-            *reinterpret_cast<uint4*>(d) = v;  // aligned4 guarantees 16-B alignment for C == 4 (see host)
-            return;
-        } else if constexpr (C == 1) {
-            *reinterpret_cast<uint32_t*>(d) = px[0][0] | (px[1][0] << 8) | (px[2][0] << 16) | (px[3][0] << 24);
+__device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4) {
+    const int lane = threadIdx.x & 63;
+    if constexpr (C == 3) {
+        if (aligned4) {
+            uint32_t packed = px[0] | (px[1] << 8) | (px[2] << 16);
+            int a = lane + lane / 3;          // (4 * lane) / 3
+            int s = lane - 3 * (lane / 3);    // (4 * lane) % 3
+            uint32_t pa = __shfl(packed, a & 63), pb = __shfl(packed, (a + 1) & 63);
+            uint32_t dw = (pa >> (8 * s)) | (pb << (24 - 8 * s));
+            int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
+            if (lane < full) reinterpret_cast<uint32_t*>(row)[lane] = dw;
+            if (lane == full && rem)
+                for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
             return;
         }
     }
-    for (int p = 0; p < n_valid; ++p)
-        for (int c = 0; c < C; ++c) d[p * C + c] = (uint8_t)px[p][c];
+    if constexpr (C == 4) {
+        if (aligned4) {
+            if (lane < n_px) reinterpret_cast<uint32_t*>(row)[lane] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+            return;
+        }
+    }
+    if (lane < n_px)
+        for (int c = 0; c < C; ++c) row[lane * C + c] = (uint8_t)px[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -144,39 +150,37 @@ __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     r -= V.tile_base;
     int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
 
-    int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    int x0 = tile_x * 32 + tx * 4, y = tile_y * 32 + ty;
-    if (y >= V.out_h || x0 >= V.out_w) return;
-
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = tile_x * kTileW;
+    const int n_px = min(kTileW, V.out_w - x0);
+    const int xc = min(x0 + lane, V.out_w - 1);   // lanes past the right edge recompute the last pixel (kept
+                                                   // active: they take part in the store shuffles)
     const uint8_t* __restrict__ src = L.src[f];
-    int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
-    uint8_t* drow = L.dst[f * L.n_views + k] + (int64_t)y * dstride + (int64_t)x0 * C;
+    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
+    uint8_t* dst = L.dst[f * L.n_views + k];
+    const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+    const int W32 = 32 * L.W;
+    const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
 
-    float yv = (float)(2 * y + 1 - V.out_h) * V.syv;
-    float bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
-    float cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
-    float bb = bz * bz;
-    int W32 = 32 * L.W;
-
-    uint32_t px[4][4];
-    int n_valid = min(4, V.out_w - x0);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (p < n_valid) {
-            float x = (float)(2 * (x0 + p) + 1 - V.out_w) * V.sxu;
-            float h = __builtin_sqrtf(__builtin_fmaf(x, x, bb));
-            int Kl, Kt;
-            float rl = eq_atan2_red(x, bz, Kl);
-            float rt = eq_atan2_red(cy, h, Kt);
-            int sx = (int)__builtin_rintf(__builtin_fmaf(rl, L.kx32, V.x0f32)) + V.x0i32 + Kl * 4 * L.W;
-            if (sx < 0) sx += W32;
-            if (sx >= W32) sx -= W32;
-            int sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
-            eq_sample<C>(src, L.src_stride, L.W, L.H, sx, sy, px[p]);
-        }
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
+        if (y >= V.out_h) break;                    // wave-uniform
+        float yv = (float)(2 * y + 1 - V.out_h) * V.syv;
+        float bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
+        float cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
+        float h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
+        int Kl, Kt;
+        float rl = eq_atan2_red(x, bz, Kl);
+        float rt = eq_atan2_red(cy, h, Kt);
+        int sx = (int)__builtin_rintf(__builtin_fmaf(rl, L.kx32, V.x0f32)) + V.x0i32 + Kl * 4 * L.W;
+        if (sx < 0) sx += W32;
+        if (sx >= W32) sx -= W32;
+        int sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+        uint32_t px[4];
+        eq_sample<C>(src, L.src_stride, L.W, L.H, sx, sy, px);
+        store_row<C>(dst + (int64_t)y * dstride + (int64_t)x0 * C, px, n_px, aligned4);
     }
-    bool aligned4 = (C == 4) ? ((dstride & 15) == 0) : ((dstride & 3) == 0);
-    store_px4<C>(drow, px, n_valid, aligned4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -251,37 +255,26 @@ __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, i
     int t = (b & 7) * chunk + (b >> 3);
     if (t >= total_tiles) return;
     int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
-    int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    int x0 = tile_x * 32 + tx * 4, y = tile_y * 32 + ty;
-    if (y >= L.h || x0 >= L.w) return;
-    int n_valid = min(4, L.w - x0);
-    int64_t o = (int64_t)y * L.w + x0;
-    float mx[4], my[4];
-    if (n_valid == 4 && (L.w & 3) == 0) {  // 16-B coalesced map reads
-        float4 vx = *reinterpret_cast<const float4*>(L.map_x + o);
-        float4 vy = *reinterpret_cast<const float4*>(L.map_y + o);
-        mx[0] = vx.x; mx[1] = vx.y; mx[2] = vx.z; mx[3] = vx.w;
-        my[0] = vy.x; my[1] = vy.y; my[2] = vy.z; my[3] = vy.w;
-    } else {
-        for (int p = 0; p < 4; ++p) {
-            mx[p] = p < n_valid ? L.map_x[o + p] : 0.0f;
-            my[p] = p < n_valid ? L.map_y[o + p] : 0.0f;
-        }
-    }
-    uint32_t px[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = tile_x * kTileW;
+    const int n_px = min(kTileW, L.w - x0);
+    const int xc = min(x0 + lane, L.w - 1);
+    const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (p < n_valid) {
-            if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx[p], my[p], L.cval, px[p]);
-            else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx[p], my[p], L.cval, px[p]);
-            if (L.valid && !L.valid[o + p]) {
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
+        if (y >= L.h) break;
+        int64_t o = (int64_t)y * L.w + xc;
+        float mx = L.map_x[o], my = L.map_y[o];      // 256 B per wavefront row, coalesced
+        uint32_t px[4];
+        if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
+        else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
+        if (L.valid && !L.valid[o]) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) px[p][c] = (uint32_t)L.fill;
-            }
+            for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.fill;
         }
+        store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4);
     }
-    bool aligned4 = (C == 4) ? ((L.dst_stride & 15) == 0) : ((L.dst_stride & 3) == 0);
-    store_px4<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_valid, aligned4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -297,58 +290,49 @@ __global__ __launch_bounds__(256) void fe_views_kernel(const FeLaunch L) {
     const FeView& V = L.view[k];
     int r = t - V.tile_base;
     int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
-    int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    int x0 = tile_x * 32 + tx * 4, y = tile_y * 32 + ty;
-    if (y >= V.out_h || x0 >= V.out_w) return;
-    int n_valid = min(4, V.out_w - x0);
-    int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = tile_x * kTileW;
+    const int n_px = min(kTileW, V.out_w - x0);
+    const int xc = min(x0 + lane, V.out_w - 1);
+    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
+    const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(V.dst) & 3) == 0);
+    const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
 
-    float yv = (float)(2 * y + 1 - V.out_h) * V.syv;       // ray y = -yv
-    float Y = __builtin_fmaf(-V.cp, yv, V.sp);
-    float z1 = __builtin_fmaf(V.sp, yv, V.cp);
-    float sz1 = V.sy * z1, cz1 = V.cy * z1;
-    float n2y = __builtin_fmaf(yv, yv, 1.0f);
-
-    uint32_t px[4][4];
-    uint32_t vmask = 0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (p < n_valid) {
-            float x = (float)(2 * (x0 + p) + 1 - V.out_w) * V.sxu;
-            float X = __builtin_fmaf(V.cy, x, sz1);
-            float Z = __builtin_fmaf(-V.sy, x, cz1);
-            float N = __builtin_sqrtf(__builtin_fmaf(x, x, n2y));
-            float d = N * (N + Z);
-            float s = d > 0.0f ? __builtin_sqrtf(2.0f / d) : 0.0f;
-            float xn = X * s, yn = -(Y * s);
-            float r2 = __builtin_fmaf(xn, xn, yn * yn);
-            float r4 = r2 * r2;
-            float radial = __builtin_fmaf(V.k4, r4 * r4, __builtin_fmaf(V.k3, r4 * r2,
-                           __builtin_fmaf(V.k2, r4, __builtin_fmaf(V.k1, r2, 1.0f))));
-            float xd = xn * radial, yd = yn * radial;
-            if (V.tang) {
-                float xy = xn * yn;
-                xd = __builtin_fmaf(V.tp2, xy, __builtin_fmaf(V.p1, __builtin_fmaf(2.0f * xn, xn, r2), xd));
-                yd = __builtin_fmaf(V.tp1, xy, __builtin_fmaf(V.p2, __builtin_fmaf(2.0f * yn, yn, r2), yd));
-            }
-            float mx = __builtin_fmaf(yd, V.b2, __builtin_fmaf(xd, V.b1, __builtin_fmaf(xd, V.f, V.cx0)));
-            float my = __builtin_fmaf(yd, V.f, V.cy0);
-            bool ok = (Z >= V.cos_tmax * N) && (mx >= 0.0f) && (mx <= V.wmax) && (my >= 0.0f) && (my <= V.hmax);
-            if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px[p]);
-            else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px[p]);
-            if (!ok && L.mask_outside) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) px[p][c] = (uint32_t)L.mask_value;
-            }
-            vmask |= (ok ? 1u : 0u) << (8 * p);
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
+        if (y >= V.out_h) break;
+        float yv = (float)(2 * y + 1 - V.out_h) * V.syv;       // ray y = -yv
+        float Y = __builtin_fmaf(-V.cp, yv, V.sp);
+        float z1 = __builtin_fmaf(V.sp, yv, V.cp);
+        float X = __builtin_fmaf(V.cy, x, V.sy * z1);
+        float Z = __builtin_fmaf(-V.sy, x, V.cy * z1);
+        float N = __builtin_sqrtf(__builtin_fmaf(x, x, __builtin_fmaf(yv, yv, 1.0f)));
+        float d = N * (N + Z);
+        float s = d > 0.0f ? __builtin_sqrtf(2.0f / d) : 0.0f;
+        float xn = X * s, yn = -(Y * s);
+        float r2 = __builtin_fmaf(xn, xn, yn * yn);
+        float r4 = r2 * r2;
+        float radial = __builtin_fmaf(V.k4, r4 * r4, __builtin_fmaf(V.k3, r4 * r2,
+                       __builtin_fmaf(V.k2, r4, __builtin_fmaf(V.k1, r2, 1.0f))));
+        float xd = xn * radial, yd = yn * radial;
+        if (V.tang) {
+            float xy = xn * yn;
+            xd = __builtin_fmaf(V.tp2, xy, __builtin_fmaf(V.p1, __builtin_fmaf(2.0f * xn, xn, r2), xd));
+            yd = __builtin_fmaf(V.tp1, xy, __builtin_fmaf(V.p2, __builtin_fmaf(2.0f * yn, yn, r2), yd));
         }
-    }
-    bool aligned4 = (C == 4) ? ((dstride & 15) == 0) : ((dstride & 3) == 0);
-    store_px4<C>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px, n_valid, aligned4);
-    if (V.valid_out) {
-        uint8_t* vo = V.valid_out + (int64_t)y * V.out_w + x0;
-        if (n_valid == 4 && (V.out_w & 3) == 0) *reinterpret_cast<uint32_t*>(vo) = vmask;
-        else for (int p = 0; p < n_valid; ++p) vo[p] = (uint8_t)((vmask >> (8 * p)) & 1u);
+        float mx = __builtin_fmaf(yd, V.b2, __builtin_fmaf(xd, V.b1, __builtin_fmaf(xd, V.f, V.cx0)));
+        float my = __builtin_fmaf(yd, V.f, V.cy0);
+        bool ok = (Z >= V.cos_tmax * N) && (mx >= 0.0f) && (mx <= V.wmax) && (my >= 0.0f) && (my <= V.hmax);
+        uint32_t px[4];
+        if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px);
+        else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px);
+        if (!ok && L.mask_outside) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.mask_value;
+        }
+        store_row<C>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px, n_px, aligned4);
+        if (V.valid_out && lane < n_px) V.valid_out[(int64_t)y * V.out_w + x0 + lane] = ok ? 1 : 0;
     }
 }
 
@@ -367,7 +351,7 @@ hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
 }
 
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
-    int tiles_x = (L.w + 31) / 32, tiles_y = (L.h + 31) / 32;
+    int tiles_x = (L.w + kTileW - 1) / kTileW, tiles_y = (L.h + kTileH - 1) / kTileH;
     int total = tiles_x * tiles_y, chunk = (total + 7) / 8;
     dim3 grid((unsigned)(chunk * 8)), block(256);
     switch (C) {

@@ -64,24 +64,35 @@ def synth_frame(np, k):
     return np.ascontiguousarray(np.roll(_BASE, 13 * k, axis=1))
 
 
-def cpu_baseline(np, frame, budget_s=12.0):
-    """Oracle ("port" of the same arithmetic, oracle/gs360_oracle.c) on this box's host cores."""
+def cpu_baseline(np, frame, budget_s=10.0):
+    """Oracle ("port" of the same arithmetic, oracle/gs360_oracle.c) on this box's host cores.
+    The thread count is picked by a short sweep (many-core hosts are not fastest with every core on a
+    3.84-MPix job); `cores` reports the thread count actually used for the timed sample."""
     from oracle import orc
     orc.build()
     views = [orc.make_view(*v) for v in view_table()]
-    cores = os.cpu_count() or 1
-    orc.equirect_views_u8(frame, views, threads=cores)          # warm (thread pool, page faults)
+    ncpu = os.cpu_count() or 1
+    cand = sorted({c for c in (ncpu, ncpu // 2, 64, 32, 16) if 1 <= c <= ncpu}, reverse=True)
+    best, best_t = cand[0], None
+    for c in cand:
+        orc.equirect_views_u8(frame, views, threads=c)              # warm this team size
+        t0 = time.perf_counter()
+        for _ in range(3):
+            orc.equirect_views_u8(frame, views, threads=c)
+        dt = (time.perf_counter() - t0) / 3
+        if best_t is None or dt < best_t:
+            best, best_t = c, dt
     n, t0 = 0, time.perf_counter()
     while True:
-        outs = orc.equirect_views_u8(frame, views, threads=cores)
+        outs = orc.equirect_views_u8(frame, views, threads=best)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 400:
+        if dt >= budget_s or n >= 2000:
             break
     mpix = n * N_VIEWS * SIZE * SIZE / 1e6
-    return {"value": round(mpix / dt, 2), "unit": "MPix/s", "cores": cores, "kind": "port",
-            "sample": f"{n} passes of 1 frame x {N_VIEWS} views (same 8K->6x800^2 workload), {dt:.1f} s, "
-                      f"OpenMP over rows, {cores} threads"}, outs
+    return {"value": round(mpix / dt, 2), "unit": "MPix/s", "cores": best, "kind": "port",
+            "sample": f"{n} passes of 1 frame x {N_VIEWS} views (same 8K->6x800^2 workload) in {dt:.1f} s; "
+                      f"OpenMP over (view,row), {best} of {ncpu} host threads (best of {cand})"}, outs
 
 
 def main():

@@ -411,27 +411,40 @@ static inline void eq_sample_px(const eq_consts *c, const uint8_t *src, long str
     }
 }
 
-/* One frame, n views.  dst[k] -> view k (height x width x C, tight unless dst_stride given). */
+/* One frame, n views.  dst[k] -> view k (height x width x C, tight unless dst_stride given).
+ * All (view, row) pairs form ONE parallel loop so that many host cores stay busy on small views. */
 ORC_API int orc_equirect_views_u8(const uint8_t *src, int W, int H, int C, long src_stride,
                                   const orc_view *views, int n_views,
                                   uint8_t *const *dst, long dst_stride, int n_threads) {
-    if (!src || !views || !dst || C < 1 || C > 4 || W < 2 || H < 2) return -1;
+    if (!src || !views || !dst || C < 1 || C > 4 || W < 2 || H < 2 || n_views < 0) return -1;
+    if (n_views == 0) return 0;
     if (src_stride == 0) src_stride = (long)W * C;
     int nt = pick_threads(n_threads);
     (void)nt;
+    eq_consts *cs = (eq_consts *)malloc(sizeof(eq_consts) * (size_t)n_views);
+    long *row0 = (long *)malloc(sizeof(long) * (size_t)(n_views + 1));
+    if (!cs || !row0) { free(cs); free(row0); return -4; }
+    row0[0] = 0;
     for (int k = 0; k < n_views; ++k) {
-        eq_consts c;
-        eq_make_consts(&views[k], W, H, &c);
-        long ds = dst_stride ? dst_stride : (long)c.out_w * C;
-        uint8_t *out = dst[k];
-#pragma omp parallel for num_threads(nt) schedule(static)
-        for (int j = 0; j < c.out_h; ++j)
-            for (int i = 0; i < c.out_w; ++i) {
-                int sx, sy;
-                eq_coord(&c, i, j, &sx, &sy);
-                eq_sample_px(&c, src, src_stride, C, sx, sy, out + (size_t)j * ds + (size_t)i * C);
-            }
+        eq_make_consts(&views[k], W, H, &cs[k]);
+        row0[k + 1] = row0[k] + cs[k].out_h;
     }
+    long total_rows = row0[n_views];
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 8)
+    for (long rr = 0; rr < total_rows; ++rr) {
+        int k = 0;
+        while (rr >= row0[k + 1]) ++k;
+        const eq_consts *c = &cs[k];
+        int j = (int)(rr - row0[k]);
+        long ds = dst_stride ? dst_stride : (long)c->out_w * C;
+        uint8_t *out = dst[k] + (size_t)j * ds;
+        for (int i = 0; i < c->out_w; ++i) {
+            int sx, sy;
+            eq_coord(c, i, j, &sx, &sy);
+            eq_sample_px(c, src, src_stride, C, sx, sy, out + (size_t)i * C);
+        }
+    }
+    free(cs); free(row0);
     return 0;
 }
 
