@@ -298,6 +298,8 @@ int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_f
     if (flags != 0) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
     if (src_stride == 0) src_stride = (size_t)W * C;
     if (src_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "src_stride smaller than a row");
+    if (src_stride >= ((size_t)1 << 24) || (uint64_t)src_stride * (uint64_t)H >= ((uint64_t)1 << 32))
+        return fail(GS360_ERR_UNSUPPORTED, "frame too large for 32-bit tap offsets (stride %zu x %d rows)", src_stride, H);
     for (int k = 0; k < n_views; ++k) {
         if (views[k].width < 1 || views[k].height < 1 || views[k].width > 32768 || views[k].height > 32768)
             return fail(GS360_ERR_ARG, "view %d has bad size %dx%d", k, views[k].width, views[k].height);

@@ -36,6 +36,20 @@ __device__ __forceinline__ uint2 ld_u64(const uint8_t* p) {
 }
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }
 
+// 8 bytes starting at the (unaligned) address p, fetched as ONE dword-aligned 12-byte access and shifted into
+// place with v_alignbyte.  The texture-address path merges dword-aligned lane accesses of a quad into cache-line
+// requests; byte-misaligned ones are looked up lane by lane (measured: 96 tag lookups per 64-lane instruction).
+// Reads bytes [p & ~3, (p & ~3) + 12).
+__device__ __forceinline__ uint2 ld_u64_via_aligned96(const uint8_t* p) {
+    uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));  // stays a global pointer
+    uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    uint2 v;
+    v.x = __builtin_amdgcn_alignbyte(d1, d0, o);
+    v.y = __builtin_amdgcn_alignbyte(d2, d1, o);
+    return v;
+}
+
 // bilinear blend of one channel, weights a0+a1 = 32, b0+b1 = 32  ->  (sum + 512) >> 10
 __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s10, uint32_t s11,
                                           uint32_t w00, uint32_t w01, uint32_t w10, uint32_t w11) {
@@ -90,7 +104,7 @@ __device__ __forceinline__ float eq_atan2_red(float yy, float xx, int& K) {
     bool big = mn > EQ_T8 * mx;
     float num = big ? mn - mx : mn;
     float den = big ? mn + mx : mx;
-    float t = den > 0.0f ? num / den : 0.0f;
+    float t = num / (den > 0.0f ? den : 1.0f);   // den == 0 only when num == 0: same value as the spec's guard, no branch
     float z = t * t;
     float p = __builtin_fmaf(EQ_C5, z, EQ_C4);
     p = __builtin_fmaf(p, z, EQ_C3);
@@ -105,35 +119,81 @@ __device__ __forceinline__ float eq_atan2_red(float yy, float xx, int& K) {
     return r0;
 }
 
+// Tap fetch for the equirect sampler, split in two so that all gathers of a wavefront can be in flight at once:
+//   eq_fetch   issues the two row reads of one pixel with NO control flow (the column is clamped so that the
+//              2*C-byte read never leaves the row); lanes whose right tap wraps around the 360-degree seam, or
+//              sits in the last columns, are flagged and repaired later by eq_sample_slow.
+//   eq_blend   unpacks the taps and applies the 1/32-px fixed-point bilinear weights.
 template <int C>
-__device__ __forceinline__ void eq_sample(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                          int sx, int sy, uint32_t (&out)[4]) {
-    int fx = sx & 31, ix = sx >> 5;
-    int fy = sy & 31, iy = sy >> 5;
-    int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
+struct EqTaps {
+    uint2 t0, t1;   // raw bytes of rows y0 / y1 starting at column ix
+    bool fix;       // needs the slow (wrapping) path
+};
+
+template <int C>
+__device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, int64_t stride, int W, int H, int sx, int sy) {
+    const int ix = sx >> 5, iy = sy >> 5;
+    const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
+    constexpr int kBack = (C == 3) ? 5 : 2;      // the 12-byte aligned read of RGB taps may run 6 bytes past them
+    const int ixl = min(ix, W - kBack);
+    // 32-bit byte offsets from the wave-uniform frame base (host guarantees H * stride < 2^32, stride < 2^24):
+    // one full-rate v_mad_u32_u24 per row instead of 64-bit multiply/add chains, and the load can use the
+    // SGPR-base + VGPR-offset addressing form.
+    const uint32_t col = (uint32_t)ixl * C;
+    const uint32_t o0 = __umul24((uint32_t)y0, (uint32_t)stride) + col;
+    const uint32_t o1 = __umul24((uint32_t)y1, (uint32_t)stride) + col;
+    const uint8_t* r0 = src + o0;
+    const uint8_t* r1 = src + o1;
+    EqTaps<C> t;
+    t.fix = ix != ixl;
+    if constexpr (C == 1) {
+        uint16_t a, b;
+        __builtin_memcpy(&a, r0, 2);
+        __builtin_memcpy(&b, r1, 2);
+        t.t0 = make_uint2(a, 0);
+        t.t1 = make_uint2(b, 0);
+    } else if constexpr (C == 3) {
+        t.t0 = ld_u64_via_aligned96(r0);
+        t.t1 = ld_u64_via_aligned96(r1);
+    } else {
+        t.t0 = ld_u64(r0);
+        t.t1 = ld_u64(r1);
+    }
+    return t;
+}
+
+template <int C>
+__device__ __forceinline__ void eq_blend(const EqTaps<C>& t, int sx, int sy, uint32_t (&out)[4]) {
+    const int fx = sx & 31, fy = sy & 31;
+    const uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
+    const uint32_t w00 = a0 * b0, w01 = a1 * b0, w10 = a0 * b1, w11 = a1 * b1;
+    if constexpr (C == 3) {
+        out[0] = blend(byte_of(t.t0.x, 0), byte_of(t.t0.x, 3), byte_of(t.t1.x, 0), byte_of(t.t1.x, 3), w00, w01, w10, w11);
+        out[1] = blend(byte_of(t.t0.x, 1), byte_of(t.t0.y, 0), byte_of(t.t1.x, 1), byte_of(t.t1.y, 0), w00, w01, w10, w11);
+        out[2] = blend(byte_of(t.t0.x, 2), byte_of(t.t0.y, 1), byte_of(t.t1.x, 2), byte_of(t.t1.y, 1), w00, w01, w10, w11);
+    } else if constexpr (C == 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            out[c] = blend(byte_of(t.t0.x, c), byte_of(t.t0.y, c), byte_of(t.t1.x, c), byte_of(t.t1.y, c), w00, w01, w10, w11);
+    } else {
+        out[0] = blend(byte_of(t.t0.x, 0), byte_of(t.t0.x, 1), byte_of(t.t1.x, 0), byte_of(t.t1.x, 1), w00, w01, w10, w11);
+    }
+}
+
+// byte-wise path with the horizontal wrap (ix + 1 == W -> column 0); used only for flagged lanes
+template <int C>
+__device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
+                                               int sx, int sy, uint32_t (&out)[4]) {
+    const int fx = sx & 31, ix = sx >> 5, fy = sy & 31, iy = sy >> 5;
+    const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
     const uint8_t* r0 = src + (int64_t)y0 * stride;
     const uint8_t* r1 = src + (int64_t)y1 * stride;
-    uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
-    uint32_t w00 = a0 * b0, w01 = a1 * b0, w10 = a0 * b1, w11 = a1 * b1;
-    uint32_t s00[4], s01[4], s10[4], s11[4];
-    bool wide = false;
-    if constexpr (C == 3) wide = ix < W - 2;  // both taps in-row and the 8-byte read stays inside the row
-    if (wide) {
-        uint2 t0 = ld_u64(r0 + 3 * ix), t1 = ld_u64(r1 + 3 * ix);
-        s00[0] = byte_of(t0.x, 0); s00[1] = byte_of(t0.x, 1); s00[2] = byte_of(t0.x, 2);
-        s01[0] = byte_of(t0.x, 3); s01[1] = byte_of(t0.y, 0); s01[2] = byte_of(t0.y, 1);
-        s10[0] = byte_of(t1.x, 0); s10[1] = byte_of(t1.x, 1); s10[2] = byte_of(t1.x, 2);
-        s11[0] = byte_of(t1.x, 3); s11[1] = byte_of(t1.y, 0); s11[2] = byte_of(t1.y, 1);
-    } else {
-        int ix1 = (ix + 1 == W) ? 0 : ix + 1;  // horizontal wrap
+    const uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
+    const uint32_t w00 = a0 * b0, w01 = a1 * b0, w10 = a0 * b1, w11 = a1 * b1;
+    const int ix1 = (ix + 1 == W) ? 0 : ix + 1;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            s00[c] = r0[ix * C + c]; s01[c] = r0[ix1 * C + c];
-            s10[c] = r1[ix * C + c]; s11[c] = r1[ix1 * C + c];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) out[c] = blend(s00[c], s01[c], s10[c], s11[c], w00, w01, w10, w11);
+    for (int c = 0; c < C; ++c)
+        out[c] = blend(r0[ix * C + c], r0[ix1 * C + c], r1[ix * C + c], r1[ix1 * C + c], w00, w01, w10, w11);
 }
 
 template <int C>
@@ -162,24 +222,70 @@ __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     const int W32 = 32 * L.W;
     const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
 
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
-        if (y >= V.out_h) break;                    // wave-uniform
-        float yv = (float)(2 * y + 1 - V.out_h) * V.syv;
-        float bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
-        float cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
-        float h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
-        int Kl, Kt;
-        float rl = eq_atan2_red(x, bz, Kl);
-        float rt = eq_atan2_red(cy, h, Kt);
+    // Phase 1: coordinates of the wavefront's 4 rows (independent dependency chains -> ILP for the long
+    // div/sqrt/polynomial sequences).  Rows past the bottom edge recompute the last row and are not stored.
+    // pitch == 0 (sp = 0, cp = 1 exactly): b = fma(0, yv, 1) = 1 for every row, so the longitude term and h depend
+    // on the column only -- they are evaluated once per lane instead of once per pixel, bit-identical to the
+    // general formula (same operations on the same operands).
+    const int ybase = tile_y * kTileH + wave * kRowsPerWave;
+    const bool level = (V.sp == 0.0f) && (V.cp == 1.0f);           // wave-uniform
+    int sxs[kRowsPerWave], sys[kRowsPerWave];
+    int sx_level = 0;
+    float h_level = 0.0f;
+    if (level) {
+        int Kl;
+        float rl = eq_atan2_red(x, 1.0f, Kl);
         int sx = (int)__builtin_rintf(__builtin_fmaf(rl, L.kx32, V.x0f32)) + V.x0i32 + Kl * 4 * L.W;
         if (sx < 0) sx += W32;
         if (sx >= W32) sx -= W32;
-        int sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
-        uint32_t px[4];
-        eq_sample<C>(src, L.src_stride, L.W, L.H, sx, sy, px);
-        store_row<C>(dst + (int64_t)y * dstride + (int64_t)x0 * C, px, n_px, aligned4);
+        sx_level = sx;
+        h_level = __builtin_sqrtf(__builtin_fmaf(x, x, 1.0f));
+    }
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int y = min(ybase + rr, V.out_h - 1);
+        float yv = (float)(2 * y + 1 - V.out_h) * V.syv;
+        float cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
+        float h;
+        int sx;
+        if (level) {
+            h = h_level;
+            sx = sx_level;
+        } else {
+            float bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
+            h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
+            int Kl;
+            float rl = eq_atan2_red(x, bz, Kl);
+            sx = (int)__builtin_rintf(__builtin_fmaf(rl, L.kx32, V.x0f32)) + V.x0i32 + Kl * 4 * L.W;
+            if (sx < 0) sx += W32;
+            if (sx >= W32) sx -= W32;
+        }
+        int Kt;
+        float rt = eq_atan2_red(cy, h, Kt);
+        sxs[rr] = sx;
+        sys[rr] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+    }
+    // Phase 2: all 8 gathers of the wavefront in flight together (no control flow between them).
+    EqTaps<C> taps[kRowsPerWave];
+    bool any_fix = false;
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        taps[rr] = eq_fetch<C>(src, L.src_stride, L.W, L.H, sxs[rr], sys[rr]);
+        any_fix |= taps[rr].fix;
+    }
+    // Phase 3: blend, repair the rare seam lanes, packed stores.
+    uint32_t px[kRowsPerWave][4];
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) eq_blend<C>(taps[rr], sxs[rr], sys[rr], px[rr]);
+    if (__any(any_fix)) {
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr)
+            if (taps[rr].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[rr], sys[rr], px[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int y = ybase + rr;
+        if (y < V.out_h) store_row<C>(dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4);
     }
 }
 
