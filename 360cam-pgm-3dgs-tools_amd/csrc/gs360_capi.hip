@@ -93,8 +93,11 @@ void make_eq_view(const gs360_view& v, int W, EqView* o) {
     o->x0i32 = (int32_t)(32 * xi);
     o->out_w = v.width;
     o->out_h = v.height;
-    o->tiles_x = (v.width + kTileW - 1) / kTileW;
-    o->tiles_y = (v.height + kTileH - 1) / kTileH;
+    // The kernel computes the left half of every row and mirrors it; level views also mirror top/bottom.
+    o->level = (o->sp == 0.0f && o->cp == 1.0f) ? 1 : 0;
+    const int half_w = (v.width + 1) / 2;
+    o->tiles_x = (half_w + kTileW - 1) / kTileW;
+    o->tiles_y = o->level ? ((v.height + 1) / 2 + kTileH / 2 - 1) / (kTileH / 2) : (v.height + kTileH - 1) / kTileH;
 }
 
 void make_fe_view(const gs360_calib& cal, const gs360_view& v, double lens_fov_deg, FeView* o) {

@@ -13,6 +13,7 @@ namespace gs360 {
 constexpr int kTileW = 64;
 constexpr int kRowsPerWave = 4;
 constexpr int kTileH = 4 * kRowsPerWave;
+constexpr int kHalfRows = kRowsPerWave / 2;   // level views: half of a wavefront's rows are horizon mirrors
 
 // ------------------------------------------------------------------------------------------------
 // EQ-SPEC v1 per-view constants.  Host computes them in float64 and rounds once.
@@ -25,6 +26,7 @@ struct EqView {
     int32_t out_w, out_h;
     int32_t tiles_x, tiles_y;
     int32_t tile_base;   // first tile index of this view inside one frame
+    int32_t level;       // pitch == 0 exactly (sp == 0, cp == 1): horizon-symmetric fast path
 };
 
 struct EqLaunch {

@@ -19,6 +19,10 @@
 // CPU oracle bit for bit; only explicit __builtin_fmaf may fuse.
 #include "gs360_kernels.h"
 
+#ifndef GS360_EXPERIMENT
+#define GS360_EXPERIMENT 0   // 1 / 2: scratch probes used while profiling (never built into lib/)
+#endif
+
 namespace gs360 {
 
 // ------------------------------------------------------------------------------------------------
@@ -56,18 +60,23 @@ __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s
     return (s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + 512u) >> 10;
 }
 
-// Store one wavefront row: lane l holds pixel l (channels in px[0..C-1]); n_px pixels are valid.
+// Store one wavefront row segment of n_px pixels.  Lane l holds the pixel at position l of the segment
+// (reversed = false) or at position n_px-1-l (reversed = true, the mirrored half of a view); channels in px[0..C-1].
 // C == 3: pixels are packed to 24 bits and re-sliced into dwords with two cross-lane shuffles so that the
 // row leaves as 4-byte stores (lane j writes bytes 4j..4j+3 = tail of pixel 4j/3 + head of the next one).
+// skip_first drops position 0 (the centre column of an odd-width view, which is its own mirror); the caller then
+// passes aligned4 = false and the per-lane byte path below handles it.
 template <int C>
-__device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4) {
+__device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4, bool reversed = false,
+                                          bool skip_first = false) {
     const int lane = threadIdx.x & 63;
     if constexpr (C == 3) {
         if (aligned4) {
             uint32_t packed = px[0] | (px[1] << 8) | (px[2] << 16);
-            int a = lane + lane / 3;          // (4 * lane) / 3
+            int a = lane + lane / 3;          // (4 * lane) / 3: first pixel contributing to dword `lane`
             int s = lane - 3 * (lane / 3);    // (4 * lane) % 3
-            uint32_t pa = __shfl(packed, a & 63), pb = __shfl(packed, (a + 1) & 63);
+            int la = reversed ? n_px - 1 - a : a, lb = reversed ? n_px - 2 - a : a + 1;
+            uint32_t pa = __shfl(packed, la & 63), pb = __shfl(packed, lb & 63);
             uint32_t dw = (pa >> (8 * s)) | (pb << (24 - 8 * s));
             int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
             if (lane < full) reinterpret_cast<uint32_t*>(row)[lane] = dw;
@@ -76,14 +85,15 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
             return;
         }
     }
+    const int pos = reversed ? n_px - 1 - lane : lane;
     if constexpr (C == 4) {
         if (aligned4) {
-            if (lane < n_px) reinterpret_cast<uint32_t*>(row)[lane] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+            if (lane < n_px) reinterpret_cast<uint32_t*>(row)[pos] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
             return;
         }
     }
-    if (lane < n_px)
-        for (int c = 0; c < C; ++c) row[lane * C + c] = (uint8_t)px[c];
+    if (lane < n_px && !(skip_first && pos == 0))
+        for (int c = 0; c < C; ++c) row[pos * C + c] = (uint8_t)px[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,8 +150,13 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
     // one full-rate v_mad_u32_u24 per row instead of 64-bit multiply/add chains, and the load can use the
     // SGPR-base + VGPR-offset addressing form.
     const uint32_t col = (uint32_t)ixl * C;
+#if GS360_EXPERIMENT == 2   // VALU-only probe: every lane reads the same two lines
+    const uint32_t o0 = (__umul24((uint32_t)y0, (uint32_t)stride) + col) & 63u;
+    const uint32_t o1 = 64u + ((__umul24((uint32_t)y1, (uint32_t)stride) + col) & 63u);
+#else
     const uint32_t o0 = __umul24((uint32_t)y0, (uint32_t)stride) + col;
     const uint32_t o1 = __umul24((uint32_t)y1, (uint32_t)stride) + col;
+#endif
     const uint8_t* r0 = src + o0;
     const uint8_t* r1 = src + o1;
     EqTaps<C> t;
@@ -196,6 +211,52 @@ __device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, 
         out[c] = blend(r0[ix * C + c], r0[ix1 * C + c], r1[ix * C + c], r1[ix1 * C + c], w00, w01, w10, w11);
 }
 
+// quantised longitude coordinate (1/32 px, wrapped to [0, 32W))
+__device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, const EqView& V) {
+    int sx = (int)__builtin_rintf(__builtin_fmaf(r0, L.kx32, V.x0f32)) + V.x0i32 + K * 4 * L.W;
+    const int W32 = 32 * L.W;
+    if (sx < 0) sx += W32;
+    if (sx >= W32) sx -= W32;
+    return sx;
+}
+
+// One pass over the wavefront's 4 row slots for one column per lane: all gathers first, then blend, repair, store.
+//   reversed = false: lane l is pixel l of the row segment starting at `col0`
+//   reversed = true : lane l is pixel n_px-1-l (the mirrored half of the view)
+template <int C>
+__device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __restrict__ src, uint8_t* dst, int64_t dstride,
+                                        const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
+                                        const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
+                                        int col0, int n_px, bool reversed, bool aligned4, bool skip_first) {
+    EqTaps<C> taps[kRowsPerWave];
+    bool any_fix = false;
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) {
+        taps[s] = eq_fetch<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s]);
+        any_fix |= taps[s].fix;
+    }
+    uint32_t px[kRowsPerWave][4];
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) eq_blend<C>(taps[s], sxs[s], sys[s], px[s]);
+    if (__any(any_fix)) {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s)
+            if (taps[s].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s)
+#if GS360_EXPERIMENT == 1   // load-path probe: only one lane-row in a million is written
+        if (row_ok[s] && px[s][0] == 0x12345u) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+#else
+        if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+#endif
+}
+
+// equirect -> rectilinear views.  The pinhole grid is mirror-symmetric about the view's vertical axis:
+// x(w-1-i) = -x(i) exactly, so latitude (even in x) is shared by the pixel pair (i, w-1-i) and longitude only
+// changes sign before the final fma/rint.  Level views (pitch 0) are also symmetric about the horizon:
+// yv(h-1-j) = -yv(j) exactly, latitude flips sign (rint is odd) -> one atan2 serves four pixels, and the
+// longitude term depends on the column only.  All of this is bit-identical to evaluating EQ-SPEC v1 per pixel.
 template <int C>
 __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk)
@@ -208,84 +269,87 @@ __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     while (k + 1 < L.n_views && r >= L.view[k + 1].tile_base) ++k;
     const EqView& V = L.view[k];
     r -= V.tile_base;
-    int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
+    const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half_w = (V.out_w + 1) >> 1;               // columns [0, half_w) are computed, the rest mirrored
     const int x0 = tile_x * kTileW;
-    const int n_px = min(kTileW, V.out_w - x0);
-    const int xc = min(x0 + lane, V.out_w - 1);   // lanes past the right edge recompute the last pixel (kept
-                                                   // active: they take part in the store shuffles)
+    const int n_px = min(kTileW, half_w - x0);
+    const int xl = min(x0 + lane, half_w - 1);            // lanes past the edge recompute the last column (they stay
+                                                          // active for the store shuffles)
     const uint8_t* __restrict__ src = L.src[f];
     const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
     uint8_t* dst = L.dst[f * L.n_views + k];
-    const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
-    const int W32 = 32 * L.W;
-    const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
+    const bool base_aligned = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+    const float x = (float)(2 * xl + 1 - V.out_w) * V.sxu;
 
-    // Phase 1: coordinates of the wavefront's 4 rows (independent dependency chains -> ILP for the long
-    // div/sqrt/polynomial sequences).  Rows past the bottom edge recompute the last row and are not stored.
-    // pitch == 0 (sp = 0, cp = 1 exactly): b = fma(0, yv, 1) = 1 for every row, so the longitude term and h depend
-    // on the column only -- they are evaluated once per lane instead of once per pixel, bit-identical to the
-    // general formula (same operations on the same operands).
-    const int ybase = tile_y * kTileH + wave * kRowsPerWave;
-    const bool level = (V.sp == 0.0f) && (V.cp == 1.0f);           // wave-uniform
-    int sxs[kRowsPerWave], sys[kRowsPerWave];
-    int sx_level = 0;
-    float h_level = 0.0f;
+    // ---- row slots of this wavefront -------------------------------------------------------------
+    int ys[kRowsPerWave];
+    bool row_ok[kRowsPerWave];
+    const bool level = V.level != 0;                      // wave-uniform
+    if (level) {
+        const int top_h = (V.out_h + 1) >> 1;
+#pragma unroll
+        for (int s = 0; s < kHalfRows; ++s) {
+            const int y = tile_y * (kTileH / 2) + wave * kHalfRows + s;
+            ys[s] = min(y, top_h - 1);
+            ys[s + kHalfRows] = V.out_h - 1 - ys[s];
+            row_ok[s] = y < top_h;
+            row_ok[s + kHalfRows] = row_ok[s] && (ys[s + kHalfRows] != ys[s]);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const int y = tile_y * kTileH + wave * kRowsPerWave + s;
+            ys[s] = min(y, V.out_h - 1);
+            row_ok[s] = y < V.out_h;
+        }
+    }
+
+    // ---- coordinates (EQ-SPEC v1) ------------------------------------------------------------------
+    int sxl[kRowsPerWave], sxm[kRowsPerWave], sys[kRowsPerWave];
     if (level) {
         int Kl;
-        float rl = eq_atan2_red(x, 1.0f, Kl);
-        int sx = (int)__builtin_rintf(__builtin_fmaf(rl, L.kx32, V.x0f32)) + V.x0i32 + Kl * 4 * L.W;
-        if (sx < 0) sx += W32;
-        if (sx >= W32) sx -= W32;
-        sx_level = sx;
-        h_level = __builtin_sqrtf(__builtin_fmaf(x, x, 1.0f));
-    }
+        const float rl = eq_atan2_red(x, 1.0f, Kl);       // b = fma(0, yv, 1) = 1 for every row
+        const int sx_left = eq_quant_lon(rl, Kl, L, V), sx_mirror = eq_quant_lon(-rl, -Kl, L, V);
+        const float h = __builtin_sqrtf(__builtin_fmaf(x, x, 1.0f));
 #pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = min(ybase + rr, V.out_h - 1);
-        float yv = (float)(2 * y + 1 - V.out_h) * V.syv;
-        float cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
-        float h;
-        int sx;
-        if (level) {
-            h = h_level;
-            sx = sx_level;
-        } else {
-            float bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
-            h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
-            int Kl;
-            float rl = eq_atan2_red(x, bz, Kl);
-            sx = (int)__builtin_rintf(__builtin_fmaf(rl, L.kx32, V.x0f32)) + V.x0i32 + Kl * 4 * L.W;
-            if (sx < 0) sx += W32;
-            if (sx >= W32) sx -= W32;
+        for (int s = 0; s < kHalfRows; ++s) {
+            const float yv = (float)(2 * ys[s] + 1 - V.out_h) * V.syv;
+            const float cy = __builtin_fmaf(-V.cp, yv, V.sp);
+            int Kt;
+            const float rt = eq_atan2_red(cy, h, Kt);
+            const int q = Kt * 8 * L.H + (int)__builtin_rintf(rt * L.ky32);
+            sys[s] = L.y0i32 - q;
+            sys[s + kHalfRows] = L.y0i32 + q;
+            sxl[s] = sxl[s + kHalfRows] = sx_left;
+            sxm[s] = sxm[s + kHalfRows] = sx_mirror;
         }
-        int Kt;
-        float rt = eq_atan2_red(cy, h, Kt);
-        sxs[rr] = sx;
-        sys[rr] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+    } else {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const float yv = (float)(2 * ys[s] + 1 - V.out_h) * V.syv;
+            const float bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
+            const float cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
+            const float h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
+            int Kl, Kt;
+            const float rl = eq_atan2_red(x, bz, Kl);
+            const float rt = eq_atan2_red(cy, h, Kt);
+            sxl[s] = eq_quant_lon(rl, Kl, L, V);
+            sxm[s] = eq_quant_lon(-rl, -Kl, L, V);
+            sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+        }
     }
-    // Phase 2: all 8 gathers of the wavefront in flight together (no control flow between them).
-    EqTaps<C> taps[kRowsPerWave];
-    bool any_fix = false;
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        taps[rr] = eq_fetch<C>(src, L.src_stride, L.W, L.H, sxs[rr], sys[rr]);
-        any_fix |= taps[rr].fix;
-    }
-    // Phase 3: blend, repair the rare seam lanes, packed stores.
-    uint32_t px[kRowsPerWave][4];
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) eq_blend<C>(taps[rr], sxs[rr], sys[rr], px[rr]);
-    if (__any(any_fix)) {
-#pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr)
-            if (taps[rr].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[rr], sys[rr], px[rr]);
-    }
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = ybase + rr;
-        if (y < V.out_h) store_row<C>(dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4);
+
+    // ---- left half, then the mirrored half ---------------------------------------------------------
+    eq_pass<C>(L, src, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false);
+    // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
+    // centre column is its own mirror and was already written: drop it from the segment.
+    const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
+    if (n_px > (centre_dup ? 1 : 0)) {
+        const int col0 = V.out_w - x0 - n_px;
+        const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
+        eq_pass<C>(L, src, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup);
     }
 }
 

@@ -4,13 +4,14 @@ This is the only door from Python into the engine.  There is NO CPU fallback: if
 library or a gfx950 device is missing every call raises Gs360Error.
 """
 import ctypes as C
+import os
 import pathlib
 import threading
 
 import numpy as np
 
 PKG_DIR = pathlib.Path(__file__).resolve().parent.parent
-LIB_PATH = PKG_DIR / "lib" / "libgs360hip.so"
+LIB_PATH = pathlib.Path(os.environ.get("GS360_LIB", PKG_DIR / "lib" / "libgs360hip.so"))  # override: profiling probes
 
 INTERP_NEAREST = 0  # == cv2.INTER_NEAREST
 INTERP_LINEAR = 1   # == cv2.INTER_LINEAR

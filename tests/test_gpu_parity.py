@@ -66,6 +66,23 @@ def test_equirect_full_size_8k_default6(ctx, orc):
     _assert_same(got, want, "cfg2 full size")
 
 
+def test_equirect_mirror_symmetry_edge_shapes(ctx, orc):
+    """the kernel computes half of each row and mirrors it (and the top half of level views): odd widths/heights,
+    widths around the 64/128 tile edges, 1-pixel views, level and pitched"""
+    src = rand_image(257, 514, seed=17)
+    specs = []
+    for w, h in [(1, 1), (2, 3), (3, 2), (63, 5), (64, 7), (65, 9), (127, 16), (128, 17), (129, 33), (130, 31), (255, 8), (257, 15)]:
+        specs.append((25.0, 0.0, 110.0, 95.0, w, h))       # level
+        specs.append((-160.0, 22.5, 110.0, 95.0, w, h))    # pitched
+    got, want = _eq_both(ctx, orc, src, specs)
+    _assert_same(got, want, "mirror edge shapes")
+    for channels in (1, 4):
+        srcc = rand_image(130, 260, c=channels, seed=18)
+        sp = [(10.0, 0.0, 100.0, 100.0, 67, 21), (10.0, -35.0, 100.0, 100.0, 66, 20), (180.0, 0.0, 120.0, 60.0, 129, 3)]
+        got, want = _eq_both(ctx, orc, srcc, sp)
+        _assert_same(got, want, f"mirror edge shapes C={channels}")
+
+
 def test_equirect_batched_frames_device_api(ctx, orc):
     """n_frames x n_views in ONE launch through the device-pointer entry point."""
     H, W = 300, 600
