@@ -1,0 +1,146 @@
+"""GPU execution of the dual-fisheye pair pipeline (the per-pair work of DF:1910-2064).
+
+One PairRenderer per device holds the remap tables of a sensor pair resident in HBM (the reference builds them
+once per run and shares them between its worker threads, DF:2582-2592, DF:2776-2804) and renders all views of one
+X/Y pair: upload the two lens images once, one table-remap launch per view (cv2.remap semantics + fused
+`out[~valid] = mask_value`), download.  `fused=True` evaluates the map in-kernel instead (FE-SPEC v1, no table
+traffic; <= 0.01 px from the reference tables).
+"""
+import threading
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .fisheye import SensorCalibration, UndistortTables
+
+INTERPOLATIONS = {"nearest": 0, "linear": 1, "cubic": 2, "lanczos4": 4}   # cv2.INTER_* values (DF:59-64)
+
+
+def engine_interpolation(flag: int) -> int:
+    """cv2 flag -> what the engine implements (nearest, linear); cubic/lanczos4 are sampled bilinearly for now."""
+    return flag if flag in (capi.INTERP_NEAREST, capi.INTERP_LINEAR) else capi.INTERP_LINEAR
+
+
+class PairRenderer:
+    def __init__(self, ctx: capi.Context, sensors: Dict[str, SensorCalibration], specs: Sequence[Dict[str, object]],
+                 tables: Optional[Dict[str, Dict[str, object]]], undistort: Optional[Dict[str, UndistortTables]],
+                 lens_fov_deg: float, fused: bool = False):
+        self.ctx = ctx
+        self.sensors = sensors
+        self.specs = list(specs)
+        self.tables = tables
+        self.lens_fov_deg = float(lens_fov_deg)
+        self.fused = bool(fused)
+        self.lock = threading.Lock()       # one pair at a time per device context (slot 0)
+        self.dev_tables = {}
+        if tables and not fused:
+            for vid, t in tables.items():
+                self.dev_tables[vid] = (ctx.to_device(t["map_x"]), ctx.to_device(t["map_y"]),
+                                        ctx.to_device(np.ascontiguousarray(t["valid"], np.uint8)))
+        self.dev_undistort = {}
+        for sid, u in (undistort or {}).items():
+            self.dev_undistort[sid] = (ctx.to_device(u.map_x), ctx.to_device(u.map_y),
+                                       ctx.to_device(np.ascontiguousarray(u.valid_mask, np.uint8)))
+
+    # ---------------------------------------------------------------------------------------------
+    def _remap(self, d_src, shape, maps, out_hw, interp, border, valid_fill):
+        H, W, C = shape
+        h, w = out_hw
+        d_dst = self.ctx.alloc(h * w * C)
+        try:
+            self.ctx.remap_table_dev(d_src, H, W, C, maps[0], maps[1], maps[2] if valid_fill is not None else None, h, w,
+                                     d_dst, interp=interp, border_value=border,
+                                     fill_value=valid_fill if valid_fill is not None else 0, slot=0)
+            return self.ctx.download(d_dst, (h, w, C), slot=0)
+        finally:
+            self.ctx.free(d_dst)
+
+    def render_pair(self, image_x: np.ndarray, image_y: np.ndarray, sensor_id_x: str, sensor_id_y: str, *,
+                    interpolation: int, mask_outside_model: bool, mask_value: int,
+                    mask_x: Optional[np.ndarray] = None, mask_y: Optional[np.ndarray] = None,
+                    want_fisheye: bool = False, want_perspective: bool = True):
+        """-> dict(perspective={view_id: img}, masks={view_id: img}, fisheye={'X': img, 'Y': img})"""
+        interp = engine_interpolation(interpolation)
+        out = {"perspective": {}, "masks": {}, "fisheye": {}}
+        with self.lock:
+            imgs = {"X": _hwc(image_x), "Y": _hwc(image_y)}
+            dev = {k: self.ctx.to_device(v) for k, v in imgs.items()}
+            dmask = {}
+            for k, m in (("X", mask_x), ("Y", mask_y)):
+                if m is not None:
+                    dmask[k] = (self.ctx.to_device(_hwc(m)), _hwc(m).shape)
+            try:
+                # borderValue=float(mask_value) -> cv::Scalar(v,0,0,0): only channel 0 gets v, and channel 0 of a
+                # cv2.imread image is BLUE.  Arrays here are RGB(A), so the value goes to index 2 for colour images.
+                C_in = imgs["X"].shape[2]
+                border = (0.0, 0.0, float(mask_value), 0.0) if C_in >= 3 else (float(mask_value), 0.0, 0.0, 0.0)
+                fill = int(mask_value) if mask_outside_model else None
+                if want_fisheye:
+                    for key, sid in (("X", sensor_id_x), ("Y", sensor_id_y)):
+                        c = self.sensors[sid]
+                        if imgs[key].shape[:2] != (c.height, c.width):
+                            raise RuntimeError("Resolution mismatch for {} lens: got {}x{}, expected {}x{}".format(
+                                key, imgs[key].shape[1], imgs[key].shape[0], c.width, c.height))
+                        out["fisheye"][key] = self._remap(dev[key], imgs[key].shape, self.dev_undistort[sid],
+                                                          (c.height, c.width), interp, border, fill)
+                if want_perspective:
+                    if self.fused:
+                        self._render_fused(out, imgs, dev, sensor_id_x, sensor_id_y, interp, mask_outside_model, mask_value)
+                    else:
+                        for spec in self.specs:
+                            vid = str(spec["view_id"])
+                            key = self.tables[vid]["lens_key"]
+                            hw = (int(spec["height"]), int(spec["width"]))
+                            out["perspective"][vid] = self._remap(dev[key], imgs[key].shape, self.dev_tables[vid], hw,
+                                                                  interp, border, fill)
+                    for spec in self.specs if dmask else ():
+                        vid = str(spec["view_id"])
+                        key = self.tables[vid]["lens_key"]
+                        if key not in dmask:
+                            raise RuntimeError("Mask source missing for lens {}".format(key))
+                        d_m, mshape = dmask[key]
+                        hw = (int(spec["height"]), int(spec["width"]))
+                        if self.fused:   # masks always go through the table path (nearest, border 0, invalid -> 0)
+                            raise RuntimeError("mask rendering needs table mode")
+                        out["masks"][vid] = self._remap(d_m, mshape, self.dev_tables[vid], hw, capi.INTERP_NEAREST,
+                                                        (0.0, 0.0, 0.0, 0.0), 0 if mask_outside_model else None)
+            finally:
+                for b in dev.values():
+                    self.ctx.free(b)
+                for b, _s in dmask.values():
+                    self.ctx.free(b)
+        return out
+
+    def _render_fused(self, out, imgs, dev, sid_x, sid_y, interp, mask_outside, mask_value):
+        views, calibs, srcs, dsts = [], [], [], []
+        C = imgs["X"].shape[2]
+        for key, sid in (("X", sid_x), ("Y", sid_y)):
+            c = self.sensors[sid]
+            if imgs[key].shape[:2] != (c.height, c.width):
+                raise RuntimeError("fused map mode needs images of the calibrated size {}x{} (lens {} is {}x{})".format(
+                    c.width, c.height, key, imgs[key].shape[1], imgs[key].shape[0]))
+        for spec in self.specs:
+            vid = str(spec["view_id"])
+            t = self.tables[vid]
+            key = t["lens_key"]
+            c = self.sensors[sid_x if key == "X" else sid_y]
+            views.append(capi.View.make(t["yaw_rel_deg"], spec["pitch_deg"], spec["hfov_deg"], spec["vfov_deg"],
+                                        spec["width"], spec["height"]))
+            calibs.append(capi.Calib.make(c.width, c.height, c.f, c.cx, c.cy, c.k1, c.k2, c.k3, c.k4, c.p1, c.p2, c.b1, c.b2))
+            srcs.append(dev[key])
+            dsts.append(self.ctx.alloc(int(spec["width"]) * int(spec["height"]) * C))
+        try:
+            self.ctx.fisheye_views_dev(srcs, calibs, C, views, self.lens_fov_deg, dsts, interp=interp,
+                                       mask_outside=mask_outside, mask_value=mask_value, slot=0)
+            for spec, d in zip(self.specs, dsts):
+                out["perspective"][str(spec["view_id"])] = self.ctx.download(
+                    d, (int(spec["height"]), int(spec["width"]), C), slot=0)
+        finally:
+            for d in dsts:
+                self.ctx.free(d)
+
+
+def _hwc(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a if a.ndim == 3 else a[:, :, None]
