@@ -133,6 +133,24 @@ class DeviceBuffer:
             self.ptr = None
 
 
+class PinnedBuffer:
+    """Page-locked host memory (gs360_host_alloc): async copies to/from it overlap with kernels."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(ctx.L.gs360_host_alloc(ctx.handle, self.nbytes, C.byref(p)), ctx.L)
+        self.ptr = p.value
+        self.view = (C.c_uint8 * self.nbytes).from_address(self.ptr)   # writable buffer for numpy.frombuffer
+
+    def free(self):
+        if self.ptr:
+            self.view = None
+            self.ctx.L.gs360_host_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
 class Context:
     """One engine context = one GPU + n_slots HIP streams.  Thread-safe per slot (a lock per slot)."""
 
@@ -178,6 +196,12 @@ class Context:
         buf.free()
         if buf in self._buffers:
             self._buffers.remove(buf)
+
+    def pinned(self, nbytes):
+        return PinnedBuffer(self, nbytes)
+
+    def unpin(self, hbuf):
+        hbuf.free()
 
     def upload(self, buf, array, slot=0, sync=True):
         a = np.ascontiguousarray(array)

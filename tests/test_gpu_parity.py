@@ -212,3 +212,25 @@ def test_fisheye_fused_vs_oracle_spec(ctx, orc, calib_kw, size, interp):
         _assert_same([got], [want], f"fused fisheye view {k} interp={interp}")
     for b in [dsrc] + dsts + vouts:
         ctx.free(b)
+
+
+def test_frame_pipeline_pinned_streams(ctx, orc):
+    """host-fed pipeline (pinned H2D -> kernel -> D2H, 2 frames in flight) returns every frame's views intact"""
+    from gs360.stream import FramePipeline
+    H, W = 256, 512
+    specs = ring_views(4, 64, 100.0) + [(20, -30, 100, 100, 64, 64)]
+    views = [gs360.View.make(*s) for s in specs]
+    pipe = FramePipeline(ctx, W, H, 3, views, n_slots=2)
+    frames = [rand_image(H, W, seed=300 + k) for k in range(5)]
+    got = {}
+    for k, f in enumerate(frames):
+        done = pipe.submit(f, tag=k)
+        if done:
+            got[done[0]] = done[1]
+    for tag, outs in pipe.drain():
+        got[tag] = outs
+    pipe.close()
+    assert sorted(got) == list(range(5))
+    for k, f in enumerate(frames):
+        want = orc.equirect_views_u8(f, [orc.make_view(*s) for s in specs])
+        _assert_same(got[k], want, f"pipeline frame {k}")
