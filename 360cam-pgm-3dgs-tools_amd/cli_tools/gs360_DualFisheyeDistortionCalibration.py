@@ -453,8 +453,8 @@ def main() -> None:
         from gs360 import capi, imageio
         from gs360.dualfisheye import PairRenderer, engine_interpolation
         if engine_interpolation(interpolation) != interpolation:
-            say("[INFO] gs360 engine: --interpolation {} requested; sampling with cv2-compatible 1/32-px bilinear "
-                "(cubic / lanczos4 are not implemented yet)".format(args.interpolation))
+            say("[INFO] gs360 engine: --interpolation {} is not implemented; sampling with cv2-compatible cubic".format(
+                args.interpolation))
         n_dev = capi.device_count()
         if n_dev <= 0:
             _die("[ERR] no MI355X visible: the gs360 engine has no CPU fallback", 2)

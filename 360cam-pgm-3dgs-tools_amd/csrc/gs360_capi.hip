@@ -53,6 +53,7 @@ struct gs360_ctx {
     hipEvent_t event[kMaxSlots][kEventsPerSlot] = {};
     Staging stage[kMaxSlots];
     hipDeviceProp_t prop;
+    int16_t* d_cubic = nullptr;   // 32*32*16 int16 cubic weight table, uploaded at context creation
 };
 
 namespace {
@@ -123,6 +124,48 @@ void make_fe_view(const gs360_calib& cal, const gs360_view& v, double lens_fov_d
     o->tiles_y = (v.height + kTileH - 1) / kTileH;
 }
 
+}  // namespace
+
+// OpenCV imgproc initInterTab2D(INTER_CUBIC, fixed point), restated: Keys kernel A = -0.75 in float32 per 1/32 phase,
+// outer product scaled by 2^15 and rounded to short, then the entries are patched so each 4x4 kernel sums to 2^15.
+void gs360::build_cubic_table(int16_t* out) {
+    float c1[32][4];
+    const float A = -0.75f;
+    for (int i = 0; i < 32; ++i) {
+        const float x = (float)i * (1.0f / 32.0f);
+        c1[i][0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c1[i][1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c1[i][2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c1[i][3] = 1.f - c1[i][0] - c1[i][1] - c1[i][2];
+    }
+    for (int fy = 0; fy < 32; ++fy)
+        for (int fx = 0; fx < 32; ++fx) {
+            int16_t* k = out + (fy * 32 + fx) * 16;
+            int sum = 0;
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    long r = std::lrintf(c1[fy][a] * c1[fx][b] * 32768.0f);
+                    r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+                    k[a * 4 + b] = (int16_t)r;
+                    sum += (int)r;
+                }
+            if (sum != 32768) {   // patch the largest / smallest entry of the block OpenCV inspects (rows/cols 2..3)
+                int hi = 10, lo = 10;
+                for (int a = 2; a < 4; ++a)
+                    for (int b = 2; b < 4; ++b) {
+                        const int idx = a * 4 + b;
+                        if (k[idx] < k[lo]) lo = idx;
+                        else if (k[idx] > k[hi]) hi = idx;
+                    }
+                const int diff = sum - 32768;
+                if (diff < 0) k[hi] = (int16_t)(k[hi] - diff);
+                else k[lo] = (int16_t)(k[lo] - diff);
+            }
+        }
+}
+
+namespace {
+
 uint8_t sat_u8(double v) {  // cv::saturate_cast<uchar>(double)
     long r = std::lrint(v);
     return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
@@ -182,6 +225,17 @@ int gs360_ctx_create(int device, int n_slots, gs360_ctx** out) {
         gs360_ctx_destroy(c);
         return rc;
     }
+    {
+        std::vector<int16_t> tab(32 * 32 * 16);
+        build_cubic_table(tab.data());
+        e = hipMalloc((void**)&c->d_cubic, tab.size() * sizeof(int16_t));
+        if (e == hipSuccess) e = hipMemcpy(c->d_cubic, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            int rc = fail(GS360_ERR_HIP, "cubic table upload failed: %s", hipGetErrorString(e));
+            gs360_ctx_destroy(c);
+            return rc;
+        }
+    }
     *out = c;
     return GS360_OK;
 }
@@ -198,6 +252,7 @@ int gs360_ctx_destroy(gs360_ctx* c) {
         if (c->stage[s].d_aux) (void)hipFree(c->stage[s].d_aux);
         if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
     }
+    if (c->d_cubic) (void)hipFree(c->d_cubic);
     delete c;
     return GS360_OK;
 }
@@ -297,7 +352,8 @@ int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_f
     if (n_frames == 0 || n_views == 0) return GS360_OK;  // empty batch is a no-op
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
     if (W < 2 || H < 2 || W > (1 << 21) || H > (1 << 21)) return fail(GS360_ERR_ARG, "bad source size %dx%d", W, H);
-    if (interp != GS360_INTERP_LINEAR) return fail(GS360_ERR_UNSUPPORTED, "equirect path implements INTER_LINEAR only");
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_CUBIC)
+        return fail(GS360_ERR_UNSUPPORTED, "equirect path implements INTER_LINEAR (1) and INTER_CUBIC (2), got %d", interp);
     if (flags != 0) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
     if (src_stride == 0) src_stride = (size_t)W * C;
     if (src_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "src_stride smaller than a row");
@@ -343,7 +399,22 @@ int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_f
             L.chunk = (L.total_tiles + 7) / 8;
             L.src_stride = (int64_t)src_stride;
             L.dst_stride = (int64_t)dst_stride;
-            HIP_TRY(launch_equirect(L, C, c->stream[slot]));
+            L.cubic_tab = c->d_cubic;
+            if (interp == GS360_INTERP_CUBIC) {   // per-pixel kernel: full-width, full-height tiles
+                int cbase = 0;
+                for (int k = 0; k < nv; ++k) {
+                    L.view[k].tiles_x = (L.view[k].out_w + kTileW - 1) / kTileW;
+                    L.view[k].tiles_y = (L.view[k].out_h + kTileH - 1) / kTileH;
+                    L.view[k].tile_base = cbase;
+                    cbase += L.view[k].tiles_x * L.view[k].tiles_y;
+                }
+                L.tiles_per_frame = cbase;
+                L.total_tiles = cbase * nf;
+                L.chunk = (L.total_tiles + 7) / 8;
+                HIP_TRY(launch_equirect_cubic(L, C, c->stream[slot]));
+            } else {
+                HIP_TRY(launch_equirect(L, C, c->stream[slot]));
+            }
         }
     }
     return GS360_OK;
@@ -359,8 +430,8 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     if (H < 1 || W < 1 || H >= 32767 || W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", W, H);
     if (h < 0 || w < 0 || h >= 32767 || w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", w, h);
     if (h == 0 || w == 0) return GS360_OK;
-    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST)
-        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1)", interp);
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC)
+        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2)", interp);
     if (src_stride == 0) src_stride = (size_t)W * C;
     if (dst_stride == 0) dst_stride = (size_t)w * C;
     if (src_stride < (size_t)W * C || dst_stride < (size_t)w * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
@@ -373,6 +444,7 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     L.interp = interp;
     L.fill = fill_value < 0 ? 0 : (fill_value > 255 ? 255 : fill_value);
     for (int k = 0; k < 4; ++k) L.cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
+    L.cubic_tab = c->d_cubic;
     HIP_TRY(launch_table(L, C, c->stream[slot]));
     return GS360_OK;
 }
@@ -386,8 +458,8 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
     if (n_views < 0) return fail(GS360_ERR_ARG, "negative count");
     if (n_views == 0) return GS360_OK;
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
-    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST)
-        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1)", interp);
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC)
+        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2)", interp);
     for (int k = 0; k < n_views; ++k) {
         if (!src_lens[k] || !dst[k]) return fail(GS360_ERR_ARG, "NULL image pointer for view %d", k);
         if (calibs[k].width < 1 || calibs[k].height < 1 || calibs[k].width >= 32767 || calibs[k].height >= 32767)
@@ -422,6 +494,7 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
         L.src_stride = (int64_t)(src_stride ? src_stride : (size_t)calibs[v0].width * C);
         L.dst_stride = (int64_t)dst_stride;
         L.cval[0] = (uint8_t)mask_value;  // borderValue=float(mask_value) -> Scalar(v,0,0,0), DF:2007
+        L.cubic_tab = c->d_cubic;
         HIP_TRY(launch_fisheye(L, C, c->stream[slot]));
     }
     return GS360_OK;

@@ -38,6 +38,7 @@ struct EqLaunch {
     int32_t y0i32;       // 16*H - 16
     int32_t n_views, n_frames;
     int32_t tiles_per_frame, total_tiles, chunk;  // chunk = ceil(total_tiles / 8) (XCD swizzle)
+    const int16_t* cubic_tab;   // 32*32*16 int16 (device) when interp == cubic
     int64_t src_stride;
     int64_t dst_stride;  // 0 = tight (out_w * C)
 };
@@ -56,6 +57,7 @@ struct TableLaunch {
     int32_t interp;
     int32_t fill;
     uint8_t cval[4];
+    const int16_t* cubic_tab;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -79,10 +81,13 @@ struct FeLaunch {
     int32_t interp, mask_outside, mask_value;
     int64_t src_stride, dst_stride;
     uint8_t cval[4];
+    const int16_t* cubic_tab;
 };
 
 // kernel launchers (gs360_kernels.hip)
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s);
+hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);
+void build_cubic_table(int16_t* out);   // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s);
 hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s);
 

@@ -353,6 +353,72 @@ __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     }
 }
 
+// Equirect cubic (EQ-SPEC v1 coordinates, 4x4 Keys taps from OpenCV's fixed-point table): the window columns
+// ix-1..ix+2 wrap around the 360-degree seam, the rows iy-1..iy+2 clamp to [0, H-1].  Straightforward per-pixel
+// evaluation (one lane = one pixel, 4 row slots per wavefront); the bilinear kernel above is the tuned path.
+template <int C>
+__global__ __launch_bounds__(256) void eq_views_cubic_kernel(const EqLaunch L) {
+    int b = blockIdx.x;
+    int t = (b & 7) * L.chunk + (b >> 3);
+    if (t >= L.total_tiles) return;
+    int f = t / L.tiles_per_frame;
+    int r = t - f * L.tiles_per_frame;
+    int k = 0;
+    while (k + 1 < L.n_views && r >= L.view[k + 1].tile_base) ++k;
+    const EqView& V = L.view[k];
+    r -= V.tile_base;
+    const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = tile_x * kTileW;
+    const int n_px = min(kTileW, V.out_w - x0);
+    const int xc = min(x0 + lane, V.out_w - 1);
+    const uint8_t* __restrict__ src = L.src[f];
+    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
+    uint8_t* dst = L.dst[f * L.n_views + k];
+    const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+    const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
+        if (y >= V.out_h) break;
+        const float yv = (float)(2 * y + 1 - V.out_h) * V.syv;
+        const float bz = __builtin_fmaf(V.sp, yv, V.cp);
+        const float cy = __builtin_fmaf(-V.cp, yv, V.sp);
+        const float h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
+        int Kl, Kt;
+        const float rl = eq_atan2_red(x, bz, Kl);
+        const float rt = eq_atan2_red(cy, h, Kt);
+        const int sx = eq_quant_lon(rl, Kl, L, V);
+        const int sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+        const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
+        const uint4* wq = reinterpret_cast<const uint4*>(L.cubic_tab + (fy * 32 + fx) * 16);
+        const uint4 wa = wq[0], wb = wq[1];
+        const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        int cols[4];
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            int xx = ix - 1 + kx;
+            cols[kx] = xx < 0 ? xx + L.W : (xx >= L.W ? xx - L.W : xx);
+        }
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const uint8_t* row = src + (int64_t)min(max(iy - 1 + ky, 0), L.H - 1) * L.src_stride;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                uint32_t pk = wpk[(ky * 4 + kx) >> 1];
+                int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
+                const uint8_t* px = row + (int64_t)cols[kx] * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += (int)px[c] * w;
+            }
+        }
+        uint32_t px[4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) px[c] = (uint32_t)min(max((acc[c] + (1 << 14)) >> 15, 0), 255);
+        store_row<C>(dst + (int64_t)y * dstride + (int64_t)x0 * C, px, n_px, aligned4);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // cv2.remap semantics (shared by the table kernel and the fused fisheye kernel)
 // ------------------------------------------------------------------------------------------------
@@ -419,6 +485,43 @@ __device__ __forceinline__ void cv_sample_nearest(const uint8_t* __restrict__ sr
     }
 }
 
+// remapBicubic, BORDER_CONSTANT: 4x4 window at (ix-1, iy-1); int16 weights (sum 32768) from the 32x32-phase table;
+// taps outside the image are the border constant; (sum + 2^14) >> 15 saturated to u8.
+template <int C>
+__device__ __forceinline__ void cv_sample_cubic(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
+                                                float mx, float my, const uint8_t (&cval)[4],
+                                                const int16_t* __restrict__ tab, uint32_t (&out)[4]) {
+    int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
+    int fx = sx & 31, fy = sy & 31;
+    int x0 = sat_s16(sx >> 5) - 1, y0 = sat_s16(sy >> 5) - 1;
+    bool outside = x0 >= W || x0 + 4 <= 0 || y0 >= H || y0 + 4 <= 0;
+    const uint4* wq = reinterpret_cast<const uint4*>(tab + (fy * 32 + fx) * 16);   // 32 B = two 16-B reads
+    uint4 wa = wq[0], wb = wq[1];
+    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        int yy = y0 + ky;
+        bool yin = (unsigned)yy < (unsigned)H;
+        const uint8_t* row = src + (int64_t)min(max(yy, 0), H - 1) * stride;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            int xx = x0 + kx;
+            bool in = yin && ((unsigned)xx < (unsigned)W);
+            const uint8_t* px = row + (int64_t)min(max(xx, 0), W - 1) * C;
+            uint32_t pk = wpk[(ky * 4 + kx) >> 1];
+            int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += (int)(in ? (uint32_t)px[c] : (uint32_t)cval[c]) * w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int r = (acc[c] + (1 << 14)) >> 15;
+        out[c] = outside ? (uint32_t)cval[c] : (uint32_t)min(max(r, 0), 255);
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
     int b = blockIdx.x;
@@ -438,6 +541,7 @@ __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, i
         float mx = L.map_x[o], my = L.map_y[o];      // 256 B per wavefront row, coalesced
         uint32_t px[4];
         if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
+        else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
         else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
         if (L.valid && !L.valid[o]) {
 #pragma unroll
@@ -496,6 +600,7 @@ __global__ __launch_bounds__(256) void fe_views_kernel(const FeLaunch L) {
         bool ok = (Z >= V.cos_tmax * N) && (mx >= 0.0f) && (mx <= V.wmax) && (my >= 0.0f) && (my <= V.hmax);
         uint32_t px[4];
         if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px);
+        else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, L.cubic_tab, px);
         else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px);
         if (!ok && L.mask_outside) {
 #pragma unroll
@@ -515,6 +620,17 @@ hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
         case 1: hipLaunchKernelGGL(eq_views_kernel<1>, grid, block, 0, s, L); break;
         case 3: hipLaunchKernelGGL(eq_views_kernel<3>, grid, block, 0, s, L); break;
         case 4: hipLaunchKernelGGL(eq_views_kernel<4>, grid, block, 0, s, L); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
+    dim3 grid((unsigned)(L.chunk * 8)), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL(eq_views_cubic_kernel<1>, grid, block, 0, s, L); break;
+        case 3: hipLaunchKernelGGL(eq_views_cubic_kernel<3>, grid, block, 0, s, L); break;
+        case 4: hipLaunchKernelGGL(eq_views_cubic_kernel<4>, grid, block, 0, s, L); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

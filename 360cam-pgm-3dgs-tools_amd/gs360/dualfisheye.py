@@ -18,8 +18,8 @@ INTERPOLATIONS = {"nearest": 0, "linear": 1, "cubic": 2, "lanczos4": 4}   # cv2.
 
 
 def engine_interpolation(flag: int) -> int:
-    """cv2 flag -> what the engine implements (nearest, linear); cubic/lanczos4 are sampled bilinearly for now."""
-    return flag if flag in (capi.INTERP_NEAREST, capi.INTERP_LINEAR) else capi.INTERP_LINEAR
+    """cv2 flag -> what the engine implements (nearest, linear, cubic); lanczos4 falls back to cubic."""
+    return flag if flag in (capi.INTERP_NEAREST, capi.INTERP_LINEAR, capi.INTERP_CUBIC) else capi.INTERP_CUBIC
 
 
 class PairRenderer:

@@ -108,10 +108,18 @@ class Engine:
                                       "the HIP engine (only equirect->rectilinear); use --engine ffmpeg")
         if abs(job.fnum("roll", 0.0)) > 1e-12:
             raise capi.Gs360Error(-4, "roll != 0 is not implemented by the HIP engine")
-        if job.interp not in ("linear", "bilinear") and not self._warned_cubic:
-            self._warned_cubic = True
-            print(f"[INFO] gs360 engine: v360 interp={job.interp} requested; the HIP engine samples with 1/32-px "
-                  "fixed-point bilinear (cubic is not implemented yet)", flush=True)
+        if job.interp in ("linear", "bilinear", "line"):
+            interp = capi.INTERP_LINEAR
+        elif job.interp in ("cubic", "bicubic"):
+            interp = capi.INTERP_CUBIC
+        else:
+            interp = capi.INTERP_CUBIC
+            if not self._warned_cubic:
+                self._warned_cubic = True
+                print(f"[INFO] gs360 engine: v360 interp={job.interp} is not implemented; sampling with cubic", flush=True)
+        interp_env = os.environ.get("GS360_INTERP")           # additive override: linear | cubic
+        if interp_env in ("linear", "cubic"):
+            interp = capi.INTERP_LINEAR if interp_env == "linear" else capi.INTERP_CUBIC
         view = capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"),
                               job.width, job.height)
         st = self.states[self.device_for(job.src)]
@@ -124,7 +132,7 @@ class Engine:
             with st.ctx.slot_locks[slot]:
                 dst = st.ctx.alloc(out_bytes)
                 try:
-                    st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot)
+                    st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp)
                     out = st.ctx.download(dst, (view.height, view.width, C), slot=slot)
                 finally:
                     st.ctx.free(dst)

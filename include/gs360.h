@@ -44,9 +44,10 @@ typedef enum gs360_status {
     GS360_ERR_NOMEM = -5
 } gs360_status;
 
-/* values equal cv2.INTER_NEAREST / cv2.INTER_LINEAR (DF:59-64) */
+/* values equal cv2.INTER_NEAREST / INTER_LINEAR / INTER_CUBIC (DF:59-64) */
 #define GS360_INTERP_NEAREST 0
 #define GS360_INTERP_LINEAR 1
+#define GS360_INTERP_CUBIC 2
 
 /* limits of one batched launch (larger requests are split internally) */
 #define GS360_MAX_VIEWS 16
@@ -103,7 +104,8 @@ int gs360_event_elapsed_ms(gs360_ctx *ctx, int slot, int event_from, int event_t
  * src_frames[f]: H x W x C equirect image, row stride src_stride bytes (0 = tight).
  * Geometry: EQ-SPEC v1: pinhole ray -> pitch about X -> yaw about Y -> lon/lat ->
  * 1/32-px fixed-point bilinear; horizontal border wraps, vertical border clamps.
- * interp must be GS360_INTERP_LINEAR.  flags: 0.
+ * interp: GS360_INTERP_LINEAR or GS360_INTERP_CUBIC (4x4 taps, OpenCV's fixed-point Keys A=-0.75 table; the
+ * reference's own default is v360 interp=cubic, PC:730).  flags: 0.
  */
 int gs360_equirect_views_u8(gs360_ctx *ctx, const void *const *src_frames, int n_frames,
                             int W, int H, int C, size_t src_stride,

@@ -101,7 +101,63 @@ static inline uint8_t sat_u8_d(double v) { /* saturate_cast<uchar>(double) */
 }
 
 /*
- * interp: 0 = INTER_NEAREST, 1 = INTER_LINEAR.  border_val has 4 entries (cv::Scalar);
+ * INTER_CUBIC weight table (OpenCV imgproc initInterTab2D, fixed point): for each of the 32x32 (fy, fx) sub-pixel
+ * phases a 4x4 int16 kernel = saturate_cast<short>(cy[k1] * cx[k2] * 32768) with the Keys coefficients A = -0.75
+ * evaluated in float32, followed by OpenCV's sum fix-up: if the 16 entries do not add up to 32768 the difference
+ * is taken from the largest (sum too small) or smallest (sum too large) of the entries [2..3]x[2..3] -- the index
+ * range the OpenCV source uses (ksize/2 .. ksize/2+1).  RESTATED FROM MEMORY OF THE OPENCV SOURCE, parity unpinned.
+ */
+static int16_t g_cubic_tab[32 * 32 * 16];
+static int g_cubic_ready = 0;
+
+static void cubic_coeffs(float x, float *c) {
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+static void cubic_init(void) {
+    if (g_cubic_ready) return;
+    float tab1[32][4];
+    for (int i = 0; i < 32; ++i) cubic_coeffs((float)i * (1.0f / 32.0f), tab1[i]);
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            int16_t *it = g_cubic_tab + (i * 32 + j) * 16;
+            int isum = 0;
+            for (int k1 = 0; k1 < 4; ++k1)
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    float v = tab1[i][k1] * tab1[j][k2];
+                    long r = lrintf(v * 32768.0f);
+                    r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+                    it[k1 * 4 + k2] = (int16_t)r;
+                    isum += (int)r;
+                }
+            if (isum != 32768) {
+                int diff = isum - 32768;
+                int Mk1 = 2, Mk2 = 2, mk1 = 2, mk2 = 2;
+                for (int k1 = 2; k1 < 4; ++k1)
+                    for (int k2 = 2; k2 < 4; ++k2) {
+                        if (it[k1 * 4 + k2] < it[mk1 * 4 + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (it[k1 * 4 + k2] > it[Mk1 * 4 + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                    }
+                if (diff < 0) it[Mk1 * 4 + Mk2] = (int16_t)(it[Mk1 * 4 + Mk2] - diff);
+                else it[mk1 * 4 + mk2] = (int16_t)(it[mk1 * 4 + mk2] - diff);
+            }
+        }
+    g_cubic_ready = 1;
+}
+
+/* copies the 32*32*16 int16 table (index (fy*32+fx)*16 + ky*4 + kx) */
+ORC_API int orc_cubic_table(int16_t *out) {
+    cubic_init();
+    memcpy(out, g_cubic_tab, sizeof(g_cubic_tab));
+    return 0;
+}
+
+/*
+ * interp: 0 = INTER_NEAREST, 1 = INTER_LINEAR, 2 = INTER_CUBIC.  border_val has 4 entries (cv::Scalar);
  * Python's borderValue=float(v) arrives as (v,0,0,0) -- channel c uses border_val[c & 3].
  * src: H x W x C interleaved u8, row stride src_stride bytes.  dst: h x w x C.
  */
@@ -111,7 +167,8 @@ ORC_API int orc_remap_u8(const uint8_t *src, int H, int W, int C, long src_strid
                          uint8_t *dst, long dst_stride, int n_threads) {
     if (!src || !map_x || !map_y || !dst || C < 1 || C > 4 || H < 1 || W < 1) return -1;
     if (H >= 32767 || W >= 32767) return -2; /* cv2.remap asserts on SHRT_MAX sizes */
-    if (interp != 0 && interp != 1) return -3;
+    if (interp != 0 && interp != 1 && interp != 2) return -3;
+    if (interp == 2) cubic_init();
     uint8_t cval[4];
     for (int c = 0; c < 4; ++c) cval[c] = sat_u8_d(border_val ? border_val[c] : 0.0);
     int nt = pick_threads(n_threads);
@@ -134,6 +191,27 @@ ORC_API int orc_remap_u8(const uint8_t *src, int H, int W, int C, long src_strid
             int sx = cv_round_f(mx[x] * 32.0f), sy = cv_round_f(my[x] * 32.0f);
             int fx = sx & 31, fy = sy & 31;
             int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+            if (interp == 2) { /* remapBicubic: 4x4 window starting at (ix-1, iy-1) */
+                int x0 = ix - 1, y0 = iy - 1;
+                if (x0 >= W || x0 + 4 <= 0 || y0 >= H || y0 + 4 <= 0) {
+                    for (int c = 0; c < C; ++c) d[c] = cval[c];
+                    continue;
+                }
+                const int16_t *wt = g_cubic_tab + (fy * 32 + fx) * 16;
+                for (int c = 0; c < C; ++c) {
+                    int acc = 0;
+                    for (int ky = 0; ky < 4; ++ky)
+                        for (int kx = 0; kx < 4; ++kx) {
+                            int xx = x0 + kx, yy = y0 + ky;
+                            int v = (xx >= 0 && xx < W && yy >= 0 && yy < H)
+                                        ? src[(size_t)yy * src_stride + (size_t)xx * C + c] : cval[c];
+                            acc += v * wt[ky * 4 + kx];
+                        }
+                    int r = (acc + (1 << 14)) >> 15;
+                    d[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+                }
+                continue;
+            }
             if (ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0) {
                 for (int c = 0; c < C; ++c) d[c] = cval[c];
                 continue;
@@ -411,11 +489,45 @@ static inline void eq_sample_px(const eq_consts *c, const uint8_t *src, long str
     }
 }
 
+/* EQ-SPEC cubic: same quantised coordinate; 4x4 window (ix-1.., iy-1..) with columns wrapping and rows clamping;
+ * OpenCV's fixed-point Keys table; (sum + 2^14) >> 15 saturated. */
+static inline void eq_sample_px_cubic(const eq_consts *c, const uint8_t *src, long stride, int C,
+                                      int sx, int sy, uint8_t *d) {
+    int fx = sx & 31, ix = sx >> 5, fy = sy & 31, iy = sy >> 5;
+    const int16_t *wt = g_cubic_tab + (fy * 32 + fx) * 16;
+    for (int ch = 0; ch < C; ++ch) {
+        int acc = 0;
+        for (int ky = 0; ky < 4; ++ky) {
+            int yy = iy - 1 + ky;
+            yy = yy < 0 ? 0 : (yy > c->H - 1 ? c->H - 1 : yy);
+            for (int kx = 0; kx < 4; ++kx) {
+                int xx = ix - 1 + kx;
+                xx = xx < 0 ? xx + c->W : (xx >= c->W ? xx - c->W : xx);
+                acc += src[(size_t)yy * stride + (size_t)xx * C + ch] * wt[ky * 4 + kx];
+            }
+        }
+        int r = (acc + (1 << 14)) >> 15;
+        d[ch] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
+ORC_API int orc_equirect_views_u8_interp(const uint8_t *src, int W, int H, int C, long src_stride,
+                                         const orc_view *views, int n_views,
+                                         uint8_t *const *dst, long dst_stride, int interp, int n_threads);
+
 /* One frame, n views.  dst[k] -> view k (height x width x C, tight unless dst_stride given).
  * All (view, row) pairs form ONE parallel loop so that many host cores stay busy on small views. */
 ORC_API int orc_equirect_views_u8(const uint8_t *src, int W, int H, int C, long src_stride,
                                   const orc_view *views, int n_views,
                                   uint8_t *const *dst, long dst_stride, int n_threads) {
+    return orc_equirect_views_u8_interp(src, W, H, C, src_stride, views, n_views, dst, dst_stride, 1, n_threads);
+}
+
+ORC_API int orc_equirect_views_u8_interp(const uint8_t *src, int W, int H, int C, long src_stride,
+                                         const orc_view *views, int n_views,
+                                         uint8_t *const *dst, long dst_stride, int interp, int n_threads) {
+    if (interp != 1 && interp != 2) return -3;
+    if (interp == 2) cubic_init();
     if (!src || !views || !dst || C < 1 || C > 4 || W < 2 || H < 2 || n_views < 0) return -1;
     if (n_views == 0) return 0;
     if (src_stride == 0) src_stride = (long)W * C;
@@ -441,7 +553,8 @@ ORC_API int orc_equirect_views_u8(const uint8_t *src, int W, int H, int C, long 
         for (int i = 0; i < c->out_w; ++i) {
             int sx, sy;
             eq_coord(c, i, j, &sx, &sy);
-            eq_sample_px(c, src, src_stride, C, sx, sy, out + (size_t)i * C);
+            if (interp == 2) eq_sample_px_cubic(c, src, src_stride, C, sx, sy, out + (size_t)i * C);
+            else eq_sample_px(c, src, src_stride, C, sx, sy, out + (size_t)i * C);
         }
     }
     free(cs); free(row0);

@@ -44,7 +44,8 @@ def test_cli_renders_full360coverage_folder(tmp_path, orc):
     args.input_is_video, args.video_bit_depth = False, 8
     plan = cut.build_view_jobs(args, sorted((tmp_path / "in").glob("*.png")), out_dir)
     for v in plan.view_specs:
-        want = orc.equirect_views_u8(src[v.source_path.stem], [orc.make_view(v.yaw_deg, v.pitch_deg, v.hfov_deg, v.vfov_deg, v.width, v.height)])[0]
+        want = orc.equirect_views_u8(src[v.source_path.stem], [orc.make_view(v.yaw_deg, v.pitch_deg, v.hfov_deg, v.vfov_deg, v.width, v.height)],
+                                     interp=2)[0]      # the planned argv says interp=cubic (PC:730)
         got = imageio.read_image(out_dir / v.output_name)
         assert np.array_equal(got, want), v.output_name
 
@@ -68,7 +69,7 @@ def test_run_one_is_thread_safe_and_cancellable(tmp_path, orc):
         t.join()
     assert results == [(0, "")] * 6
     for v in plan.view_specs:
-        want = orc.equirect_views_u8(src["pano_000"], [orc.make_view(v.yaw_deg, v.pitch_deg, v.hfov_deg, v.vfov_deg, v.width, v.height)])[0]
+        want = orc.equirect_views_u8(src["pano_000"], [orc.make_view(v.yaw_deg, v.pitch_deg, v.hfov_deg, v.vfov_deg, v.width, v.height)], interp=2)[0]
         assert np.array_equal(imageio.read_image(out_dir / v.output_name), want)
     # missing input -> rc != 0 with text, no exception; cancelled -> 130
     bad = list(plan.jobs[0][0])

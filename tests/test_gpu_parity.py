@@ -122,6 +122,17 @@ def test_equirect_empty_and_errors(ctx):
         ctx.equirect_views(src, [gs360.View.make(0, 0, 90, 90, 8, 8)], interp=gs360.INTERP_NEAREST)
 
 
+@pytest.mark.parametrize("channels", [1, 3, 4])
+def test_equirect_cubic(ctx, orc, channels):
+    """cubic sampler (the reference's default interp, PC:730): wrap columns / clamp rows, OpenCV fixed-point table"""
+    src = rand_image(193, 386, c=channels, seed=71)
+    specs = [(0, 0, 110, 110, 130, 70), (180, 0, 100, 100, 65, 65), (-75.5, 33, 90, 120, 67, 129), (0, 90, 120, 120, 64, 64),
+             (10, -89, 60, 60, 33, 31)]
+    got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], interp=gs360.INTERP_CUBIC)
+    want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], interp=2)
+    _assert_same(got, want, f"equirect cubic C={channels}")
+
+
 # ---- table remap (cv2.remap semantics) ----------------------------------------------------------
 def _rand_maps(h, w, H, W, seed, spread=12.0):
     rng = np.random.default_rng(seed)
@@ -134,7 +145,7 @@ def _rand_maps(h, w, H, W, seed, spread=12.0):
 
 
 @pytest.mark.parametrize("channels", [1, 3, 4])
-@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("interp", [0, 1, 2])
 def test_table_remap_random_maps(ctx, orc, channels, interp):
     H, W, h, w = 97, 131, 75, 108
     src = rand_image(H, W, c=channels, seed=21)
@@ -185,7 +196,7 @@ def test_table_remap_fisheye_maps_from_oracle(ctx, orc):
 
 # ---- fused fisheye (FE-SPEC v1) ---------------------------------------------------------------
 @pytest.mark.parametrize("calib_kw,size", [(TEMPLATE_CALIB, 3840), (FULL_CALIB, None)])
-@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("interp", [0, 1, 2])
 def test_fisheye_fused_vs_oracle_spec(ctx, orc, calib_kw, size, interp):
     kw = dict(calib_kw)
     if size:  # shrink the template sensor 8x to keep the test light

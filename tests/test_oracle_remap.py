@@ -137,3 +137,40 @@ def test_valid_fill_and_threads(orc):
 def test_size_limits(orc):
     with pytest.raises(RuntimeError):
         orc.remap_u8(np.zeros((1, 32767, 1), np.uint8), np.zeros((1, 1), np.float32), np.zeros((1, 1), np.float32))
+
+
+# ---- INTER_CUBIC (restated from the OpenCV source; parity unpinned, see oracle header) ---------------------------
+def test_cubic_table_properties(orc):
+    t = orc.cubic_table().astype(np.int64)
+    assert (t.reshape(1024, 16).sum(axis=1) == 32768).all()          # every phase kernel sums to 2^15 after the fix-up
+    assert t[0, 0, 1, 1] == 32767 and t[0, 0, 2, 2] == 1             # phase 0: short saturation of 1.0 + the +1 patch
+    assert t[0, 0].sum() == 32768 and (t[0, 0] != 0).sum() == 2
+    # Keys A=-0.75 at x = 1/2: (-0.09375, 0.59375, 0.59375, -0.09375) -> outer product * 32768
+    w = np.array([-0.09375, 0.59375, 0.59375, -0.09375])
+    assert np.array_equal(t[16, 16], np.rint(np.outer(w, w) * 32768).astype(np.int64))
+    assert np.array_equal(t[16, 16], t[16, 16].T)
+
+
+def test_cubic_identity_and_constant(orc):
+    src = rand_image(23, 31)
+    xx, yy = grid(23, 31)
+    out = orc.remap_u8(src, xx, yy, interp=2, border_value=(9, 9, 9, 9))
+    assert np.array_equal(out, src)                  # (S*32767 + S22*1 + 16384) >> 15 == S for 8-bit S
+    const = np.full((12, 12, 3), 200, np.uint8)
+    rng = np.random.default_rng(3)
+    mx = rng.uniform(1.5, 9.5, (20, 20)).astype(np.float32)
+    my = rng.uniform(1.5, 9.5, (20, 20)).astype(np.float32)
+    assert (orc.remap_u8(const, mx, my, interp=2) == 200).all()       # kernels sum to exactly 2^15
+
+
+def test_cubic_half_shift_known_answer_and_border(orc):
+    row = np.array([[10, 20, 40, 80, 160, 250]], np.uint8)[:, :, None]
+    src = np.repeat(row, 6, axis=0)
+    mx = np.array([[2.5]], np.float32)
+    my = np.array([[2.0]], np.float32)
+    # fy = 0 -> vertical kernel (0, 32767.., 1 patch) collapses to the row; horizontal (-3072, 19456, 19456, -3072)/32768
+    t = orc.cubic_table().astype(np.int64)[0, 16]
+    want = int(((src[1:5, 1:5, 0].astype(np.int64) * t).sum() + 16384) >> 15)
+    assert int(orc.remap_u8(src, mx, my, interp=2)[0, 0, 0]) == want
+    far = orc.remap_u8(src, np.array([[-3.0, 6.0, 2.0]], np.float32), np.array([[2.0, 2.0, 9.0]], np.float32), interp=2, border_value=77.0)
+    assert far[0, :, 0].tolist() == [77, 77, 77]      # window fully outside: x0+4 <= 0, x0 >= W, y0 >= H
