@@ -75,7 +75,15 @@ struct FeView {
     int32_t tiles_x, tiles_y, tile_base;
 };
 
-struct FeLaunch {
+struct FeCommon {          // per-launch constants of fe_views_kernel (one launch per view)
+    int32_t total_tiles, chunk;
+    int32_t interp, mask_outside, mask_value;
+    int64_t src_stride, dst_stride;
+    uint8_t cval[4];
+    const int16_t* cubic_tab;
+};
+
+struct FeLaunch {          // host-side batch description; launch_fisheye() issues one kernel per view
     FeView view[GS360_MAX_VIEWS];
     int32_t n_views, total_tiles, chunk;
     int32_t interp, mask_outside, mask_value;

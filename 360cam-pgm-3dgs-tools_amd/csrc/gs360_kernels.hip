@@ -393,23 +393,54 @@ __global__ __launch_bounds__(256) void eq_views_cubic_kernel(const EqLaunch L) {
         const uint4* wq = reinterpret_cast<const uint4*>(L.cubic_tab + (fy * 32 + fx) * 16);
         const uint4 wa = wq[0], wb = wq[1];
         const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-        int cols[4];
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            int xx = ix - 1 + kx;
-            cols[kx] = xx < 0 ? xx + L.W : (xx >= L.W ? xx - L.W : xx);
-        }
         int acc[4] = {0, 0, 0, 0};
+        bool fast = false;
+        if constexpr (C == 3) fast = (ix >= 1) && (ix + 2 <= L.W - 3);   // no seam wrap, and the 16-byte aligned read stays in-row
+        if (__all(fast)) {
+            // RGB fast path: the 4 taps of a row are 12 contiguous bytes -> one dword-aligned 16-byte read per row
+            const uint32_t col = (uint32_t)(ix - 1) * 3u;
+            uint32_t taps[4][3];
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            const uint8_t* row = src + (int64_t)min(max(iy - 1 + ky, 0), L.H - 1) * L.src_stride;
+            for (int ky = 0; ky < 4; ++ky) {
+                const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), L.H - 1), (uint32_t)L.src_stride) + col;
+                const uint8_t* p = src + off;
+                const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+                taps[ky][0] = __builtin_amdgcn_alignbyte(d1, d0, o);
+                taps[ky][1] = __builtin_amdgcn_alignbyte(d2, d1, o);
+                taps[ky][2] = __builtin_amdgcn_alignbyte(d3, d2, o);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const uint32_t pk = wpk[(ky * 4 + kx) >> 1];
+                    const int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int bi = kx * 3 + c;
+                        acc[c] += (int)byte_of(taps[ky][bi >> 2], bi & 3) * w;
+                    }
+                }
+        } else {
+            int cols[4];
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
-                uint32_t pk = wpk[(ky * 4 + kx) >> 1];
-                int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
-                const uint8_t* px = row + (int64_t)cols[kx] * C;
+                int xx = ix - 1 + kx;
+                cols[kx] = xx < 0 ? xx + L.W : (xx >= L.W ? xx - L.W : xx);
+            }
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] += (int)px[c] * w;
+            for (int ky = 0; ky < 4; ++ky) {
+                const uint8_t* row = src + (int64_t)min(max(iy - 1 + ky, 0), L.H - 1) * L.src_stride;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    uint32_t pk = wpk[(ky * 4 + kx) >> 1];
+                    int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
+                    const uint8_t* px = row + (int64_t)cols[kx] * C;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += (int)px[c] * w;
+                }
             }
         }
         uint32_t px[4];
@@ -554,16 +585,15 @@ __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, i
 // ------------------------------------------------------------------------------------------------
 // FE-SPEC v1: fused fisheye -> perspective
 // ------------------------------------------------------------------------------------------------
+// One launch per view: the view block travels as a plain by-value kernel argument (SGPR-resident).  Indexing an
+// array of these 148-byte blocks dynamically made the compiler spill the whole argument struct to scratch
+// (2368 B/lane, 13x slower), so the host loops over views instead.
 template <int C>
-__global__ __launch_bounds__(256) void fe_views_kernel(const FeLaunch L) {
+__global__ __launch_bounds__(256) void fe_views_kernel(const FeView V, const FeCommon L) {
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
     if (t >= L.total_tiles) return;
-    int k = 0;
-    while (k + 1 < L.n_views && t >= L.view[k + 1].tile_base) ++k;
-    const FeView& V = L.view[k];
-    int r = t - V.tile_base;
-    int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
+    int tile_y = t / V.tiles_x, tile_x = t - tile_y * V.tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = tile_x * kTileW;
     const int n_px = min(kTileW, V.out_w - x0);
@@ -650,14 +680,25 @@ hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
 }
 
 hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s) {
-    dim3 grid((unsigned)(L.chunk * 8)), block(256);
-    switch (C) {
-        case 1: hipLaunchKernelGGL(fe_views_kernel<1>, grid, block, 0, s, L); break;
-        case 3: hipLaunchKernelGGL(fe_views_kernel<3>, grid, block, 0, s, L); break;
-        case 4: hipLaunchKernelGGL(fe_views_kernel<4>, grid, block, 0, s, L); break;
-        default: return hipErrorInvalidValue;
+    for (int k = 0; k < L.n_views; ++k) {
+        FeCommon K;
+        K.total_tiles = L.view[k].tiles_x * L.view[k].tiles_y;
+        K.chunk = (K.total_tiles + 7) / 8;
+        K.interp = L.interp; K.mask_outside = L.mask_outside; K.mask_value = L.mask_value;
+        K.src_stride = L.src_stride; K.dst_stride = L.dst_stride;
+        for (int i = 0; i < 4; ++i) K.cval[i] = L.cval[i];
+        K.cubic_tab = L.cubic_tab;
+        dim3 grid((unsigned)(K.chunk * 8)), block(256);
+        switch (C) {
+            case 1: hipLaunchKernelGGL(fe_views_kernel<1>, grid, block, 0, s, L.view[k], K); break;
+            case 3: hipLaunchKernelGGL(fe_views_kernel<3>, grid, block, 0, s, L.view[k], K); break;
+            case 4: hipLaunchKernelGGL(fe_views_kernel<4>, grid, block, 0, s, L.view[k], K); break;
+            default: return hipErrorInvalidValue;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 }  // namespace gs360

@@ -259,7 +259,7 @@ class Context:
         fn, h, L = self.L.gs360_equirect_views_u8, self.handle, self.L
 
         def call():
-            rc = fn(h, fp, nf, W, H, Cn, 0, va, nv, dp, 0, interp, 0, slot)
+            rc = fn(h, fp, nf, W, H, Cn, 0, va, nv, dp, 0, int(interp), 0, slot)
             if rc:
                 _check(rc, L)
         call.keepalive = (fp, dp, va)

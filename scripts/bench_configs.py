@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Secondary measurements: the other BASELINE.json configs (device-resident, HIP-event timed, parity-checked on one
+view each).  Informational -- bench.py (cfg2) is the headline.  Prints one JSON object per config.
+
+    python scripts/bench_configs.py [--steps 50]
+"""
+import argparse
+import json
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "360cam-pgm-3dgs-tools_amd"))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+
+import gs360  # noqa: E402
+from gs360 import fisheye as fe  # noqa: E402
+from oracle import orc  # noqa: E402  (checker + algorithmic-byte counter only)
+from util import PRESET_FISHEYELIKE, PRESET_FULL360, HFOV_12MM, HFOV_14MM, HFOV_17MM, TEMPLATE_CALIB, ring_views  # noqa: E402
+
+
+def synth(h, w, k=0, c=3):
+    x = np.arange(w, dtype=np.uint32)[None, :]
+    y = np.arange(h, dtype=np.uint32)[:, None]
+    n = (((x * np.uint32(2654435761)) ^ (y * np.uint32(40503 + 977 * k))) >> np.uint32(27)).astype(np.uint8)
+    img = np.empty((h, w, c), np.uint8)
+    for ch in range(c):
+        img[..., ch] = (((x + 31 * ch) * 255) // w).astype(np.uint8) + n
+    return img
+
+
+def time_steps(ctx, call, steps, warmup=5):
+    for _ in range(warmup):
+        call()
+    ctx.sync(-1)
+    ctx.event_record(0, 0)
+    for _ in range(steps):
+        call()
+    ctx.event_record(0, 1)
+    return ctx.event_elapsed_ms(0, 0, 1) / steps
+
+
+def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR):
+    frames = [synth(H, W, k) for k in range(n_frames)]
+    d_fr = [ctx.to_device(f) for f in frames]
+    views = [gs360.View.make(*s) for s in specs]
+    d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(n_frames) for s in specs]
+    fp_call = ctx.make_equirect_call(d_fr, W, H, 3, views, d_out, slot=0, interp=interp)
+    ms = time_steps(ctx, fp_call, steps)
+    # parity of one view of frame 0, algorithmic bytes from the oracle
+    k = len(specs) // 2
+    got = ctx.download(d_out[k], (specs[k][5], specs[k][4], 3))
+    want = orc.equirect_views_u8(frames[0], [orc.make_view(*specs[k])], threads=0, interp=2 if interp == 2 else 1)[0]
+    uv = sum(orc.equirect_distinct_texels(orc.make_view(*s), W, H) for s in specs)
+    out_px = sum(s[4] * s[5] for s in specs)
+    algo = (out_px * 3 + uv * 3) * n_frames
+    for b in d_fr + d_out:
+        ctx.free(b)
+    return {"config": name, "frames_per_launch": n_frames, "views": len(specs), "out_MPix_per_frame": round(out_px / 1e6, 2),
+            "ms_per_launch": round(ms, 4), "us_per_frame": round(ms / n_frames * 1e3, 1),
+            "MPix_per_s": round(out_px * n_frames / ms / 1e3, 0), "algorithmic_MB_per_frame": round(algo / n_frames / 1e6, 1),
+            "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
+            "parity_vs_oracle": bool(np.array_equal(got, want))}
+
+
+def fisheye_cfg(ctx, steps):
+    cal_kw = dict(TEMPLATE_CALIB, width=4000, height=4000)
+    c = fe.SensorCalibration("0", "equisolid_fisheye", cal_kw["width"], cal_kw["height"], cal_kw["f"], cal_kw["cx"], cal_kw["cy"],
+                             cal_kw["k1"], cal_kw["k2"], cal_kw["k3"])
+    specs = fe.sfm10_specs(1750, 14.0, "36 36", 40.0, 40.0)[:6]          # BASELINE cfg4: 6 views
+    tables = fe.choose_lens_tables({"0": c}, "0", "0", specs, 0.0, 180.0, 190.0)
+    imgs = {"X": synth(4000, 4000, 1), "Y": synth(4000, 4000, 2)}
+    dev = {k: ctx.to_device(v) for k, v in imgs.items()}
+    res = []
+    d_tab = {v: (ctx.to_device(t["map_x"]), ctx.to_device(t["map_y"]), ctx.to_device(np.ascontiguousarray(t["valid"], np.uint8)))
+             for v, t in tables.items()}
+    d_out = {v: ctx.alloc(1750 * 1750 * 3) for v in tables}
+
+    def table_call():
+        for spec in specs:
+            v = spec["view_id"]
+            t = tables[v]
+            ctx.remap_table_dev(dev[t["lens_key"]], 4000, 4000, 3, d_tab[v][0], d_tab[v][1], d_tab[v][2], 1750, 1750, d_out[v],
+                                interp=1, border_value=(0, 0, 0, 0), fill_value=0, slot=0)
+    ms = time_steps(ctx, table_call, steps)
+    v0 = specs[1]["view_id"]
+    t = tables[v0]
+    got = ctx.download(d_out[v0], (1750, 1750, 3))
+    want = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=1, threads=0), t["valid"], 0)
+    uv = sum(orc.table_distinct_texels(tables[s["view_id"]]["map_x"], tables[s["view_id"]]["map_y"], 4000, 4000) for s in specs)
+    px = 6 * 1750 * 1750
+    algo_table = px * (3 + 8 + 1) + uv * 3
+    res.append({"config": "cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, TABLE mode (reference-identical maps)", "ms_per_pair": round(ms, 4),
+                "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_table / 1e6, 1),
+                "achieved_GB_per_s": round(algo_table / ms / 1e6, 0), "frac_of_8TBps": round(algo_table / ms / 1e6 / 8000, 3),
+                "parity_vs_oracle": bool(np.array_equal(got, want))})
+    calib = gs360.Calib.make(c.width, c.height, c.f, c.cx, c.cy, c.k1, c.k2, c.k3)
+    views = [gs360.View.make(tables[s["view_id"]]["yaw_rel_deg"], s["pitch_deg"], s["hfov_deg"], s["vfov_deg"], 1750, 1750) for s in specs]
+    srcs = [dev[tables[s["view_id"]]["lens_key"]] for s in specs]
+    outs = [d_out[s["view_id"]] for s in specs]
+
+    def fused_call():
+        ctx.fisheye_views_dev(srcs, [calib] * 6, 3, views, 190.0, outs, interp=1, mask_outside=True, mask_value=0, slot=0)
+    ms = time_steps(ctx, fused_call, steps)
+    s1 = specs[1]
+    mx, my, valid = orc.fisheye_spec_map(orc.make_calib(c.width, c.height, c.f, c.cx, c.cy, c.k1, c.k2, c.k3),
+                                         tables[v0]["yaw_rel_deg"], s1["pitch_deg"], s1["hfov_deg"], s1["vfov_deg"], 1750, 1750, 190.0)
+    want = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], mx, my, interp=1, threads=0), valid, 0)
+    got = ctx.download(d_out[v0], (1750, 1750, 3))
+    algo_fused = px * 3 + uv * 3
+    res.append({"config": "cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, FUSED mode (FE-SPEC v1, no map traffic)", "ms_per_pair": round(ms, 4),
+                "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_fused / 1e6, 1),
+                "achieved_GB_per_s": round(algo_fused / ms / 1e6, 0), "frac_of_8TBps": round(algo_fused / ms / 1e6 / 8000, 3),
+                "parity_vs_oracle": bool(np.array_equal(got, want))})
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    args = ap.parse_args()
+    ctx = gs360.Context(0, n_slots=1)
+    rows = []
+    rows.append(equirect_cfg(ctx, "cfg1 5760x2880 -> default preset 8x1600^2", 5760, 2880, ring_views(8, 1600, HFOV_12MM), 8, args.steps))
+    rows.append(equirect_cfg(ctx, "cfg2 7680x3840 -> 6x800^2 (headline, bench.py)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps))
+    rows.append(equirect_cfg(ctx, "cfg2 with INTER_CUBIC (reference default interp)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps,
+                             interp=gs360.INTERP_CUBIC))
+    rows.append(equirect_cfg(ctx, "cfg3 7680x3840 -> full360coverage 12x1600^2", 7680, 3840,
+                             [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps))
+    rows.append(equirect_cfg(ctx, "cfg5 7680x3840 -> fisheyelike 10x2048^2 (u8, no fp16/mask fusion)", 7680, 3840,
+                             [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps))
+    rows += fisheye_cfg(ctx, args.steps)
+    for r in rows:
+        print(json.dumps(r))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
