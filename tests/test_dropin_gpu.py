@@ -81,3 +81,32 @@ def test_run_one_is_thread_safe_and_cancellable(tmp_path, orc):
         assert cut.run_one(plan.jobs[0][0]) == (130, "")
     finally:
         cut.stop_event.clear()
+
+
+def test_engine_sharding_is_deterministic_across_device_counts(tmp_path, orc):
+    """frames shard across devices by source path; the output set must not depend on how many devices take part.
+    Two engine contexts on the one visible GPU stand in for two devices."""
+    from gs360 import engine as eng
+    from gs360.jobspec import parse_job_argv
+    src = make_panos(tmp_path / "in", n=5, w=256, h=128)
+    args = cut.create_arg_parser().parse_args(["-i", str(tmp_path / "in"), "--count", "3", "--size", "48", "--ext", "png"])
+    for a in ("size", "hfov", "focal_mm"):
+        setattr(args, a + "_explicit", getattr(args, a + "_explicit", False))
+    args.input_is_video, args.video_bit_depth = False, 8
+    results = {}
+    for tag, devices in (("one", [0]), ("two", [0, 0]), ("three", [0, 0, 0])):
+        out_dir = tmp_path / f"out_{tag}"
+        plan = cut.build_view_jobs(args, sorted((tmp_path / "in").glob("*.png")), out_dir)
+        e = eng.Engine(devices=devices)
+        used = set()
+        for argv, _s, _d in plan.jobs:
+            job = parse_job_argv(argv)
+            used.add(e.device_for(job.src))
+            e.run_job(job)
+        e.close()
+        results[tag] = {p.name: imageio.read_image(p) for p in sorted(out_dir.iterdir())}
+        assert len(results[tag]) == 15
+        if len(devices) > 1:
+            assert len(used) > 1          # the frames really were spread over several contexts
+    for name, img in results["one"].items():
+        assert np.array_equal(img, results["two"][name]) and np.array_equal(img, results["three"][name])
