@@ -245,3 +245,52 @@ def test_frame_pipeline_pinned_streams(ctx, orc):
     for k, f in enumerate(frames):
         want = orc.equirect_views_u8(f, [orc.make_view(*s) for s in specs])
         _assert_same(got[k], want, f"pipeline frame {k}")
+
+
+# ---- full BASELINE sizes: bit-exact where the oracle is fast enough, size-independent properties otherwise -------
+def test_full_size_cfg3_full360coverage_checks(ctx, orc):
+    """BASELINE cfg3 frame: 7680x3840 -> 12 x 1600^2 (full360coverage).  Every byte of 3 views (level, +30, -30
+    pitch) against the oracle, plus a checksum over all 12."""
+    src = rand_image(3840, 7680, seed=33)
+    specs = [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360]
+    got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs])
+    pick = [0, 1, 8]
+    want = orc.equirect_views_u8(src, [orc.make_view(*specs[k]) for k in pick], threads=0)
+    _assert_same([got[k] for k in pick], want, "cfg3 full size")
+    all_want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], threads=0)
+    assert [int(g.astype(np.uint64).sum()) for g in got] == [int(w.astype(np.uint64).sum()) for w in all_want]
+
+
+def test_full_size_properties_roll_constant_symmetry(ctx):
+    """size-independent properties at 8K / 2048^2 (BASELINE cfg5 shape), GPU against itself:
+    (a) rolling the panorama by k texels == yawing the camera by k texels; (b) a constant image stays constant;
+    (c) a left-right mirrored panorama gives the mirrored view for yaw 0."""
+    H, W = 3840, 7680
+    src = rand_image(H, W, seed=34)
+    v0 = gs360.View.make(0.0, 30.0, HFOV_17MM, HFOV_17MM, 2048, 2048)
+    k = 640
+    vk = gs360.View.make(360.0 * k / W, 30.0, HFOV_17MM, HFOV_17MM, 2048, 2048)     # exactly k texels: 30 degrees
+    a = ctx.equirect_views(np.ascontiguousarray(np.roll(src, -k, axis=1)), [v0])[0]
+    b = ctx.equirect_views(src, [vk])[0]
+    assert np.array_equal(a, b)
+    const = np.full((H, W, 3), 93, np.uint8)
+    assert (ctx.equirect_views(const, [vk])[0] == 93).all()
+    # mirror: texel centres sit at half-integers, so flipping the panorama left-right maps column c -> W-1-c and the
+    # yaw-0 view onto its own mirror image; the 1/32-px quantisation is symmetric except on exact .5 ties
+    lvl = gs360.View.make(0.0, 0.0, HFOV_17MM, HFOV_17MM, 2048, 2048)
+    m = ctx.equirect_views(np.ascontiguousarray(src[:, ::-1]), [lvl])[0][:, ::-1]
+    d = np.abs(m.astype(int) - ctx.equirect_views(src, [lvl])[0].astype(int))
+    assert (d > 0).mean() < 0.08 and d.max() <= 24        # only rounding-tie buckets may differ, by one 1/32-px step
+
+
+def test_full_size_cfg4_table_remap_template_sensor(ctx, orc):
+    """BASELINE cfg4 shape with the shipped template calibration: 3840^2 lens -> 1750^2 view, reference-identical
+    host tables sampled on the GPU vs the oracle's cv2.remap restatement on the same tables (linear + cubic)."""
+    from gs360 import fisheye as fe
+    c = fe.SensorCalibration("0", "equisolid_fisheye", **TEMPLATE_CALIB)
+    mx, my, valid = fe.perspective_tables(c, 40.0, 0.0, HFOV_14MM, HFOV_14MM, 1750, 1750, 190.0)
+    src = rand_image(3840, 3840, seed=35)
+    for interp in (1, 2):
+        got = ctx.remap(src, mx, my, interpolation=interp, border_value=0.0, valid=valid, fill_value=0)
+        want = orc.valid_fill(orc.remap_u8(src, mx, my, interp=interp, border_value=0.0, threads=0), valid, 0)
+        _assert_same([got], [want], f"cfg4 full size interp={interp}")
