@@ -351,7 +351,8 @@ int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_f
     if (n_frames < 0 || n_views < 0) return fail(GS360_ERR_ARG, "negative count");
     if (n_frames == 0 || n_views == 0) return GS360_OK;  // empty batch is a no-op
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
-    if (W < 2 || H < 2 || W > (1 << 21) || H > (1 << 21)) return fail(GS360_ERR_ARG, "bad source size %dx%d", W, H);
+    if (W < 8 || H < 2 || W > (1 << 21) || H > (1 << 21))
+        return fail(GS360_ERR_ARG, "bad source size %dx%d (an equirect frame is at least 8 texels wide)", W, H);
     if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_CUBIC)
         return fail(GS360_ERR_UNSUPPORTED, "equirect path implements INTER_LINEAR (1) and INTER_CUBIC (2), got %d", interp);
     if (flags != 0) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
@@ -445,6 +446,7 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     L.fill = fill_value < 0 ? 0 : (fill_value > 255 ? 255 : fill_value);
     for (int k = 0; k < 4; ++k) L.cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
     L.cubic_tab = c->d_cubic;
+    L.pipelined = (W >= 8 && src_stride < ((size_t)1 << 24) && (uint64_t)src_stride * (uint64_t)H < ((uint64_t)1 << 32)) ? 1 : 0;
     HIP_TRY(launch_table(L, C, c->stream[slot]));
     return GS360_OK;
 }
@@ -495,6 +497,10 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
         L.dst_stride = (int64_t)dst_stride;
         L.cval[0] = (uint8_t)mask_value;  // borderValue=float(mask_value) -> Scalar(v,0,0,0), DF:2007
         L.cubic_tab = c->d_cubic;
+        L.pipelined = 1;
+        for (int k = 0; k < nv; ++k)
+            if (calibs[v0 + k].width < 8 || (uint64_t)L.src_stride * (uint64_t)calibs[v0 + k].height >= ((uint64_t)1 << 32)) L.pipelined = 0;
+        if ((uint64_t)L.src_stride >= ((uint64_t)1 << 24)) L.pipelined = 0;
         HIP_TRY(launch_fisheye(L, C, c->stream[slot]));
     }
     return GS360_OK;

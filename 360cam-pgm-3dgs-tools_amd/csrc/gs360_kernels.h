@@ -58,6 +58,7 @@ struct TableLaunch {
     int32_t fill;
     uint8_t cval[4];
     const int16_t* cubic_tab;
+    int32_t pipelined;   // W >= 8 and 32-bit tap offsets: split fetch/blend path allowed
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -81,6 +82,7 @@ struct FeCommon {          // per-launch constants of fe_views_kernel (one launc
     int64_t src_stride, dst_stride;
     uint8_t cval[4];
     const int16_t* cubic_tab;
+    int32_t pipelined;
 };
 
 struct FeLaunch {          // host-side batch description; launch_fisheye() issues one kernel per view
@@ -90,6 +92,7 @@ struct FeLaunch {          // host-side batch description; launch_fisheye() issu
     int64_t src_stride, dst_stride;
     uint8_t cval[4];
     const int16_t* cubic_tab;
+    int32_t pipelined;
 };
 
 // kernel launchers (gs360_kernels.hip)

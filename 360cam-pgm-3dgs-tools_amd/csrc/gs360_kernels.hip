@@ -553,6 +553,56 @@ __device__ __forceinline__ void cv_sample_cubic(const uint8_t* __restrict__ src,
     }
 }
 
+// Split bilinear fetch for cv2 semantics (same idea as eq_fetch): the two row reads are issued unconditionally from
+// a clamped, always-valid position so that a wavefront keeps all its gathers in flight; `fast` says the 2x2
+// footprint was fully inside the image and the wide read stayed in-row, otherwise the pixel is redone afterwards by
+// the straight-line border path (cv_sample_linear).  Needs W >= 8 and 32-bit tap offsets (checked on the host).
+template <int C>
+struct CvTaps {
+    uint2 t0, t1;
+    int fx, fy;
+    bool fast;
+};
+
+template <int C>
+__device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
+                                                     float mx, float my) {
+    const int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
+    const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+    constexpr int kBack = (C == 3) ? 5 : 2;
+    CvTaps<C> t;
+    t.fx = sx & 31;
+    t.fy = sy & 31;
+    t.fast = ix >= 0 && iy >= 0 && ix <= W - kBack && iy < H - 1;
+    const int xa = min(max(ix, 0), W - kBack), ya = min(max(iy, 0), H - 1), yb = min(ya + 1, H - 1);
+    const uint32_t col = (uint32_t)xa * C;
+    const uint8_t* r0 = src + (__umul24((uint32_t)ya, (uint32_t)stride) + col);
+    const uint8_t* r1 = src + (__umul24((uint32_t)yb, (uint32_t)stride) + col);
+    if constexpr (C == 1) {
+        uint16_t a, b;
+        __builtin_memcpy(&a, r0, 2);
+        __builtin_memcpy(&b, r1, 2);
+        t.t0 = make_uint2(a, 0);
+        t.t1 = make_uint2(b, 0);
+    } else if constexpr (C == 3) {
+        t.t0 = ld_u64_via_aligned96(r0);
+        t.t1 = ld_u64_via_aligned96(r1);
+    } else {
+        t.t0 = ld_u64(r0);
+        t.t1 = ld_u64(r1);
+    }
+    return t;
+}
+
+template <int C>
+__device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out)[4]) {
+    EqTaps<C> e;
+    e.t0 = t.t0;
+    e.t1 = t.t1;
+    e.fix = false;
+    eq_blend<C>(e, t.fx, t.fy, out);     // same 1/32-px weights: only the fractional bits of sx, sy are used
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
     int b = blockIdx.x;
@@ -564,7 +614,44 @@ __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, i
     const int n_px = min(kTileW, L.w - x0);
     const int xc = min(x0 + lane, L.w - 1);
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
+    if (L.interp == GS360_INTERP_LINEAR && L.pipelined) {
+        // maps of the wavefront's 4 rows -> all 8 gathers in flight -> blend -> border/valid fix-ups -> packed stores
+        const int ybase = tile_y * kTileH + wave * kRowsPerWave;
+        float mxs[kRowsPerWave], mys[kRowsPerWave];
+        bool inval[kRowsPerWave];
 #pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) {
+            const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
+            mxs[rr] = L.map_x[o];
+            mys[rr] = L.map_y[o];
+            inval[rr] = L.valid && !L.valid[o];
+        }
+        CvTaps<C> taps[kRowsPerWave];
+        bool any_slow = false;
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) {
+            taps[rr] = cv_fetch_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr]);
+            any_slow |= !taps[rr].fast;
+        }
+        uint32_t px[kRowsPerWave][4];
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
+        if (__any(any_slow)) {
+#pragma unroll
+            for (int rr = 0; rr < kRowsPerWave; ++rr)
+                if (!taps[rr].fast) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) {
+            if (inval[rr]) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.fill;
+            }
+            const int y = ybase + rr;
+            if (y < L.h) store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4);
+        }
+        return;
+    }
     for (int rr = 0; rr < kRowsPerWave; ++rr) {
         const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
         if (y >= L.h) break;
@@ -602,10 +689,13 @@ __global__ __launch_bounds__(256) void fe_views_kernel(const FeView V, const FeC
     const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(V.dst) & 3) == 0);
     const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
 
+    const int ybase = tile_y * kTileH + wave * kRowsPerWave;
+    const bool pipelined = (L.interp == GS360_INTERP_LINEAR) && L.pipelined;
+    float mxs[kRowsPerWave], mys[kRowsPerWave];
+    bool oks[kRowsPerWave];
 #pragma unroll
     for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
-        if (y >= V.out_h) break;
+        const int y = min(ybase + rr, V.out_h - 1);
         float yv = (float)(2 * y + 1 - V.out_h) * V.syv;       // ray y = -yv
         float Y = __builtin_fmaf(-V.cp, yv, V.sp);
         float z1 = __builtin_fmaf(V.sp, yv, V.cp);
@@ -627,17 +717,43 @@ __global__ __launch_bounds__(256) void fe_views_kernel(const FeView V, const FeC
         }
         float mx = __builtin_fmaf(yd, V.b2, __builtin_fmaf(xd, V.b1, __builtin_fmaf(xd, V.f, V.cx0)));
         float my = __builtin_fmaf(yd, V.f, V.cy0);
-        bool ok = (Z >= V.cos_tmax * N) && (mx >= 0.0f) && (mx <= V.wmax) && (my >= 0.0f) && (my <= V.hmax);
-        uint32_t px[4];
-        if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px);
-        else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, L.cubic_tab, px);
-        else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, px);
-        if (!ok && L.mask_outside) {
+        mxs[rr] = mx;
+        mys[rr] = my;
+        oks[rr] = (Z >= V.cos_tmax * N) && (mx >= 0.0f) && (mx <= V.wmax) && (my >= 0.0f) && (my <= V.hmax);
+    }
+    uint32_t px[kRowsPerWave][4];
+    if (pipelined) {
+        CvTaps<C> taps[kRowsPerWave];
+        bool any_slow = false;
 #pragma unroll
-            for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.mask_value;
+        for (int rr = 0; rr < kRowsPerWave; ++rr) {
+            taps[rr] = cv_fetch_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr]);
+            any_slow |= !taps[rr].fast;
         }
-        store_row<C>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px, n_px, aligned4);
-        if (V.valid_out && lane < n_px) V.valid_out[(int64_t)y * V.out_w + x0 + lane] = ok ? 1 : 0;
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
+        if (__any(any_slow)) {
+#pragma unroll
+            for (int rr = 0; rr < kRowsPerWave; ++rr)
+                if (!taps[rr].fast) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
+        }
+    } else {
+        for (int rr = 0; rr < kRowsPerWave; ++rr) {
+            if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
+            else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
+            else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int y = ybase + rr;
+        if (y >= V.out_h) break;
+        if (!oks[rr] && L.mask_outside) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.mask_value;
+        }
+        store_row<C>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4);
+        if (V.valid_out && lane < n_px) V.valid_out[(int64_t)y * V.out_w + x0 + lane] = oks[rr] ? 1 : 0;
     }
 }
 
@@ -688,6 +804,7 @@ hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s) {
         K.src_stride = L.src_stride; K.dst_stride = L.dst_stride;
         for (int i = 0; i < 4; ++i) K.cval[i] = L.cval[i];
         K.cubic_tab = L.cubic_tab;
+        K.pipelined = L.pipelined;
         dim3 grid((unsigned)(K.chunk * 8)), block(256);
         switch (C) {
             case 1: hipLaunchKernelGGL(fe_views_kernel<1>, grid, block, 0, s, L.view[k], K); break;

@@ -250,7 +250,7 @@ class Context:
         _check(self.L.gs360_equirect_views_u8(self.handle, fp, nf, W, H, Cn, src_stride, va, nv, dp, dst_stride,
                                               interp, 0, slot), self.L)
 
-    def make_equirect_call(self, frames, W, H, Cn, views, dsts, slot=0, interp=INTERP_LINEAR):
+    def make_equirect_call(self, frames, W, H, Cn, views, dsts, slot=0, interp=INTERP_LINEAR, src_stride=0):
         """Pre-marshal one batched launch; returns a zero-argument callable (used by bench loops)."""
         nf, nv = len(frames), len(views)
         fp = (C.c_void_p * nf)(*[b.ptr for b in frames])
@@ -259,7 +259,7 @@ class Context:
         fn, h, L = self.L.gs360_equirect_views_u8, self.handle, self.L
 
         def call():
-            rc = fn(h, fp, nf, W, H, Cn, 0, va, nv, dp, 0, int(interp), 0, slot)
+            rc = fn(h, fp, nf, W, H, Cn, int(src_stride), va, nv, dp, 0, int(interp), 0, slot)
             if rc:
                 _check(rc, L)
         call.keepalive = (fp, dp, va)

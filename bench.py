@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct HBM-resident frames per step (one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
+    ap.add_argument("--stride-pad", type=int, default=0, help="experiments only: extra bytes per source row")
     ap.add_argument("--src-width", type=int, default=7680, help="experiments only: equirect width (height = width/2); "
                     "any value other than 7680 is NOT the BASELINE workload and is labelled as such")
     args = ap.parse_args()
@@ -134,9 +135,18 @@ def main():
     views = [gs360.View.make(*v) for v in view_table()]
     nf = max(1, min(args.frames, gs360.capi.MAX_FRAMES))
     frames_host = [synth_frame(np, k + 7 * rank) for k in range(nf)]
-    d_frames = [ctx.to_device(f) for f in frames_host]
+    stride = W * C + args.stride_pad
+    if args.stride_pad:
+        padded = []
+        for f in frames_host:
+            buf = np.zeros((H, stride), np.uint8)
+            buf[:, :W * C] = f.reshape(H, W * C)
+            padded.append(buf)
+        d_frames = [ctx.to_device(b) for b in padded]
+    else:
+        d_frames = [ctx.to_device(f) for f in frames_host]
     d_out = [ctx.alloc(SIZE * SIZE * C) for _ in range(nf * N_VIEWS)]
-    step = ctx.make_equirect_call(d_frames, W, H, C, views, d_out, slot=0)
+    step = ctx.make_equirect_call(d_frames, W, H, C, views, d_out, slot=0, src_stride=stride if args.stride_pad else 0)
 
     def barrier():
         ctx.sync(-1)
