@@ -401,17 +401,7 @@ int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_f
             L.src_stride = (int64_t)src_stride;
             L.dst_stride = (int64_t)dst_stride;
             L.cubic_tab = c->d_cubic;
-            if (interp == GS360_INTERP_CUBIC) {   // per-pixel kernel: full-width, full-height tiles
-                int cbase = 0;
-                for (int k = 0; k < nv; ++k) {
-                    L.view[k].tiles_x = (L.view[k].out_w + kTileW - 1) / kTileW;
-                    L.view[k].tiles_y = (L.view[k].out_h + kTileH - 1) / kTileH;
-                    L.view[k].tile_base = cbase;
-                    cbase += L.view[k].tiles_x * L.view[k].tiles_y;
-                }
-                L.tiles_per_frame = cbase;
-                L.total_tiles = cbase * nf;
-                L.chunk = (L.total_tiles + 7) / 8;
+            if (interp == GS360_INTERP_CUBIC) {   // same tiling and symmetry reuse, 4x4 taps
                 HIP_TRY(launch_equirect_cubic(L, C, c->stream[slot]));
             } else {
                 HIP_TRY(launch_equirect(L, C, c->stream[slot]));

@@ -220,14 +220,120 @@ __device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, 
     return sx;
 }
 
+// ---- cubic variant of the equirect sampler (4x4 Keys taps, OpenCV fixed-point table) -------------------------------
+// eq_cubic_fetch issues the 4 row reads of one RGB pixel (12 contiguous bytes each, fetched as a dword-aligned 16-byte
+// read) plus the 32-byte weight entry without control flow; lanes whose window touches the seam or the last columns are
+// flagged and redone by eq_cubic_slow.
+struct EqCubicTaps {
+    uint32_t row[4][3];   // 12 tap bytes of each window row
+    uint4 wa, wb;         // 16 int16 weights
+    bool fix;
+};
+
+__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const uint8_t* __restrict__ src, int sx, int sy) {
+    const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
+    EqCubicTaps t;
+    const int x0 = min(max(ix - 1, 0), L.W - 6);            // 16-byte aligned read of 12 tap bytes stays in-row
+    t.fix = (x0 != ix - 1);
+    const uint4* wq = reinterpret_cast<const uint4*>(L.cubic_tab + (fy * 32 + fx) * 16);
+    t.wa = wq[0];
+    t.wb = wq[1];
+    const uint32_t col = (uint32_t)x0 * 3u;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), L.H - 1), (uint32_t)L.src_stride) + col;
+        const uint8_t* p = src + off;
+        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+        t.row[ky][0] = __builtin_amdgcn_alignbyte(d1, d0, o);
+        t.row[ky][1] = __builtin_amdgcn_alignbyte(d2, d1, o);
+        t.row[ky][2] = __builtin_amdgcn_alignbyte(d3, d2, o);
+    }
+    return t;
+}
+
+__device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, uint32_t (&out)[4]) {
+    const uint32_t wpk[8] = {t.wa.x, t.wa.y, t.wa.z, t.wa.w, t.wb.x, t.wb.y, t.wb.z, t.wb.w};
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const uint32_t pk = wpk[(ky * 4 + kx) >> 1];
+            const int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int bi = kx * 3 + c;
+                acc[c] += (int)byte_of(t.row[ky][bi >> 2], bi & 3) * w;
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((acc[c] + (1 << 14)) >> 15, 0), 255);
+}
+
+// generic cubic sample: columns wrap, rows clamp (any channel count; also the repair path of the RGB fast path)
+template <int C>
+__device__ __forceinline__ void eq_cubic_slow(const EqLaunch& L, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
+    const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
+    const uint4* wq = reinterpret_cast<const uint4*>(L.cubic_tab + (fy * 32 + fx) * 16);
+    const uint4 wa = wq[0], wb = wq[1];
+    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    int cols[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+        int xx = ix - 1 + kx;
+        cols[kx] = xx < 0 ? xx + L.W : (xx >= L.W ? xx - L.W : xx);
+    }
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint8_t* row = src + (int64_t)min(max(iy - 1 + ky, 0), L.H - 1) * L.src_stride;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const uint32_t pk = wpk[(ky * 4 + kx) >> 1];
+            const int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
+            const uint8_t* px = row + (int64_t)cols[kx] * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += (int)px[c] * w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = (uint32_t)min(max((acc[c] + (1 << 14)) >> 15, 0), 255);
+}
+
 // One pass over the wavefront's 4 row slots for one column per lane: all gathers first, then blend, repair, store.
 //   reversed = false: lane l is pixel l of the row segment starting at `col0`
 //   reversed = true : lane l is pixel n_px-1-l (the mirrored half of the view)
-template <int C>
+template <int C, bool CUBIC>
 __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __restrict__ src, uint8_t* dst, int64_t dstride,
                                         const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
                                         const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
                                         int col0, int n_px, bool reversed, bool aligned4, bool skip_first) {
+    if constexpr (CUBIC) {
+        uint32_t px[kRowsPerWave][4];
+        if constexpr (C == 3) {
+            // two row slots at a time: 8 tap reads + 4 weight reads in flight, 24 tap dwords live
+#pragma unroll
+            for (int s0 = 0; s0 < kRowsPerWave; s0 += 2) {
+                EqCubicTaps ta = eq_cubic_fetch(L, src, sxs[s0], sys[s0]);
+                EqCubicTaps tb = eq_cubic_fetch(L, src, sxs[s0 + 1], sys[s0 + 1]);
+                eq_cubic_blend(ta, px[s0]);
+                eq_cubic_blend(tb, px[s0 + 1]);
+                if (__any(ta.fix | tb.fix)) {
+                    if (ta.fix) eq_cubic_slow<C>(L, src, sxs[s0], sys[s0], px[s0]);
+                    if (tb.fix) eq_cubic_slow<C>(L, src, sxs[s0 + 1], sys[s0 + 1], px[s0 + 1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) eq_cubic_slow<C>(L, src, sxs[s], sys[s], px[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s)
+            if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+        return;
+    }
     EqTaps<C> taps[kRowsPerWave];
     bool any_fix = false;
 #pragma unroll
@@ -257,7 +363,7 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 // changes sign before the final fma/rint.  Level views (pitch 0) are also symmetric about the horizon:
 // yv(h-1-j) = -yv(j) exactly, latitude flips sign (rint is odd) -> one atan2 serves four pixels, and the
 // longitude term depends on the column only.  All of this is bit-identical to evaluating EQ-SPEC v1 per pixel.
-template <int C>
+template <int C, bool CUBIC>
 __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk)
     int b = blockIdx.x;
@@ -342,111 +448,14 @@ __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     }
 
     // ---- left half, then the mirrored half ---------------------------------------------------------
-    eq_pass<C>(L, src, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false);
+    eq_pass<C, CUBIC>(L, src, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false);
     // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
     // centre column is its own mirror and was already written: drop it from the segment.
     const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
     if (n_px > (centre_dup ? 1 : 0)) {
         const int col0 = V.out_w - x0 - n_px;
         const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
-        eq_pass<C>(L, src, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup);
-    }
-}
-
-// Equirect cubic (EQ-SPEC v1 coordinates, 4x4 Keys taps from OpenCV's fixed-point table): the window columns
-// ix-1..ix+2 wrap around the 360-degree seam, the rows iy-1..iy+2 clamp to [0, H-1].  Straightforward per-pixel
-// evaluation (one lane = one pixel, 4 row slots per wavefront); the bilinear kernel above is the tuned path.
-template <int C>
-__global__ __launch_bounds__(256) void eq_views_cubic_kernel(const EqLaunch L) {
-    int b = blockIdx.x;
-    int t = (b & 7) * L.chunk + (b >> 3);
-    if (t >= L.total_tiles) return;
-    int f = t / L.tiles_per_frame;
-    int r = t - f * L.tiles_per_frame;
-    int k = 0;
-    while (k + 1 < L.n_views && r >= L.view[k + 1].tile_base) ++k;
-    const EqView& V = L.view[k];
-    r -= V.tile_base;
-    const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x0 = tile_x * kTileW;
-    const int n_px = min(kTileW, V.out_w - x0);
-    const int xc = min(x0 + lane, V.out_w - 1);
-    const uint8_t* __restrict__ src = L.src[f];
-    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
-    uint8_t* dst = L.dst[f * L.n_views + k];
-    const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
-    const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
-        if (y >= V.out_h) break;
-        const float yv = (float)(2 * y + 1 - V.out_h) * V.syv;
-        const float bz = __builtin_fmaf(V.sp, yv, V.cp);
-        const float cy = __builtin_fmaf(-V.cp, yv, V.sp);
-        const float h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
-        int Kl, Kt;
-        const float rl = eq_atan2_red(x, bz, Kl);
-        const float rt = eq_atan2_red(cy, h, Kt);
-        const int sx = eq_quant_lon(rl, Kl, L, V);
-        const int sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
-        const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
-        const uint4* wq = reinterpret_cast<const uint4*>(L.cubic_tab + (fy * 32 + fx) * 16);
-        const uint4 wa = wq[0], wb = wq[1];
-        const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-        int acc[4] = {0, 0, 0, 0};
-        bool fast = false;
-        if constexpr (C == 3) fast = (ix >= 1) && (ix + 2 <= L.W - 3);   // no seam wrap, and the 16-byte aligned read stays in-row
-        if (__all(fast)) {
-            // RGB fast path: the 4 taps of a row are 12 contiguous bytes -> one dword-aligned 16-byte read per row
-            const uint32_t col = (uint32_t)(ix - 1) * 3u;
-            uint32_t taps[4][3];
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), L.H - 1), (uint32_t)L.src_stride) + col;
-                const uint8_t* p = src + off;
-                const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
-                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
-                taps[ky][0] = __builtin_amdgcn_alignbyte(d1, d0, o);
-                taps[ky][1] = __builtin_amdgcn_alignbyte(d2, d1, o);
-                taps[ky][2] = __builtin_amdgcn_alignbyte(d3, d2, o);
-            }
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 4; ++kx) {
-                    const uint32_t pk = wpk[(ky * 4 + kx) >> 1];
-                    const int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int bi = kx * 3 + c;
-                        acc[c] += (int)byte_of(taps[ky][bi >> 2], bi & 3) * w;
-                    }
-                }
-        } else {
-            int cols[4];
-#pragma unroll
-            for (int kx = 0; kx < 4; ++kx) {
-                int xx = ix - 1 + kx;
-                cols[kx] = xx < 0 ? xx + L.W : (xx >= L.W ? xx - L.W : xx);
-            }
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const uint8_t* row = src + (int64_t)min(max(iy - 1 + ky, 0), L.H - 1) * L.src_stride;
-#pragma unroll
-                for (int kx = 0; kx < 4; ++kx) {
-                    uint32_t pk = wpk[(ky * 4 + kx) >> 1];
-                    int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
-                    const uint8_t* px = row + (int64_t)cols[kx] * C;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] += (int)px[c] * w;
-                }
-            }
-        }
-        uint32_t px[4];
-#pragma unroll
-        for (int c = 0; c < C; ++c) px[c] = (uint32_t)min(max((acc[c] + (1 << 14)) >> 15, 0), 255);
-        store_row<C>(dst + (int64_t)y * dstride + (int64_t)x0 * C, px, n_px, aligned4);
+        eq_pass<C, CUBIC>(L, src, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup);
     }
 }
 
@@ -763,9 +772,9 @@ __global__ __launch_bounds__(256) void fe_views_kernel(const FeView V, const FeC
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
     dim3 grid((unsigned)(L.chunk * 8)), block(256);
     switch (C) {
-        case 1: hipLaunchKernelGGL(eq_views_kernel<1>, grid, block, 0, s, L); break;
-        case 3: hipLaunchKernelGGL(eq_views_kernel<3>, grid, block, 0, s, L); break;
-        case 4: hipLaunchKernelGGL(eq_views_kernel<4>, grid, block, 0, s, L); break;
+        case 1: hipLaunchKernelGGL((eq_views_kernel<1, false>), grid, block, 0, s, L); break;
+        case 3: hipLaunchKernelGGL((eq_views_kernel<3, false>), grid, block, 0, s, L); break;
+        case 4: hipLaunchKernelGGL((eq_views_kernel<4, false>), grid, block, 0, s, L); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -774,9 +783,9 @@ hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
     dim3 grid((unsigned)(L.chunk * 8)), block(256);
     switch (C) {
-        case 1: hipLaunchKernelGGL(eq_views_cubic_kernel<1>, grid, block, 0, s, L); break;
-        case 3: hipLaunchKernelGGL(eq_views_cubic_kernel<3>, grid, block, 0, s, L); break;
-        case 4: hipLaunchKernelGGL(eq_views_cubic_kernel<4>, grid, block, 0, s, L); break;
+        case 1: hipLaunchKernelGGL((eq_views_kernel<1, true>), grid, block, 0, s, L); break;
+        case 3: hipLaunchKernelGGL((eq_views_kernel<3, true>), grid, block, 0, s, L); break;
+        case 4: hipLaunchKernelGGL((eq_views_kernel<4, true>), grid, block, 0, s, L); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
