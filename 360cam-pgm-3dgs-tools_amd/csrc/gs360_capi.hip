@@ -346,8 +346,22 @@ int gs360_event_elapsed_ms(gs360_ctx* c, int slot, int from, int to, float* ms) 
 int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_frames, int W, int H, int C,
                             size_t src_stride, const gs360_view* views, int n_views, void* const* dst,
                             size_t dst_stride, int interp, uint32_t flags, int slot) {
+    return gs360_equirect_views_masked_u8(c, src_frames, nullptr, n_frames, W, H, C, src_stride, 0, views, n_views, dst,
+                                          dst_stride, interp, flags, slot);
+}
+
+int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, const void* const* mask_frames, int n_frames,
+                                   int W, int H, int C, size_t src_stride, size_t mask_stride, const gs360_view* views,
+                                   int n_views, void* const* dst, size_t dst_stride, int interp, uint32_t flags, int slot) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
     if (!src_frames || !views || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (mask_frames) {
+        if (mask_stride == 0) mask_stride = (size_t)W;
+        if (mask_stride < (size_t)W) return fail(GS360_ERR_ARG, "mask_stride smaller than a row");
+        if ((uint64_t)mask_stride * (uint64_t)H >= ((uint64_t)1 << 32)) return fail(GS360_ERR_UNSUPPORTED, "mask too large");
+        for (int f = 0; f < n_frames; ++f)
+            if (!mask_frames[f]) return fail(GS360_ERR_ARG, "mask_frames[%d] is NULL", f);
+    }
     if (n_frames < 0 || n_views < 0) return fail(GS360_ERR_ARG, "negative count");
     if (n_frames == 0 || n_views == 0) return GS360_OK;  // empty batch is a no-op
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
@@ -388,6 +402,7 @@ int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_f
             }
             for (int f = 0; f < nf; ++f) {
                 L.src[f] = (const uint8_t*)src_frames[f0 + f];
+                L.mask[f] = mask_frames ? (const uint8_t*)mask_frames[f0 + f] : nullptr;
                 for (int k = 0; k < nv; ++k) L.dst[f * nv + k] = (uint8_t*)dst[(size_t)(f0 + f) * n_views + v0 + k];
             }
             L.kx32 = (float)(32.0 * (double)W / (2.0 * kPi));
@@ -399,6 +414,7 @@ int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_f
             L.total_tiles = base * nf;
             L.chunk = (L.total_tiles + 7) / 8;
             L.src_stride = (int64_t)src_stride;
+            L.mask_stride = (int64_t)mask_stride;
             L.dst_stride = (int64_t)dst_stride;
             L.cubic_tab = c->d_cubic;
             if (interp == GS360_INTERP_CUBIC) {   // same tiling and symmetry reuse, 4x4 taps

@@ -31,6 +31,7 @@ struct EqView {
 
 struct EqLaunch {
     const uint8_t* src[GS360_MAX_FRAMES];
+    const uint8_t* mask[GS360_MAX_FRAMES];   // optional keep-masks (H x W u8), all null when unused
     uint8_t* dst[GS360_MAX_FRAMES * GS360_MAX_VIEWS];
     EqView view[GS360_MAX_VIEWS];
     float kx32, ky32;    // 32*W/(2*pi), 32*H/pi
@@ -40,6 +41,7 @@ struct EqLaunch {
     int32_t tiles_per_frame, total_tiles, chunk;  // chunk = ceil(total_tiles / 8) (XCD swizzle)
     const int16_t* cubic_tab;   // 32*32*16 int16 (device) when interp == cubic
     int64_t src_stride;
+    int64_t mask_stride;
     int64_t dst_stride;  // 0 = tight (out_w * C)
 };
 

@@ -305,8 +305,17 @@ __device__ __forceinline__ void eq_cubic_slow(const EqLaunch& L, const uint8_t* 
 // One pass over the wavefront's 4 row slots for one column per lane: all gathers first, then blend, repair, store.
 //   reversed = false: lane l is pixel l of the row segment starting at `col0`
 //   reversed = true : lane l is pixel n_px-1-l (the mirrored half of the view)
+// keep-mask sample of one pixel: nearest texel of the EQ-SPEC coordinate, wrap in x, clamp in y
+__device__ __forceinline__ uint32_t eq_mask_at(const EqLaunch& L, const uint8_t* __restrict__ mask, int sx, int sy) {
+    int xn = (sx + 16) >> 5;
+    if (xn >= L.W) xn -= L.W;
+    const int yn = min(max((sy + 16) >> 5, 0), L.H - 1);
+    return mask[(uint32_t)yn * (uint32_t)L.mask_stride + (uint32_t)xn];
+}
+
 template <int C, bool CUBIC>
-__device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __restrict__ src, uint8_t* dst, int64_t dstride,
+__device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __restrict__ src, const uint8_t* __restrict__ mask,
+                                        uint8_t* dst, int64_t dstride,
                                         const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
                                         const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
                                         int col0, int n_px, bool reversed, bool aligned4, bool skip_first) {
@@ -329,12 +338,24 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s) eq_cubic_slow<C>(L, src, sxs[s], sys[s], px[s]);
         }
+        if (mask) {                                       // wave-uniform
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s)
+                if (eq_mask_at(L, mask, sxs[s], sys[s]) < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
+        }
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s)
             if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
         return;
     }
     EqTaps<C> taps[kRowsPerWave];
+    uint32_t keep[kRowsPerWave];
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) keep[s] = 255u;
+    if (mask) {                                           // wave-uniform: mask reads join the tap reads in flight
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) keep[s] = eq_mask_at(L, mask, sxs[s], sys[s]);
+    }
     bool any_fix = false;
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s) {
@@ -348,6 +369,11 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s)
             if (taps[s].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
+    }
+    if (mask) {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s)
+            if (keep[s] < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
     }
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s)
@@ -384,6 +410,7 @@ __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     const int xl = min(x0 + lane, half_w - 1);            // lanes past the edge recompute the last column (they stay
                                                           // active for the store shuffles)
     const uint8_t* __restrict__ src = L.src[f];
+    const uint8_t* __restrict__ mask = L.mask[f];
     const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
     uint8_t* dst = L.dst[f * L.n_views + k];
     const bool base_aligned = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
@@ -448,14 +475,14 @@ __global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
     }
 
     // ---- left half, then the mirrored half ---------------------------------------------------------
-    eq_pass<C, CUBIC>(L, src, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false);
+    eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false);
     // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
     // centre column is its own mirror and was already written: drop it from the segment.
     const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
     if (n_px > (centre_dup ? 1 : 0)) {
         const int col0 = V.out_w - x0 - n_px;
         const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
-        eq_pass<C, CUBIC>(L, src, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup);
+        eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup);
     }
 }
 

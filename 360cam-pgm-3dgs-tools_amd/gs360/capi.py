@@ -23,7 +23,8 @@ EXPORTS = (
     "gs360_abi_version", "gs360_device_count", "gs360_last_error", "gs360_ctx_create", "gs360_ctx_destroy",
     "gs360_device_info", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
     "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_sync", "gs360_event_record",
-    "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_remap_table_u8", "gs360_fisheye_views_u8",
+    "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_equirect_views_masked_u8", "gs360_remap_table_u8",
+    "gs360_fisheye_views_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
 )
 
@@ -89,6 +90,7 @@ def load_library(path=None):
         L.gs360_event_record.argtypes = [vp, i, i]
         L.gs360_event_elapsed_ms.argtypes = [vp, i, i, i, C.POINTER(C.c_float)]
         L.gs360_equirect_views_u8.argtypes = [vp, pvp, i, i, i, i, sz, C.POINTER(View), i, pvp, sz, i, u32, i]
+        L.gs360_equirect_views_masked_u8.argtypes = [vp, pvp, pvp, i, i, i, i, sz, sz, C.POINTER(View), i, pvp, sz, i, u32, i]
         L.gs360_remap_table_u8.argtypes = [vp, vp, i, i, i, sz, vp, vp, vp, i, i, i, C.POINTER(C.c_double), i, vp, sz, i]
         L.gs360_fisheye_views_u8.argtypes = [vp, pvp, C.POINTER(Calib), i, sz, C.POINTER(View), i, C.c_double, i, i, i,
                                              pvp, sz, pvp, i]
@@ -241,12 +243,20 @@ class Context:
 
     # -- hot path, device-resident ----------------------------------------------------------
     def equirect_views_dev(self, frames, W, H, Cn, views, dsts, slot=0, src_stride=0, dst_stride=0,
-                           interp=INTERP_LINEAR):
-        """frames: list of DeviceBuffer (H x W x C); dsts: list (len frames*views) of DeviceBuffer."""
+                           interp=INTERP_LINEAR, masks=None):
+        """frames: list of DeviceBuffer (H x W x C); dsts: list (len frames*views) of DeviceBuffer;
+        masks: optional list of DeviceBuffer (H x W u8 keep-masks, one per frame) fused into the output."""
         nf, nv = len(frames), len(views)
         fp = (C.c_void_p * max(nf, 1))(*[b.ptr for b in frames])
         dp = (C.c_void_p * max(nf * nv, 1))(*[b.ptr for b in dsts])
         va = (View * max(nv, 1))(*views)
+        if masks is not None:
+            if len(masks) != nf:
+                raise ValueError("one mask per frame")
+            mp = (C.c_void_p * max(nf, 1))(*[b.ptr for b in masks])
+            _check(self.L.gs360_equirect_views_masked_u8(self.handle, fp, mp, nf, W, H, Cn, src_stride, 0, va, nv, dp,
+                                                         dst_stride, interp, 0, slot), self.L)
+            return
         _check(self.L.gs360_equirect_views_u8(self.handle, fp, nf, W, H, Cn, src_stride, va, nv, dp, dst_stride,
                                               interp, 0, slot), self.L)
 

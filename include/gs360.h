@@ -114,6 +114,19 @@ int gs360_equirect_views_u8(gs360_ctx *ctx, const void *const *src_frames, int n
                             int interp, uint32_t flags, int slot);
 
 /*
+ * Same, with a per-frame keep-mask fused into the store (BASELINE config 5; no reference counterpart): mask_frames[f]
+ * is an H x W single-channel uint8 image in the SegmentationMaskTool convention (0 = masked target, 255 = keep,
+ * reference cli_tools/gs360_SegmentationMaskTool.py:765-774).  The mask is sampled NEAREST at the same source
+ * coordinate (texel ((sx+16)>>5 mod W, clamp((sy+16)>>5)) of EQ-SPEC v1) and the output pixel is written as 0 on all
+ * channels where the mask value is < 128.  mask_stride in bytes (0 = W).
+ */
+int gs360_equirect_views_masked_u8(gs360_ctx *ctx, const void *const *src_frames, const void *const *mask_frames,
+                                   int n_frames, int W, int H, int C, size_t src_stride, size_t mask_stride,
+                                   const gs360_view *views, int n_views,
+                                   void *const *dst, size_t dst_stride,
+                                   int interp, uint32_t flags, int slot);
+
+/*
  * cv2.remap with float32 maps, BORDER_CONSTANT; then, if valid != NULL, dst[~valid] = fill_value
  * on all channels.  src: H x W x C; map_x/map_y/valid: h x w (tight); dst: h x w x C.
  * border_value: 4 doubles (cv::Scalar; Python's borderValue=float(v) is {v,0,0,0}).

@@ -523,10 +523,24 @@ ORC_API int orc_equirect_views_u8(const uint8_t *src, int W, int H, int C, long 
     return orc_equirect_views_u8_interp(src, W, H, C, src_stride, views, n_views, dst, dst_stride, 1, n_threads);
 }
 
+ORC_API int orc_equirect_views_masked_u8(const uint8_t *src, const uint8_t *mask, int W, int H, int C, long src_stride,
+                                         long mask_stride, const orc_view *views, int n_views,
+                                         uint8_t *const *dst, long dst_stride, int interp, int n_threads);
+
 ORC_API int orc_equirect_views_u8_interp(const uint8_t *src, int W, int H, int C, long src_stride,
                                          const orc_view *views, int n_views,
                                          uint8_t *const *dst, long dst_stride, int interp, int n_threads) {
+    return orc_equirect_views_masked_u8(src, NULL, W, H, C, src_stride, 0, views, n_views, dst, dst_stride, interp, n_threads);
+}
+
+/* mask != NULL: keep-mask fused into the output (BASELINE config 5, build-defined; mask convention of the reference's
+ * SegmentationMaskTool, SEG:765-774: 0 = masked, 255 = keep): nearest texel of the same quantised coordinate,
+ * out = 0 where mask < 128. */
+ORC_API int orc_equirect_views_masked_u8(const uint8_t *src, const uint8_t *mask, int W, int H, int C, long src_stride,
+                                         long mask_stride, const orc_view *views, int n_views,
+                                         uint8_t *const *dst, long dst_stride, int interp, int n_threads) {
     if (interp != 1 && interp != 2) return -3;
+    if (mask && mask_stride == 0) mask_stride = W;
     if (interp == 2) cubic_init();
     if (!src || !views || !dst || C < 1 || C > 4 || W < 2 || H < 2 || n_views < 0) return -1;
     if (n_views == 0) return 0;
@@ -555,6 +569,13 @@ ORC_API int orc_equirect_views_u8_interp(const uint8_t *src, int W, int H, int C
             eq_coord(c, i, j, &sx, &sy);
             if (interp == 2) eq_sample_px_cubic(c, src, src_stride, C, sx, sy, out + (size_t)i * C);
             else eq_sample_px(c, src, src_stride, C, sx, sy, out + (size_t)i * C);
+            if (mask) {
+                int xn = (sx + 16) >> 5, yn = (sy + 16) >> 5;
+                if (xn >= W) xn -= W;
+                yn = yn < 0 ? 0 : (yn > H - 1 ? H - 1 : yn);
+                if (mask[(size_t)yn * mask_stride + xn] < 128)
+                    for (int ch = 0; ch < C; ++ch) out[(size_t)i * C + ch] = 0;
+            }
         }
     }
     free(cs); free(row0);

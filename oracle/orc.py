@@ -52,6 +52,8 @@ def lib():
         L.orc_equirect_views_u8_interp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(OrcView),
                                                    C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
         L.orc_cubic_table.argtypes = [C.c_void_p]
+        L.orc_equirect_views_masked_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
+                                                   C.POINTER(OrcView), C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
         L.orc_equirect_distinct_texels.argtypes = [C.POINTER(OrcView), C.c_int, C.c_int, C.c_void_p]
         L.orc_equirect_distinct_texels.restype = C.c_long
         L.orc_table_distinct_texels.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int]
@@ -146,14 +148,20 @@ def cubic_table():
     return t.reshape(32, 32, 4, 4)
 
 
-def equirect_views_u8(src, views, threads=1, interp=1):
+def equirect_views_u8(src, views, threads=1, interp=1, mask=None):
     src = np.ascontiguousarray(src, dtype=np.uint8)
     H, W, Cn = src.shape
     arr = (OrcView * len(views))(*views)
     outs = [np.empty((v.height, v.width, Cn), np.uint8) for v in views]
     ptrs = (C.c_void_p * len(views))(*[o.ctypes.data for o in outs])
-    rc = lib().orc_equirect_views_u8_interp(_ptr(src), W, H, Cn, src.strides[0], arr, len(views), ptrs, 0, int(interp),
-                                            int(threads))
+    if mask is not None:
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape == (H, W)
+        rc = lib().orc_equirect_views_masked_u8(_ptr(src), _ptr(m), W, H, Cn, src.strides[0], m.strides[0], arr, len(views),
+                                                ptrs, 0, int(interp), int(threads))
+    else:
+        rc = lib().orc_equirect_views_u8_interp(_ptr(src), W, H, Cn, src.strides[0], arr, len(views), ptrs, 0, int(interp),
+                                                int(threads))
     if rc != 0:
         raise RuntimeError(f"orc_equirect_views_u8 rc={rc}")
     return outs

@@ -44,21 +44,36 @@ def time_steps(ctx, call, steps, warmup=5):
     return ctx.event_elapsed_ms(0, 0, 1) / steps
 
 
-def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR):
+def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR, with_mask=False):
     frames = [synth(H, W, k) for k in range(n_frames)]
     d_fr = [ctx.to_device(f) for f in frames]
     views = [gs360.View.make(*s) for s in specs]
     d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(n_frames) for s in specs]
-    fp_call = ctx.make_equirect_call(d_fr, W, H, 3, views, d_out, slot=0, interp=interp)
+    masks = d_masks = None
+    if with_mask:   # disks of value 0 on a 255 background, seed-fixed
+        rng = np.random.default_rng(20260424)
+        yy, xx = np.ogrid[:H, :W]
+        m = np.full((H, W), 255, np.uint8)
+        for _ in range(40):
+            cy, cx, r = int(rng.integers(0, H)), int(rng.integers(0, W)), int(rng.integers(40, 400))
+            m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 0
+        masks = [np.ascontiguousarray(np.roll(m, 97 * k, axis=1)) for k in range(n_frames)]
+        d_masks = [ctx.to_device(mm) for mm in masks]
+
+        def fp_call():
+            ctx.equirect_views_dev(d_fr, W, H, 3, views, d_out, slot=0, interp=interp, masks=d_masks)
+    else:
+        fp_call = ctx.make_equirect_call(d_fr, W, H, 3, views, d_out, slot=0, interp=interp)
     ms = time_steps(ctx, fp_call, steps)
     # parity of one view of frame 0, algorithmic bytes from the oracle
     k = len(specs) // 2
     got = ctx.download(d_out[k], (specs[k][5], specs[k][4], 3))
-    want = orc.equirect_views_u8(frames[0], [orc.make_view(*specs[k])], threads=0, interp=2 if interp == 2 else 1)[0]
+    want = orc.equirect_views_u8(frames[0], [orc.make_view(*specs[k])], threads=0, interp=2 if interp == 2 else 1,
+                                 mask=masks[0] if masks else None)[0]
     uv = sum(orc.equirect_distinct_texels(orc.make_view(*s), W, H) for s in specs)
     out_px = sum(s[4] * s[5] for s in specs)
     algo = (out_px * 3 + uv * 3) * n_frames
-    for b in d_fr + d_out:
+    for b in d_fr + d_out + (d_masks or []):
         ctx.free(b)
     return {"config": name, "frames_per_launch": n_frames, "views": len(specs), "out_MPix_per_frame": round(out_px / 1e6, 2),
             "ms_per_launch": round(ms, 4), "us_per_frame": round(ms / n_frames * 1e3, 1),
@@ -133,6 +148,8 @@ def main():
                              [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps))
     rows.append(equirect_cfg(ctx, "cfg5 7680x3840 -> fisheyelike 10x2048^2 (u8, no fp16/mask fusion)", 7680, 3840,
                              [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps))
+    rows.append(equirect_cfg(ctx, "cfg5 + fused keep-mask multiply (u8 mask, nearest, threshold 128)", 7680, 3840,
+                             [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps, with_mask=True))
     rows += fisheye_cfg(ctx, args.steps)
     for r in rows:
         print(json.dumps(r))

@@ -83,6 +83,37 @@ def test_equirect_mirror_symmetry_edge_shapes(ctx, orc):
         _assert_same(got, want, f"mirror edge shapes C={channels}")
 
 
+@pytest.mark.parametrize("interp", [1, 2])
+def test_equirect_fused_keep_mask(ctx, orc, interp):
+    """BASELINE config 5's fused mask multiply (SegmentationMaskTool convention: 0 = masked, 255 = keep)"""
+    H, W = 240, 480
+    frames = [rand_image(H, W, seed=500 + f) for f in range(2)]
+    rng = np.random.default_rng(501)
+    masks = []
+    for f in range(2):
+        m = np.full((H, W), 255, np.uint8)
+        for _ in range(12):                                   # disks of zeros, seed-fixed
+            cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(8, 40)
+            yy, xx = np.ogrid[:H, :W]
+            m[(yy - cy) ** 2 + (np.minimum(abs(xx - cx), W - abs(xx - cx))) ** 2 <= r * r] = 0
+        m[rng.integers(0, H, 50), rng.integers(0, W, 50)] = rng.integers(100, 160, 50).astype(np.uint8)   # around the threshold
+        masks.append(m)
+    specs = [(0, 0, 110, 110, 130, 70), (180, 0, 100, 100, 65, 65), (-75.5, 33, 90, 120, 67, 129), (0, 90, 120, 120, 64, 64)]
+    views = [gs360.View.make(*s) for s in specs]
+    dfr = [ctx.to_device(f) for f in frames]
+    dms = [ctx.to_device(m) for m in masks]
+    dsts = [ctx.alloc(s[4] * s[5] * 3) for _ in frames for s in specs]
+    ctx.equirect_views_dev(dfr, W, H, 3, views, dsts, interp=interp, masks=dms)
+    ctx.sync(0)
+    for f in range(2):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], interp=interp, mask=masks[f])
+        got = [ctx.download(dsts[f * len(specs) + k], (s[5], s[4], 3)) for k, s in enumerate(specs)]
+        _assert_same(got, want, f"masked frame {f} interp={interp}")
+        assert any((g == 0).all(axis=2).mean() > 0.02 for g in got)      # the mask really removed pixels
+    for b in dfr + dms + dsts:
+        ctx.free(b)
+
+
 def test_equirect_batched_frames_device_api(ctx, orc):
     """n_frames x n_views in ONE launch through the device-pointer entry point."""
     H, W = 300, 600
