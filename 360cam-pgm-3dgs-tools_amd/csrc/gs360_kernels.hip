@@ -389,8 +389,11 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 // changes sign before the final fma/rint.  Level views (pitch 0) are also symmetric about the horizon:
 // yv(h-1-j) = -yv(j) exactly, latitude flips sign (rint is odd) -> one atan2 serves four pixels, and the
 // longitude term depends on the column only.  All of this is bit-identical to evaluating EQ-SPEC v1 per pixel.
+// Occupancy is capped at 4 wavefronts per SIMD (4 workgroups per CU): measured optimum for the 8K workload -- with
+// more resident wavefronts their gathers evict each other's lines from the 32 KiB vector L1 (6 blocks/CU: 24.3 us per
+// frame, 4: 23.1, 3: 27.4, 1: 45.5).
 template <int C, bool CUBIC>
-__global__ __launch_bounds__(256) void eq_views_kernel(const EqLaunch L) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void eq_views_kernel(const EqLaunch L) {
     // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk)
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
