@@ -38,6 +38,7 @@ class PairRenderer:
             for vid, t in tables.items():
                 self.dev_tables[vid] = (ctx.to_device(t["map_x"]), ctx.to_device(t["map_y"]),
                                         ctx.to_device(np.ascontiguousarray(t["valid"], np.uint8)))
+        self._scratch = None                # grow-only output buffer shared by the per-view launches of a pair
         self.dev_undistort = {}
         for sid, u in (undistort or {}).items():
             self.dev_undistort[sid] = (ctx.to_device(u.map_x), ctx.to_device(u.map_y),
@@ -47,14 +48,15 @@ class PairRenderer:
     def _remap(self, d_src, shape, maps, out_hw, interp, border, valid_fill):
         H, W, C = shape
         h, w = out_hw
-        d_dst = self.ctx.alloc(h * w * C)
-        try:
-            self.ctx.remap_table_dev(d_src, H, W, C, maps[0], maps[1], maps[2] if valid_fill is not None else None, h, w,
-                                     d_dst, interp=interp, border_value=border,
-                                     fill_value=valid_fill if valid_fill is not None else 0, slot=0)
-            return self.ctx.download(d_dst, (h, w, C), slot=0)
-        finally:
-            self.ctx.free(d_dst)
+        need = h * w * C
+        if self._scratch is None or self._scratch.nbytes < need:
+            if self._scratch is not None:
+                self.ctx.free(self._scratch)
+            self._scratch = self.ctx.alloc(need)
+        self.ctx.remap_table_dev(d_src, H, W, C, maps[0], maps[1], maps[2] if valid_fill is not None else None, h, w,
+                                 self._scratch, interp=interp, border_value=border,
+                                 fill_value=valid_fill if valid_fill is not None else 0, slot=0)
+        return self.ctx.download(self._scratch, (h, w, C), slot=0)
 
     def render_pair(self, image_x: np.ndarray, image_y: np.ndarray, sensor_id_x: str, sensor_id_y: str, *,
                     interpolation: int, mask_outside_model: bool, mask_value: int,

@@ -29,6 +29,15 @@ class _DeviceState:
         self.lock = threading.Lock()              # guards the LRU bookkeeping
         self.key_locks = {}                       # key -> lock: one decode+upload per frame
         self.slot_cycle = itertools.cycle(range(_SLOTS_PER_DEVICE))
+        self.out_bufs = [None] * _SLOTS_PER_DEVICE   # grow-only per-slot output buffers (no hipMalloc/hipFree per job)
+
+    def out_buffer(self, slot, nbytes):
+        buf = self.out_bufs[slot]
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                self.ctx.free(buf)
+            buf = self.out_bufs[slot] = self.ctx.alloc(max(nbytes, 1 << 20))
+        return buf
 
 
 class Engine:
@@ -130,12 +139,9 @@ class Engine:
                 slot = next(st.slot_cycle)
             out_bytes = view.height * view.width * C
             with st.ctx.slot_locks[slot]:
-                dst = st.ctx.alloc(out_bytes)
-                try:
-                    st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp)
-                    out = st.ctx.download(dst, (view.height, view.width, C), slot=slot)
-                finally:
-                    st.ctx.free(dst)
+                dst = st.out_buffer(slot, out_bytes)
+                st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp)
+                out = st.ctx.download(dst, (view.height, view.width, C), slot=slot)
         finally:
             self.release_frame(st, entry)
         imageio.write_image(job.dst, out, jpeg_q=job.jpeg_q)
