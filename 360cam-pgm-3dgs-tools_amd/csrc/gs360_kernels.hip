@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
             uint32_t pa = __shfl(packed, la & 63), pb = __shfl(packed, lb & 63);
             uint32_t dw = (pa >> (8 * s)) | (pb << (24 - 8 * s));
             int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
-            if (lane < full) reinterpret_cast<uint32_t*>(row)[lane] = dw;
+            if (lane < full) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
             if (lane == full && rem)
                 for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
             return;
