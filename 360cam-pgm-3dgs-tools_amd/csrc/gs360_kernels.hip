@@ -1,19 +1,22 @@
 // gs360_kernels.hip -- hand-written gfx950 kernels for the 360PerspCut reprojection hot path.
 //
-//   eq_views_kernel      equirect -> rectilinear views, analytic in-kernel map (EQ-SPEC v1), replaces the
-//                        per-view ffmpeg v360 processes of cli_tools/gs360_360PerspCut.py:310-314.
-//   table_remap_kernel   cv2.remap(INTER_LINEAR|INTER_NEAREST, BORDER_CONSTANT) + valid fill, replaces
-//                        cli_tools/gs360_DualFisheyeDistortionCalibration.py:2001-2014 / :2031-2043.
+//   eq_views_kernel      equirect -> rectilinear views, analytic in-kernel map (EQ-SPEC v1), bilinear or cubic, optional
+//                        fused keep-mask; replaces the per-view ffmpeg v360 processes of
+//                        cli_tools/gs360_360PerspCut.py:310-314.
+//   table_remap_kernel   cv2.remap(INTER_NEAREST|LINEAR|CUBIC, BORDER_CONSTANT) + valid fill, replaces
+//                        cli_tools/gs360_DualFisheyeDistortionCalibration.py:2001-2014 / :2031-2043 / :1198-1212.
 //   fe_views_kernel      fused dual-fisheye -> perspective (FE-SPEC v1), DF:1759-1823 evaluated in-kernel.
 //
-// All three are HBM/L2-bound byte gathers (no contraction -> no MFMA).  Work decomposition: one 64x16
-// output tile per 256-thread workgroup; a wavefront owns 4 rows of the tile and its 64 lanes are 64
-// CONSECUTIVE pixels of one output row, so one gather instruction walks a short arc of one or two
-// source rows (few cache lines per instruction -- the texture-address path processes lines, not bytes).
+// All three are memory-system-bound byte gathers (no contraction -> no MFMA).  Work decomposition: one 64-column x
+// 16-row output tile per 256-thread workgroup; a wavefront owns 4 row slots of the tile and its 64 lanes are 64
+// CONSECUTIVE pixels of one output row.  A wavefront first computes the source coordinates of all its pixels, then
+// issues ALL tap reads with no control flow in between (dword-aligned 12-byte reads + v_alignbyte: the texture-address
+// path merges aligned lane accesses into line requests, misaligned ones are looked up lane by lane), then blends.
 // Each lane packs its RGB result into a dword and the row is written as whole dwords after a two-shuffle
 // (ds_bpermute) repack, i.e. 192 contiguous bytes per wavefront row.  Tiles are numbered row-major per
 // view and handed to XCDs in contiguous chunks (block b runs on XCD b % 8) so that neighbouring tiles --
-// which share source cache lines -- hit the same per-XCD L2.
+// which share source cache lines -- hit the same per-XCD L2.  DESIGN.md section 5 has the measurements behind
+// each of these choices.
 //
 // Compile with -ffp-contract=off: the float32 specs are defined operation by operation and must match the
 // CPU oracle bit for bit; only explicit __builtin_fmaf may fuse.
@@ -28,14 +31,9 @@ namespace gs360 {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);  // unaligned dword load (gfx950 runs in unaligned access mode)
-    return v;
-}
 __device__ __forceinline__ uint2 ld_u64(const uint8_t* p) {
     uint2 v;
-    __builtin_memcpy(&v, p, 8);
+    __builtin_memcpy(&v, p, 8);  // unaligned 8-byte load (gfx950 runs in unaligned access mode)
     return v;
 }
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }

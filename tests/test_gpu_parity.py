@@ -325,3 +325,29 @@ def test_full_size_cfg4_table_remap_template_sensor(ctx, orc):
         got = ctx.remap(src, mx, my, interpolation=interp, border_value=0.0, valid=valid, fill_value=0)
         want = orc.valid_fill(orc.remap_u8(src, mx, my, interp=interp, border_value=0.0, threads=0), valid, 0)
         _assert_same([got], [want], f"cfg4 full size interp={interp}")
+
+
+def test_api_limits_are_reported_not_crashed(ctx):
+    """maximum sizes / unsupported shapes come back as Gs360Error with a message (the boundary never aborts)"""
+    tiny = rand_image(4, 4)
+    with pytest.raises(gs360.Gs360Error) as e:
+        ctx.equirect_views(tiny, [gs360.View.make(0, 0, 90, 90, 4, 4)])         # narrower than 8 texels
+    assert e.value.code == -1
+    src = rand_image(8, 16)
+    with pytest.raises(gs360.Gs360Error):
+        ctx.equirect_views(src, [gs360.View.make(0, 0, 90, 90, 40000, 2)])       # view wider than 32768
+    big_w = np.zeros((1, 32767, 1), np.uint8)                                      # cv2.remap's own SHRT_MAX limit
+    m = np.zeros((2, 2), np.float32)
+    with pytest.raises(gs360.Gs360Error):
+        ctx.remap(big_w, m, m)
+    with pytest.raises(gs360.Gs360Error):
+        ctx.remap(rand_image(8, 8), m, m, interpolation=4)                        # lanczos4 is not implemented at the ABI
+    with pytest.raises(gs360.Gs360Error):
+        ctx.remap(rand_image(8, 8, c=1)[:, :, 0].reshape(8, 4, 2), m, m)          # 2 channels
+    assert ctx.remap(rand_image(8, 8), np.zeros((0, 5), np.float32), np.zeros((0, 5), np.float32)).shape == (0, 5, 3)
+    # 1x1 source, every interpolation: all taps are border or the single texel
+    one = np.array([[[10, 20, 30]]], np.uint8)
+    mm = np.array([[0.0, 0.5, -0.5, 3.0]], np.float32)
+    for interp in (0, 1, 2):
+        out = ctx.remap(one, mm, np.zeros_like(mm), interpolation=interp, border_value=(1, 2, 3, 4))
+        assert out[0, 0].tolist() == [10, 20, 30] and out[0, 3].tolist() == [1, 2, 3]
