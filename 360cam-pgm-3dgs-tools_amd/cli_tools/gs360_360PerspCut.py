@@ -85,98 +85,94 @@ def detect_input_bit_depth(in_path: pathlib.Path) -> int:
     return 8
 
 
+# Option table: (flags, argparse keywords).  Names, destinations, types and defaults are the reference's CLI surface
+# (PC:432-531) because the GUI builds Namespaces from this parser (gs360_GUI.py:301); the help wording is ours.
+_OPTIONS = (
+    (("-i", "--in"), dict(dest="input_dir", required=True, help="folder of equirectangular stills, or one equirectangular video file")),
+    (("-o", "--out"), dict(dest="out_dir", default=None, help="where the views go (default: <input>/_geometry)")),
+    (("--preset",), dict(choices=list(_planner.PRESET_NAMES), default="default",
+                         help="view layout: default = 8-view ring; fisheyelike = 10 views at 17 mm; full360coverage = 12 views at "
+                              "14 mm with +/-30 deg extras; 2views = front/back at 6 mm, 3600 px; evenMinus30 / evenPlus30 = even "
+                              "slots pitched; fisheyeXY = the X/Y fisheye pair only")),
+    (("--count",), dict(type=int, default=8, help="number of yaw slots around the horizon")),
+    (("--addcam",), dict(default="", help="extra pitched views per slot letter, e.g. 'B', 'B:U', 'D:D20' (comma separated)")),
+    (("--addcam-deg",), dict(type=float, default=30.0, help="pitch magnitude used when U/D carry no number")),
+    (("--add-top",), dict(action="store_true", help="also emit a straight-up view (pitch +90)")),
+    (("--add-bottom",), dict(action="store_true", help="also emit a straight-down view (pitch -90)")),
+    (("--add-topdown",), dict(action="store_true", dest="add_topdown", help=argparse.SUPPRESS)),
+    (("--delcam",), dict(default="", help="drop ring views by letter, e.g. 'B,D'")),
+    (("--setcam",), dict(default="", help="set ('A=30', 'A=U', 'A=D20') or shift ('A:+10') the pitch of a view")),
+    (("--size",), dict(type=int, default=1600, action="flagged", help="edge length of the square views in pixels")),
+    (("--ext",), dict(default="jpg", help="output image type (jpg / png / tif)")),
+    (("--jpeg-quality-95",), dict(action="store_true", help="write JPEGs at ~95 %% quality instead of the maximum")),
+    (("-f", "--fps"), dict(type=float, default=None, help="frames per second to extract when the input is a video")),
+    (("--start",), dict(type=float, default=None, help="video start time in seconds")),
+    (("--end",), dict(type=float, default=None, help="video end time in seconds")),
+    (("--keep-rec709",), dict(action="store_true", help="keep the Rec.709 transfer curve of video inputs (default converts to sRGB)")),
+    (("--hfov",), dict(type=float, default=None, action="flagged", help="horizontal field of view in degrees; wins over --focal-mm")),
+    (("--focal-mm",), dict(type=float, default=12.0, action="flagged", help="focal length in mm on the virtual sensor")),
+    (("--sensor-mm",), dict(default="36 36", help="virtual sensor size in mm, '36 36' or '36x24'")),
+    (("-j", "--jobs"), dict(default="auto", help="concurrent jobs (a number, or 'auto' = half the cores)")),
+    (("--print-cmd",), dict(choices=["once", "none", "all"], default="once", help="how many planned job lines to echo")),
+    (("--ffmpeg",), dict(default="ffmpeg", help="ffmpeg executable used for jobs that stay on the subprocess path")),
+    (("--dry-run",), dict(action="store_true", help="print the plan and exit")),
+    # additive: executor selection (default = GS360_ENGINE or the HIP engine)
+    (("--engine",), dict(choices=["hip", "ffmpeg"], default=None, help="hip = in-process MI355X engine (default), ffmpeg = one subprocess per job")),
+)
+
+
 def create_arg_parser() -> argparse.ArgumentParser:
-    """The reference's argument surface (PC:417-532) plus one additive option, --engine."""
     ap = argparse.ArgumentParser(
-        description=("Batch convert equirectangular images with ffmpeg/v360, "
-                     "including optional virtual camera add/delete/set operations."),
+        description="Cut equirectangular panoramas into preset perspective views on the GPU (drop-in for the ffmpeg/v360 tool).",
         formatter_class=argparse.ArgumentDefaultsHelpFormatter,
-        epilog=("Notes: presets can be overridden with --focal-mm / --size / --sensor-mm. "
-                "Priority: --hfov overrides --focal-mm. "
-                "Use --setcam to specify absolute or relative pitch values per camera."))
-    ap.add_argument("-i", "--in", dest="input_dir", required=True,
-                    help="Input folder (equirectangular images) or a video file containing equirectangular frames")
-    ap.add_argument("-o", "--out", dest="out_dir", default=None,
-                    help="Output folder. Defaults to <input>/_geometry if omitted")
-    ap.add_argument("--preset", choices=list(_planner.PRESET_NAMES), default="default",
-                    help=("default=8-view baseline / "
-                          "fisheyelike=10-view mix (auto focal 17mm, custom deletions/additions) / "
-                          "full360coverage=8-view wide cover (auto focal 14mm, del B,D,F,H add B,D,F,H) / "
-                          "2views=front/back only (6mm focal, 3600px) / "
-                          "evenMinus30=even slots pitch -30deg / "
-                          "evenPlus30=even slots pitch +30deg / "
-                          "fisheyeXY=fisheye X/Y pair only (Equisolid 3600px FOV180)"))
-    ap.add_argument("--count", type=int, default=8, help="Horizontal division count (4=90deg, 8=45deg)")
-    ap.add_argument("--addcam", default="",
-                    help="Add virtual cameras, e.g. 'B' (+/-default pitch), 'B:U', 'D:D20', 'F:U15' (comma separated)")
-    ap.add_argument("--addcam-deg", type=float, default=30.0,
-                    help="Default magnitude in degrees when 'U/D' in --addcam/--setcam omit a value (default 30)")
-    ap.add_argument("--add-top", action="store_true", help="Include cube-map style top view (pitch +90 deg)")
-    ap.add_argument("--add-bottom", action="store_true", help="Include cube-map style bottom view (pitch -90 deg)")
-    ap.add_argument("--add-topdown", action="store_true", dest="add_topdown", help=argparse.SUPPRESS)
-    ap.add_argument("--delcam", default="", help="Remove baseline cameras by letter, e.g. 'B,D'")
-    ap.add_argument("--setcam", default="",
-                    help="Override/adjust baseline pitch. Absolute: 'A=30','A=U','A=D20'. Relative: 'A:+10','B:-5'.")
-    ap.add_argument("--size", type=int, default=1600, action=StoreWithFlag, help="Square output size per view")
-    ap.add_argument("--ext", default="jpg", help="Output extension (jpg=high quality mjpeg)")
-    ap.add_argument("--jpeg-quality-95", action="store_true",
-                    help="When set with --ext jpg, encode outputs at approximately 95% JPEG quality instead of maximum.")
-    ap.add_argument("-f", "--fps", type=float, default=None,
-                    help="Frame extraction rate (fps) when input is a video file")
-    ap.add_argument("--start", type=float, default=None, help="Optional start time in seconds when input is a video file")
-    ap.add_argument("--end", type=float, default=None, help="Optional end time in seconds when input is a video file")
-    ap.add_argument("--keep-rec709", action="store_true",
-                    help="Keep Rec.709 transfer characteristics for video inputs (default: convert to sRGB)")
-    ap.add_argument("--hfov", type=float, default=None, action=StoreWithFlag,
-                    help="Horizontal FOV in degrees (overrides focal length)")
-    ap.add_argument("--focal-mm", type=float, default=12.0, action=StoreWithFlag,
-                    help="Focal length in millimetres when --hfov is not set")
-    ap.add_argument("--sensor-mm", default="36 36", help="Sensor width/height in millimetres, e.g. '36 36' or '36x24'")
-    ap.add_argument("-j", "--jobs", default="auto",
-                    help="Concurrent ffmpeg processes (number or 'auto'=physical cores/2)")
-    ap.add_argument("--print-cmd", choices=["once", "none", "all"], default="once",
-                    help="How many ffmpeg commands to print: once/none/all")
-    ap.add_argument("--ffmpeg", default="ffmpeg", help="Path to the ffmpeg executable")
-    ap.add_argument("--dry-run", action="store_true", help="Print all commands without executing them")
-    # additive: engine selection (default = GS360_ENGINE or the HIP engine)
-    ap.add_argument("--engine", choices=["hip", "ffmpeg"], default=None,
-                    help="Executor for the planned jobs: hip = in-process MI355X engine, ffmpeg = reference subprocess path")
+        epilog="Presets only replace --size / --focal-mm / --hfov values you did not pass yourself.")
+    for flags, kw in _OPTIONS:
+        kw = dict(kw)
+        if kw.get("action") == "flagged":
+            kw["action"] = StoreWithFlag
+        ap.add_argument(*flags, **kw)
     return ap
 
 
-# ---- parallel execution and cancellation (PC:535-590) ------------------------------------------------
-stop_event = threading.Event()
+# ---- cancellation and the subprocess executor (contract: PC:535-590) -----------------------------------------------
+stop_event = threading.Event()      # names below are read by the GUI (gs360_GUI.py:9170, :18811)
 procs_lock = threading.Lock()
 running_procs = set()
-
 sig_hits = 0
-_engine_choice = None  # set by main(); None -> environment / default
+_engine_choice = None               # set by main(); None -> environment / default
 
 
 def on_signal(sig, frame):
+    """First signal: stop handing out work and ask children to terminate; second: kill them."""
     global sig_hits
     sig_hits += 1
-    if not stop_event.is_set():
+    first = not stop_event.is_set()
+    stop_event.set()
+    if first:
         print("\n[INFO] Cancel requested. Stopping new jobs and terminating running processes...", file=sys.stderr)
-        stop_event.set()
     with procs_lock:
-        for p in list(running_procs):
-            try:
-                p.terminate() if sig_hits == 1 else p.kill()
-            except Exception:
-                pass
+        victims = list(running_procs)
+    for proc in victims:
+        try:
+            (proc.terminate if sig_hits == 1 else proc.kill)()
+        except Exception:
+            pass
     if sig_hits >= 2:
         print("[INFO] Force exiting", file=sys.stderr)
 
 
-try:
-    if threading.current_thread() is threading.main_thread():
-        signal.signal(signal.SIGINT, on_signal)
-        signal.signal(signal.SIGTERM, on_signal)
-        if os.name == "nt" and hasattr(signal, "SIGBREAK"):
-            signal.signal(signal.SIGBREAK, on_signal)
-except Exception:
-    pass
+def _install_signal_handlers():
+    if threading.current_thread() is not threading.main_thread():
+        return
+    names = ["SIGINT", "SIGTERM"] + (["SIGBREAK"] if os.name == "nt" else [])
+    for name in names:
+        try:
+            signal.signal(getattr(signal, name), on_signal)
+        except (AttributeError, ValueError, OSError):
+            pass
+
+
+_install_signal_handlers()
 
 
 def parse_jobs(s: str) -> int:
@@ -190,25 +186,26 @@ def _selected_engine() -> str:
 
 
 def _run_subprocess(cmd: List[str]) -> Tuple[int, str]:
-    """The reference's executor: one external process per job, polled so cancellation lands within 0.5 s."""
+    """One external process for the job, polled twice a second so a cancel request reaches it quickly."""
     try:
         proc = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     except OSError as exc:
         return 127, f"{cmd[0]}: {exc}"
     with procs_lock:
         running_procs.add(proc)
+    rc = None
     try:
-        while True:
+        while rc is None:
             try:
                 rc = proc.wait(timeout=0.5)
-                break
             except subprocess.TimeoutExpired:
                 if stop_event.is_set():
                     try:
                         proc.terminate()
                     except Exception:
                         pass
-        return rc, (proc.stderr.read() or b"").decode(errors="ignore")
+        text = (proc.stderr.read() or b"").decode(errors="ignore")
+        return rc, text
     finally:
         with procs_lock:
             running_procs.discard(proc)

@@ -38,67 +38,66 @@ DEFAULT_PERSPECTIVE_METASHAPE_XML_NAME = "perspective_cams.xml"
 INTERPOLATION_MAP = dict(INTERPOLATIONS)
 
 
-def build_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(description=(
-        "Dual-fisheye calibration tool: export perspective views by default, optionally save validation-oriented "
-        "fisheye outputs, and optionally export color-corrected-only images. "
-        "Use gs360_Video2Frames.py beforehand for video frame extraction."))
-    a = p.add_argument
-    a("-i", "--input-dir", required=False,
-      help="Input directory containing fisheye frame pairs (e.g. *_X.jpg, *_Y.jpg). Optional when --metadata-only is used.")
-    a("--metadata-only", action="store_true", help="Export COLMAP text + perspective Metashape XML only.")
-    a("-x", "--camera-xml", default=str(DEFAULT_CAMERA_XML), help="Metashape camera XML path (contains sensor calibration).")
-    a("-o", "--output-dir", default=None, help="Undistorted fisheye output directory (default: <fisheye_dir>_undistorted).")
-    a("--suffixes", default="_X,_Y", help="Comma-separated stem suffix filter (default: _X,_Y).")
-    a("--ext", default="jpg,jpeg,png,tif,tiff", help="Comma-separated extensions to process.")
-    a("--input-lut", default=None, help="Optional input 3D LUT (.cube) applied before undistortion.")
-    a("--lut-output-color-space", metavar="{passthrough,srgb}", default="srgb", help="Color space to save after LUT application.")
-    a("--input-color-profile", choices=("native", "osmo360-dlogm"), default="native", help=argparse.SUPPRESS)
-    a("--dlogm-lut", default=str(DEFAULT_DLOGM_LUT), help=argparse.SUPPRESS)
-    a("--sensor-id-x", default=None, help="Optional sensor_id override for *_X frames.")
-    a("--sensor-id-y", default=None, help="Optional sensor_id override for *_Y frames.")
-    a("--interpolation", choices=tuple(INTERPOLATION_MAP.keys()), default="cubic", help="Resampling interpolation (default: cubic).")
-    a("--undistort-zoom", default="auto", help="Undistort zoom factor: a positive float or 'auto'.")
-    a("--mask-outside-model", dest="mask_outside_model", action="store_true",
-      help="Mask pixels outside the ideal model radius as constant color.")
-    a("--no-mask-outside-model", dest="mask_outside_model", action="store_false",
-      help="Disable model/FOV based masking for undistorted fisheye outputs.")
-    p.set_defaults(mask_outside_model=True)
-    a("--mask-value", type=int, default=0, help="Mask fill value in [0,255] when model/FOV masking is enabled.")
-    a("--limit", type=int, default=0, help=argparse.SUPPRESS)
-    a("--workers", type=int, default=DEFAULT_WORKERS,
-      help="Worker threads for pair processing (default: CPU core count = {}).".format(DEFAULT_WORKERS))
-    a("--memory-throttle-percent", type=float, default=80.0,
-      help="Reduce active worker submission when system memory usage exceeds this percent (default: 80).")
-    a("--dry-run", action="store_true", help="List targets and calibration mapping without writing files.")
-    a("--report-json", default=None, help=argparse.SUPPRESS)
-    a("--no-perspective", action="store_true", help="Disable perspective conversion stage.")
-    a("--save-fisheye-output", action="store_true", help="Save undistorted fisheye images for validation (default: disabled).")
-    a("--save-color-corrected-output", action="store_true",
-      help="Save input images after input color-profile conversion only (default: disabled).")
-    a("--color-corrected-output-dir", default=None, help="Color-corrected-only output dir (default: <fisheye_dir>_colorcorrected).")
-    a("--fisheye-output-dir", default=None, help=argparse.SUPPRESS)
-    a("--no-fisheye-output", action="store_true", help=argparse.SUPPRESS)
-    a("--perspective-output-dir", default=None, help="Perspective / COLMAP root dir (default: <fisheye_dir>_perspective_colmap).")
-    a("--perspective-ext", default="jpg", help="Perspective output extension (default: jpg).")
-    a("--perspective-mask-ext", default="png", help="Perspective mask output extension (default: png).")
-    a("--perspective-size", type=int, default=1750, help="Perspective output size (default: 1750).")
-    a("--perspective-focal-mm", type=float, default=14.0, help="Perspective focal length in mm (default: 14).")
-    a("--perspective-sensor-mm", default="36 36", help="Perspective sensor size string (default: '36 36').")
-    a("--perspective-yaw-delta-deg", type=float, default=40.0, help="Yaw delta in degrees for SFM10 layout (default: 40).")
-    a("--perspective-pitch-delta-deg", type=float, default=40.0, help="Pitch delta in degrees for SFM10 layout (default: 40).")
-    a("--perspective-jpeg-quality", type=int, default=95, help="JPEG quality for perspective outputs.")
-    a("--lens-fov-deg", type=float, default=190.0, help="Usable fisheye FOV per lens in degrees (default: 190).")
-    a("--lens-x-yaw-deg", type=float, default=0.0, help="Rig yaw offset for X lens.")
-    a("--lens-y-yaw-deg", type=float, default=180.0, help="Rig yaw offset for Y lens.")
-    a("--camera-extrinsics-xml", default=None, help="Optional Metashape alignment XML for the input dual-fisheye pairs.")
-    a("--pointcloud-ply", default=None, help="Optional Metashape point cloud PLY used when exporting perspective COLMAP text.")
-    a("--mask-input-dir", default=None, help="Optional mask folder matching the pair images by file name.")
-    a("--perspective-metashape-xml-name", default=DEFAULT_PERSPECTIVE_METASHAPE_XML_NAME,
-      help="Perspective Metashape XML file name written under the perspective output directory.")
+# (flags, keywords): option names / destinations / types / defaults are the reference's command line (DF:124-450) -- the
+# GUI composes exactly these flags (gs360_GUI.py:9971-10147); the help wording is ours.  H = hidden legacy option.
+H = argparse.SUPPRESS
+_OPTIONS = (
+    (("-i", "--input-dir"), dict(required=False, help="folder with the *_X / *_Y fisheye stills (not needed with --metadata-only)")),
+    (("--metadata-only",), dict(action="store_true", help="export camera metadata only (not available in this build)")),
+    (("-x", "--camera-xml"), dict(default=str(DEFAULT_CAMERA_XML), help="Metashape XML holding the lens calibration")),
+    (("-o", "--output-dir"), dict(default=None, help="folder for undistorted fisheye images (default <input>_undistorted)")),
+    (("--suffixes",), dict(default="_X,_Y", help="stem suffixes of the two lenses, comma separated")),
+    (("--ext",), dict(default="jpg,jpeg,png,tif,tiff", help="input extensions to pick up, comma separated")),
+    (("--input-lut",), dict(default=None, help=".cube LUT applied before resampling (not available in this build)")),
+    (("--lut-output-color-space",), dict(metavar="{passthrough,srgb}", default="srgb", help="colour space written after the LUT")),
+    (("--input-color-profile",), dict(choices=("native", "osmo360-dlogm"), default="native", help=H)),
+    (("--dlogm-lut",), dict(default=str(DEFAULT_DLOGM_LUT), help=H)),
+    (("--sensor-id-x",), dict(default=None, help="force this sensor id for the X lens")),
+    (("--sensor-id-y",), dict(default=None, help="force this sensor id for the Y lens")),
+    (("--interpolation",), dict(choices=tuple(INTERPOLATION_MAP.keys()), default="cubic", help="resampling kernel")),
+    (("--undistort-zoom",), dict(default="auto", help="zoom of the undistorted fisheye output: a positive number or 'auto'")),
+    (("--mask-outside-model",), dict(dest="mask_outside_model", action="store_true", help="paint pixels outside the lens model with --mask-value")),
+    (("--no-mask-outside-model",), dict(dest="mask_outside_model", action="store_false", help="leave pixels outside the lens model as sampled")),
+    (("--mask-value",), dict(type=int, default=0, help="grey level 0-255 used for masked pixels and the resampling border")),
+    (("--limit",), dict(type=int, default=0, help=H)),
+    (("--workers",), dict(type=int, default=DEFAULT_WORKERS, help="pairs processed concurrently (default: CPU cores = {})".format(DEFAULT_WORKERS))),
+    (("--memory-throttle-percent",), dict(type=float, default=80.0, help="accepted for compatibility (host-memory throttle threshold)")),
+    (("--dry-run",), dict(action="store_true", help="list what would be written and stop")),
+    (("--report-json",), dict(default=None, help=H)),
+    (("--no-perspective",), dict(action="store_true", help="skip the perspective views")),
+    (("--save-fisheye-output",), dict(action="store_true", help="also write undistorted fisheye images")),
+    (("--save-color-corrected-output",), dict(action="store_true", help="also write the inputs after the colour stage only")),
+    (("--color-corrected-output-dir",), dict(default=None, help="folder for those (default <input>_colorcorrected)")),
+    (("--fisheye-output-dir",), dict(default=None, help=H)),
+    (("--no-fisheye-output",), dict(action="store_true", help=H)),
+    (("--perspective-output-dir",), dict(default=None, help="COLMAP-style root for the views (default <input>_perspective_colmap)")),
+    (("--perspective-ext",), dict(default="jpg", help="file type of the views")),
+    (("--perspective-mask-ext",), dict(default="png", help="file type of the cut masks")),
+    (("--perspective-size",), dict(type=int, default=1750, help="edge length of the square views")),
+    (("--perspective-focal-mm",), dict(type=float, default=14.0, help="focal length of the views in mm")),
+    (("--perspective-sensor-mm",), dict(default="36 36", help="virtual sensor size of the views in mm")),
+    (("--perspective-yaw-delta-deg",), dict(type=float, default=40.0, help="yaw offset of the side views")),
+    (("--perspective-pitch-delta-deg",), dict(type=float, default=40.0, help="pitch offset of the up/down views")),
+    (("--perspective-jpeg-quality",), dict(type=int, default=95, help="JPEG quality of the views")),
+    (("--lens-fov-deg",), dict(type=float, default=190.0, help="usable field of view of each fisheye lens")),
+    (("--lens-x-yaw-deg",), dict(type=float, default=0.0, help="rig yaw of the X lens")),
+    (("--lens-y-yaw-deg",), dict(type=float, default=180.0, help="rig yaw of the Y lens")),
+    (("--camera-extrinsics-xml",), dict(default=None, help="Metashape alignment XML (enables metadata export in the reference tool)")),
+    (("--pointcloud-ply",), dict(default=None, help="Metashape point cloud used by the metadata export")),
+    (("--mask-input-dir",), dict(default=None, help="folder with masks named like the inputs; they are cut with the same maps")),
+    (("--perspective-metashape-xml-name",), dict(default=DEFAULT_PERSPECTIVE_METASHAPE_XML_NAME, help="name of the exported camera XML")),
     # additive
-    a("--map-mode", choices=("table", "fused"), default="table",
-      help="table = reference-identical NumPy remap tables sampled on the GPU; fused = map evaluated in-kernel")
+    (("--map-mode",), dict(choices=("table", "fused"), default="table",
+                           help="table = reference-identical NumPy remap tables sampled on the GPU; fused = map evaluated in-kernel")),
+)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Dual-fisheye pairs -> SFM10 perspective views (and optional undistorted fisheyes) "
+                                            "on the GPU; drop-in for the cv2-based tool.")
+    for flags, kw in _OPTIONS:
+        p.add_argument(*flags, **kw)
+    p.set_defaults(mask_outside_model=True)
     return p
 
 
