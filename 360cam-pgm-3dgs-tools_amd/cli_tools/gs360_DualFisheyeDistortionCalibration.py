@@ -10,9 +10,10 @@ and the same output layout (<dir>_perspective_colmap/Images|Masks, <dir>_undisto
 What changed underneath: the per-pair `cv2.remap` calls (reference :2001-2014, :2031-2043, :1198-1212) run on the
 GPU through libgs360hip.so.  Default `--map-mode table` samples the reference-identical NumPy tables
 (gs360/fisheye.py) with cv2's 8-bit fixed-point arithmetic -> bit-identical to the reference for nearest/linear;
-`--map-mode fused` evaluates the map in-kernel.  Not built here (outside the reprojection hot path):
-the .cube LUT colour stage and the COLMAP / Metashape metadata export -- the flags are accepted, and asking for
-those stages is reported as an error instead of being silently skipped.
+`--map-mode fused` evaluates the map in-kernel.  `--input-lut` (.cube 3D LUT + optional Rec.709 -> sRGB re-encode,
+reference :494-725) also runs on the GPU, on the uploaded lens images before any resampling (8-bit images).
+Not built here (outside the pixel path): the COLMAP / Metashape metadata export -- the flags are
+accepted, and asking for that stage is reported as an error instead of being silently skipped.
 """
 import argparse
 import os
@@ -25,6 +26,7 @@ _HERE = pathlib.Path(__file__).resolve().parent
 if str(_HERE.parent) not in sys.path:
     sys.path.insert(0, str(_HERE.parent))
 
+from gs360 import color  # noqa: E402
 from gs360 import fisheye as fe  # noqa: E402
 from gs360.dualfisheye import INTERPOLATIONS  # noqa: E402
 
@@ -48,7 +50,7 @@ _OPTIONS = (
     (("-o", "--output-dir"), dict(default=None, help="folder for undistorted fisheye images (default <input>_undistorted)")),
     (("--suffixes",), dict(default="_X,_Y", help="stem suffixes of the two lenses, comma separated")),
     (("--ext",), dict(default="jpg,jpeg,png,tif,tiff", help="input extensions to pick up, comma separated")),
-    (("--input-lut",), dict(default=None, help=".cube LUT applied before resampling (not available in this build)")),
+    (("--input-lut",), dict(default=None, help=".cube 3D LUT applied to the lens images on the GPU before resampling (8-bit images)")),
     (("--lut-output-color-space",), dict(metavar="{passthrough,srgb}", default="srgb", help="colour space written after the LUT")),
     (("--input-color-profile",), dict(choices=("native", "osmo360-dlogm"), default="native", help=H)),
     (("--dlogm-lut",), dict(default=str(DEFAULT_DLOGM_LUT), help=H)),
@@ -115,13 +117,8 @@ def parse_undistort_zoom_arg(value: str) -> Optional[float]:
     return zoom
 
 
-def normalize_lut_output_color_space(value: str) -> str:
-    text = str(value or "passthrough").strip().lower()
-    if text == "native":
-        return "passthrough"
-    if text in {"passthrough", "srgb"}:
-        return text
-    raise ValueError("Unsupported --lut-output-color-space: {}".format(value))
+normalize_lut_output_color_space = color.normalize_lut_output_color_space
+load_cube_lut = color.load_cube_lut
 
 
 # ---- pair discovery (reference :831-914) ---------------------------------------------------------------
@@ -222,14 +219,16 @@ def main() -> None:
         input_lut_path = pathlib.Path(args.dlogm_lut).expanduser().resolve()
     elif legacy_profile != "native":
         _die("[ERR] Unsupported --input-color-profile: {}".format(legacy_profile))
+    input_lut = None
     if input_lut_path is not None:
-        _die("[ERR] Failed to load input LUT: the .cube colour stage is not part of the gs360 engine build "
-             "(reprojection hot path only); run without --input-lut")
+        try:
+            input_lut = color.load_cube_lut(input_lut_path)
+        except Exception as exc:
+            _die("[ERR] Failed to load input LUT: {}".format(exc))
     try:
         lut_space = normalize_lut_output_color_space(str(args.lut_output_color_space).strip().lower())
     except Exception as exc:
         _die("[ERR] {}".format(exc))
-    del lut_space
 
     camera_xml_value = str(args.camera_xml or "").strip()
     camera_xml_path = pathlib.Path(camera_xml_value).expanduser().resolve() if camera_xml_value else None
@@ -362,7 +361,11 @@ def main() -> None:
     say("[INFO] mask input dir: {}".format(mask_dir_path) if mask_dir_path else "[INFO] mask input dir: disabled")
     say("[INFO] workers: {} (memory auto-throttle > {}%)".format(workers, "{:.1f}".format(mem_threshold * 100.0)))
     say("[INFO] pair worker mode: enabled")
-    say("[INFO] input LUT: disabled")
+    if input_lut_path is not None:
+        say("[INFO] input LUT: {}".format(input_lut_path))
+        say("[INFO] LUT output color space: {}".format(lut_space))
+    else:
+        say("[INFO] input LUT: disabled")
     if write_fisheye:
         say("[INFO] undistort zoom: auto" if zoom_override is None else "[INFO] undistort zoom: {:.6f}".format(zoom_override))
     else:
@@ -458,6 +461,7 @@ def main() -> None:
         if n_dev <= 0:
             _die("[ERR] no MI355X visible: the gs360 engine has no CPU fallback", 2)
         contexts = [capi.Context(device=d, n_slots=1) for d in range(n_dev)]
+        stage = color.ColorStage(input_lut, lut_space) if input_lut is not None else None
         renderers = {}
         for d, ctx in enumerate(contexts):
             for sp in sorted(used_pairs):
@@ -472,11 +476,13 @@ def main() -> None:
             if base in pair_masks:
                 mx, my = imageio.read_image(pair_masks[base][0]), imageio.read_image(pair_masks[base][1])
             res = r.render_pair(img_x, img_y, sx, sy, interpolation=interpolation, mask_outside_model=bool(args.mask_outside_model),
-                                mask_value=mask_value, mask_x=mx, mask_y=my, want_fisheye=write_fisheye, want_perspective=write_persp)
+                                mask_value=mask_value, mask_x=mx, mask_y=my, want_fisheye=write_fisheye, want_perspective=write_persp,
+                                color_stage=stage, want_color=save_color)
             names = {"color": [], "fisheye": [], "persp": [], "mask": []}
             if save_color:
-                for p, im in ((x_path, img_x), (y_path, img_y)):
-                    _write_image(color_dir / p.name, im, None)
+                for key, p in (("X", x_path), ("Y", y_path)):
+                    _write_image(color_dir / p.name, res["color"][key].reshape(
+                        (img_x if key == "X" else img_y).shape), None)
                     names["color"].append(p.name)
             for key, p in (("X", x_path), ("Y", y_path)):
                 if key in res["fisheye"]:
@@ -531,6 +537,8 @@ def main() -> None:
             while pending:
                 done, pending = wait(pending, return_when=FIRST_COMPLETED)
                 drain(list(done))
+        if stage is not None:
+            stage.close()
         for ctx in contexts:
             ctx.close()
 

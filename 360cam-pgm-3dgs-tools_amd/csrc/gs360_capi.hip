@@ -512,6 +512,89 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
     return GS360_OK;
 }
 
+// ---- input colour stage ------------------------------------------------------------------------
+struct gs360_color_plan {
+    int device = 0;
+    int lut_size = 0;
+    void* d_lut = nullptr;      // float4[size^3]
+    float* d_tables = nullptr;  // float[1024]
+};
+
+int gs360_color_plan_create(gs360_ctx* c, const float* lut, int lut_size, const float* level_pos,
+                            const float* out_thresholds, gs360_color_plan** out) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (!lut || !level_pos || !out_thresholds || !out) return fail(GS360_ERR_ARG, "NULL argument");
+    if (lut_size < 2 || lut_size > 256) return fail(GS360_ERR_ARG, "LUT size %d outside [2,256]", lut_size);
+    const int nmax = lut_size - 1;
+    for (int i = 0; i < 768; ++i)   // positions index the table: refuse anything that would read outside it
+        if (!(level_pos[i] >= 0.0f && level_pos[i] <= (float)nmax))
+            return fail(GS360_ERR_ARG, "level_pos[%d] = %g outside [0,%d]", i, (double)level_pos[i], nmax);
+    for (int k = 2; k < 256; ++k)
+        if (!(out_thresholds[k] >= out_thresholds[k - 1]))
+            return fail(GS360_ERR_ARG, "out_thresholds must be non-decreasing (entry %d)", k);
+    HIP_TRY(hipSetDevice(c->device));
+    gs360_color_plan* p = new (std::nothrow) gs360_color_plan();
+    if (!p) return fail(GS360_ERR_NOMEM, "out of host memory");
+    p->device = c->device;
+    p->lut_size = lut_size;
+    const size_t n3 = (size_t)lut_size * lut_size * lut_size;
+    std::vector<float> packed(n3 * 4);
+    for (size_t i = 0; i < n3; ++i) {
+        packed[4 * i + 0] = lut[3 * i + 0];
+        packed[4 * i + 1] = lut[3 * i + 1];
+        packed[4 * i + 2] = lut[3 * i + 2];
+        packed[4 * i + 3] = 0.0f;
+    }
+    float tables[1024];
+    std::memcpy(tables, level_pos, 768 * sizeof(float));
+    std::memcpy(tables + 768, out_thresholds, 256 * sizeof(float));
+    hipError_t e = hipMalloc(&p->d_lut, packed.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_tables, sizeof(tables));
+    if (e == hipSuccess) e = hipMemcpy(p->d_lut, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->d_lut) (void)hipFree(p->d_lut);
+        if (p->d_tables) (void)hipFree(p->d_tables);
+        delete p;
+        return fail(GS360_ERR_HIP, "colour plan upload failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return GS360_OK;
+}
+
+int gs360_color_plan_destroy(gs360_ctx* c, gs360_color_plan* p) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (!p) return GS360_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (p->d_lut) HIP_TRY(hipFree(p->d_lut));
+    if (p->d_tables) HIP_TRY(hipFree(p->d_tables));
+    delete p;
+    return GS360_OK;
+}
+
+int gs360_color_apply_u8(gs360_ctx* c, const gs360_color_plan* p, const void* src, int H, int W, int C, size_t src_stride,
+                         int red_index, void* dst, size_t dst_stride, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!p || !src || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (p->device != c->device) return fail(GS360_ERR_ARG, "colour plan belongs to device %d, ctx is device %d", p->device, c->device);
+    if (C != 3 && C != 4) return fail(GS360_ERR_ARG, "the LUT stage needs 3 or 4 channels (got %d)", C);   // DF:693-697
+    if (red_index != 0 && red_index != 2) return fail(GS360_ERR_ARG, "red_index must be 0 (RGB) or 2 (BGR)");
+    if (H < 0 || W < 0) return fail(GS360_ERR_ARG, "bad size");
+    if (H == 0 || W == 0) return GS360_OK;
+    if (H > 65535) return fail(GS360_ERR_UNSUPPORTED, "image height %d above 65535", H);
+    if (src_stride == 0) src_stride = (size_t)W * C;
+    if (dst_stride == 0) dst_stride = (size_t)W * C;
+    if (src_stride < (size_t)W * C || dst_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
+    HIP_TRY(hipSetDevice(c->device));
+    ColorLaunch L;
+    L.src = (const uint8_t*)src; L.dst = (uint8_t*)dst; L.lut = p->d_lut; L.tables = p->d_tables;
+    L.H = H; L.W = W; L.lut_size = p->lut_size; L.red_index = red_index;
+    L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
+    HIP_TRY(launch_color(L, C, c->stream[slot]));
+    return GS360_OK;
+}
+
 // ---- host-buffer conveniences ------------------------------------------------------------------
 int gs360_equirect_views_u8_host(gs360_ctx* c, const uint8_t* src, int W, int H, int C, size_t src_stride,
                                  const gs360_view* views, int n_views, uint8_t* const* dst, size_t dst_stride,

@@ -97,6 +97,19 @@ struct FeLaunch {          // host-side batch description; launch_fisheye() issu
     int32_t pipelined;
 };
 
+// ------------------------------------------------------------------------------------------------
+// input colour stage (gs360_color.hip): DF:684-725 for 8-bit images
+// ------------------------------------------------------------------------------------------------
+struct ColorLaunch {
+    const uint8_t* src;
+    uint8_t* dst;
+    const void* lut;        // device float4[size^3], [b][g][r] -> (R,G,B,0)
+    const float* tables;    // device float[1024]: level positions R,G,B x 256, then 256 output thresholds
+    int32_t H, W, lut_size, red_index;
+    int64_t src_stride, dst_stride;
+};
+hipError_t launch_color(const ColorLaunch& L, int C, hipStream_t s);
+
 // kernel launchers (gs360_kernels.hip)
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s);
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);

@@ -25,6 +25,7 @@ EXPORTS = (
     "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_sync", "gs360_event_record",
     "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_equirect_views_masked_u8", "gs360_remap_table_u8",
     "gs360_fisheye_views_u8",
+    "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
 )
 
@@ -94,6 +95,9 @@ def load_library(path=None):
         L.gs360_remap_table_u8.argtypes = [vp, vp, i, i, i, sz, vp, vp, vp, i, i, i, C.POINTER(C.c_double), i, vp, sz, i]
         L.gs360_fisheye_views_u8.argtypes = [vp, pvp, C.POINTER(Calib), i, sz, C.POINTER(View), i, C.c_double, i, i, i,
                                              pvp, sz, pvp, i]
+        L.gs360_color_plan_create.argtypes = [vp, vp, i, vp, vp, pvp]
+        L.gs360_color_plan_destroy.argtypes = [vp, vp]
+        L.gs360_color_apply_u8.argtypes = [vp, vp, vp, i, i, i, sz, i, vp, sz, i]
         L.gs360_equirect_views_u8_host.argtypes = [vp, vp, i, i, i, sz, C.POINTER(View), i, pvp, sz, i, u32, i]
         L.gs360_remap_table_u8_host.argtypes = [vp, vp, i, i, i, sz, vp, vp, vp, i, i, i, C.POINTER(C.c_double), i, vp,
                                                 sz, i]
@@ -292,6 +296,31 @@ class Context:
         va = (View * nv)(*views)
         _check(self.L.gs360_fisheye_views_u8(self.handle, sp, ca, Cn, 0, va, nv, float(lens_fov_deg), interp,
                                              1 if mask_outside else 0, int(mask_value), dp, 0, vo, slot), self.L)
+
+    # -- input colour stage ------------------------------------------------------------------
+    def color_plan(self, lut_table, level_pos, out_thresholds):
+        """lut_table: float32 [n][n][n][3] ([b][g][r], .cube order); level_pos: float32 [3][256]; out_thresholds:
+        float32 [256] (entry 0 unused).  Returns an opaque plan handle (free with color_plan_free)."""
+        lut = np.ascontiguousarray(lut_table, dtype=np.float32)
+        if lut.ndim != 4 or lut.shape[3] != 3 or not (lut.shape[0] == lut.shape[1] == lut.shape[2]):
+            raise ValueError("lut_table must be [n][n][n][3]")
+        pos = np.ascontiguousarray(level_pos, dtype=np.float32)
+        thr = np.ascontiguousarray(out_thresholds, dtype=np.float32)
+        if pos.shape != (3, 256) or thr.shape != (256,):
+            raise ValueError("level_pos must be [3][256] and out_thresholds [256]")
+        h = C.c_void_p()
+        _check(self.L.gs360_color_plan_create(self.handle, lut.ctypes.data, int(lut.shape[0]), pos.ctypes.data,
+                                              thr.ctypes.data, C.byref(h)), self.L)
+        return h
+
+    def color_plan_free(self, plan):
+        if plan:
+            _check(self.L.gs360_color_plan_destroy(self.handle, plan), self.L)
+
+    def color_apply_dev(self, plan, src, H, W, Cn, dst=None, red_index=0, src_stride=0, dst_stride=0, slot=0):
+        """Apply a colour plan to a device-resident H x W x C image (in place when dst is None)."""
+        _check(self.L.gs360_color_apply_u8(self.handle, plan, src.ptr, H, W, Cn, src_stride, red_index,
+                                           (dst or src).ptr, dst_stride, slot), self.L)
 
     # -- hot path, host buffers (synchronous) -----------------------------------------------
     def equirect_views(self, src, views, slot=0, interp=INTERP_LINEAR):

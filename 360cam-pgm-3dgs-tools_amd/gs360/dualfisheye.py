@@ -61,18 +61,32 @@ class PairRenderer:
     def render_pair(self, image_x: np.ndarray, image_y: np.ndarray, sensor_id_x: str, sensor_id_y: str, *,
                     interpolation: int, mask_outside_model: bool, mask_value: int,
                     mask_x: Optional[np.ndarray] = None, mask_y: Optional[np.ndarray] = None,
-                    want_fisheye: bool = False, want_perspective: bool = True):
-        """-> dict(perspective={view_id: img}, masks={view_id: img}, fisheye={'X': img, 'Y': img})"""
+                    want_fisheye: bool = False, want_perspective: bool = True,
+                    color_stage=None, want_color: bool = False):
+        """-> dict(perspective={view_id: img}, masks={view_id: img}, fisheye={'X': img, 'Y': img}, color={'X','Y'})
+
+        `color_stage` (gs360.color.ColorStage) converts both lens images on the device right after the upload, i.e.
+        before every resampling step, as load_prepared_input_image does on the host (DF:728-743); `want_color`
+        returns the converted images (the --save-color-corrected-output files, DF:1953-1959)."""
         interp = engine_interpolation(interpolation)
-        out = {"perspective": {}, "masks": {}, "fisheye": {}}
+        out = {"perspective": {}, "masks": {}, "fisheye": {}, "color": {}}
         with self.lock:
             imgs = {"X": _hwc(image_x), "Y": _hwc(image_y)}
+            if color_stage is not None:
+                for v in imgs.values():
+                    color_stage.check_image(v.shape, v.dtype)
             dev = {k: self.ctx.to_device(v) for k, v in imgs.items()}
             dmask = {}
             for k, m in (("X", mask_x), ("Y", mask_y)):
                 if m is not None:
                     dmask[k] = (self.ctx.to_device(_hwc(m)), _hwc(m).shape)
             try:
+                if color_stage is not None:
+                    for k, v in imgs.items():
+                        color_stage.apply_dev(self.ctx, dev[k], v.shape, red_index=0, slot=0)   # arrays here are RGB(A)
+                if want_color:
+                    for k, v in imgs.items():
+                        out["color"][k] = self.ctx.download(dev[k], v.shape, slot=0) if color_stage is not None else v
                 # borderValue=float(mask_value) -> cv::Scalar(v,0,0,0): only channel 0 gets v, and channel 0 of a
                 # cv2.imread image is BLUE.  Arrays here are RGB(A), so the value goes to index 2 for colour images.
                 C_in = imgs["X"].shape[2]

@@ -150,6 +150,34 @@ int gs360_fisheye_views_u8(gs360_ctx *ctx, const void *const *src_lens, const gs
                            int interp, int mask_outside, int mask_value,
                            void *const *dst, size_t dst_stride, uint8_t *const *valid_out, int slot);
 
+/* ---- input colour stage (dual-fisheye tool, before resampling) -------------------------------- */
+
+/*
+ * The `--input-lut` stage of cli_tools/gs360_DualFisheyeDistortionCalibration.py: apply_input_color_pipeline
+ * (DF:684-725) = image_to_float01 -> apply_cube_lut_trilinear (DF:620-681) -> optional rec709_to_srgb
+ * (DF:565-600) -> float01_to_image, for 8-bit images.  Because the input has 256 levels per channel and the
+ * output 256, the two scalar ends of that pipeline are passed in as tables the caller computes with the reference's
+ * own float32 expressions (the Python host does this with NumPy, gs360/color.py), and the kernel evaluates the
+ * trilinear interpolation between them in the reference's float32 operation order:
+ *   level_pos[c*256 + v]  LUT-grid position `clip((v/255 - domain_min[c]) / span[c], 0, 1) * (size-1)` of input
+ *                         level v on channel c (c = 0,1,2 = R,G,B)
+ *   out_thresholds[k]     k = 1..255: the smallest float32 LUT output x for which the encoded 8-bit result is >= k
+ *                         (entry 0 is ignored; +inf = never reached).  The encode step is monotone, so the output
+ *                         level is the number of thresholds <= x.
+ *   lut                   size^3 RGB float32 triples, red fastest ([b][g][r][3], the .cube order, DF:556-562)
+ * All three are HOST pointers, copied at plan creation.
+ */
+typedef struct gs360_color_plan gs360_color_plan;
+int gs360_color_plan_create(gs360_ctx *ctx, const float *lut, int lut_size, const float *level_pos,
+                            const float *out_thresholds, gs360_color_plan **out);
+int gs360_color_plan_destroy(gs360_ctx *ctx, gs360_color_plan *plan);
+/*
+ * Applies the plan to an H x W x C uint8 image (C = 3 or 4; a 4th channel is copied), device pointers, dst may equal
+ * src.  red_index = 0 for RGB(A) memory order, 2 for BGR(A) (cv2.imread order, DF:697-699).
+ */
+int gs360_color_apply_u8(gs360_ctx *ctx, const gs360_color_plan *plan, const void *src, int H, int W, int C,
+                         size_t src_stride, int red_index, void *dst, size_t dst_stride, int slot);
+
 /* ---- host-buffer conveniences (synchronous: H2D -> kernel -> D2H on `slot`) ----------------- */
 int gs360_equirect_views_u8_host(gs360_ctx *ctx, const uint8_t *src, int W, int H, int C, size_t src_stride,
                                  const gs360_view *views, int n_views,

@@ -134,12 +134,56 @@ def fisheye_cfg(ctx, steps):
     return res
 
 
+def color_cfg(ctx, steps):
+    """--input-lut stage on one 4000x4000 lens image, 33^3 cube, sRGB re-encode: a smooth image (colour locality, the
+    photographic case) and i.i.d. noise (every pixel in another LUT cell: the L2-gather worst case)."""
+    from gs360 import color
+    from oracle import color_np
+    n = 33
+    g = np.linspace(0, 1, n, dtype=np.float32)
+    bb, gg, rr = np.meshgrid(g, g, g, indexing="ij")
+    table = np.stack([rr ** 0.8, 0.9 * gg + 0.1 * bb, np.sqrt(bb)], -1).astype(np.float32)
+    stage = color.ColorStage(color.CubeLUT(n, table, np.zeros(3, np.float32), np.ones(3, np.float32)), "srgb")
+    res = []
+    for label, img in (("smooth+hash image", synth(4000, 4000, 3)),
+                       ("i.i.d. noise image", np.random.default_rng(1).integers(0, 256, (4000, 4000, 3), dtype=np.uint8))):
+        d_in, d_out = ctx.to_device(img), ctx.alloc(img.nbytes)
+        plan = stage._plan(ctx)
+
+        def call():
+            ctx.color_apply_dev(plan, d_in, 4000, 4000, 3, dst=d_out, slot=0)
+        ms = time_steps(ctx, call, steps)
+        got = ctx.download(d_out, img.shape)
+        rows = np.r_[0:4000:131]
+        want = color_np.color_pipeline(img[rows], table, stage.lut.domain_min, stage.lut.domain_max, "srgb", red_index=0)
+        algo = 2 * img.nbytes                      # read + write of the image; the LUT (575 KB) is cache-resident
+        res.append({"config": "colour stage 4000x4000x3, 33^3 LUT + Rec.709->sRGB, " + label, "ms_per_image": round(ms, 4),
+                    "MPix_per_s": round(16.0 / ms * 1e3, 0), "algorithmic_MB_per_image": round(algo / 1e6, 1),
+                    "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
+                    "parity_vs_oracle": bool(np.array_equal(got[rows], want))})
+        ctx.free(d_in)
+        ctx.free(d_out)
+    stage.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--only", default="", help="comma list of: equirect, fisheye, color (default all)")
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=1)
     rows = []
+    only = {t for t in args.only.split(",") if t}
+    if only and "equirect" not in only:
+        if "fisheye" in only:
+            rows += fisheye_cfg(ctx, args.steps)
+        if "color" in only:
+            rows += color_cfg(ctx, args.steps)
+        for r in rows:
+            print(json.dumps(r))
+        ctx.close()
+        return
     rows.append(equirect_cfg(ctx, "cfg1 5760x2880 -> default preset 8x1600^2", 5760, 2880, ring_views(8, 1600, HFOV_12MM), 8, args.steps))
     rows.append(equirect_cfg(ctx, "cfg2 7680x3840 -> 6x800^2 (headline, bench.py)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps))
     rows.append(equirect_cfg(ctx, "cfg2 with INTER_CUBIC (reference default interp)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps,
@@ -150,7 +194,10 @@ def main():
                              [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps))
     rows.append(equirect_cfg(ctx, "cfg5 + fused keep-mask multiply (u8 mask, nearest, threshold 128)", 7680, 3840,
                              [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps, with_mask=True))
-    rows += fisheye_cfg(ctx, args.steps)
+    if not only or "fisheye" in only:
+        rows += fisheye_cfg(ctx, args.steps)
+    if not only or "color" in only:
+        rows += color_cfg(ctx, args.steps)
     for r in rows:
         print(json.dumps(r))
     ctx.close()

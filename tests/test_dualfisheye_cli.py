@@ -158,3 +158,72 @@ def test_pair_pipeline_end_to_end_on_gpu(tmp_path, orc, mode):
         got = imageio.read_image(d.resolve().with_name("shots_undistorted") / "frame_0001_Y.png")
         want = orc.valid_fill(orc.remap_u8(imgs[(1, "Y")], und.map_x, und.map_y, interp=1, border_value=(0, 0, 5, 0)), und.valid_mask, 5)
         assert np.array_equal(got, want)
+
+
+# ---- --input-lut (.cube colour stage, DF:494-725 / DF:2098-2118 / DF:2453-2458) -------------------------------------
+def write_cube(path, n=5):
+    g = np.linspace(0.0, 1.0, n)
+    rows = ["LUT_3D_SIZE {}".format(n)]
+    for b in g:
+        for gg in g:
+            for r in g:
+                rows.append("{:.6f} {:.6f} {:.6f}".format(0.9 * r ** 0.7 + 0.05 * gg, 0.8 * gg + 0.1 * b ** 2, 1.02 * b ** 0.5 - 0.01))
+    path.write_text("\n".join(rows) + "\n")
+
+
+def test_input_lut_flag_errors_and_info_lines(tmp_path):
+    d = tmp_path / "shots"
+    make_pairs(d, n=1)
+    xml = tmp_path / "c.xml"
+    xml.write_text(SMALL_XML)
+    r = run(["-i", str(d), "-x", str(xml), "--dry-run", "--input-lut", str(tmp_path / "none.cube")])
+    assert r.returncode == 1 and "[ERR] Failed to load input LUT: LUT file not found:" in r.stderr
+    bad = tmp_path / "bad.cube"
+    bad.write_text("LUT_3D_SIZE 2\n0 0 0\n")
+    r = run(["-i", str(d), "-x", str(xml), "--dry-run", "--input-lut", str(bad)])
+    assert r.returncode == 1 and "[ERR] Failed to load input LUT: LUT row count mismatch" in r.stderr
+    cube = tmp_path / "look.cube"
+    write_cube(cube)
+    r = run(["-i", str(d), "-x", str(xml), "--dry-run", "--input-lut", str(cube), "--lut-output-color-space", "native",
+             "--save-color-corrected-output"])
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    assert f"[INFO] input LUT: {cube.resolve()}" in out and "[INFO] LUT output color space: passthrough" in out
+    assert f"[INFO] color-corrected output: {d.resolve().with_name('shots_colorcorrected')}" in out
+    assert "[DRY][COLOR]    1/   1 frame_0000_X.png -> frame_0000_X.png" in out
+    assert out[-1] == "[DONE] processed=2 skipped=0 total=2 persp_outputs=10 mask_outputs=0 color_outputs=2 errors=0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("space", ["srgb", "passthrough"])
+def test_pair_pipeline_with_input_lut_on_gpu(tmp_path, orc, space):
+    """colour stage first, resampling second (DF:1938-1947): outputs equal oracle-remap(oracle-colour(image))"""
+    from gs360 import color
+    from oracle import color_np
+    d = tmp_path / "shots"
+    imgs = make_pairs(d, n=1)
+    xml = tmp_path / "c.xml"
+    xml.write_text(SMALL_XML)
+    cube = tmp_path / "look.cube"
+    write_cube(cube)
+    r = run(["-i", str(d), "-x", str(xml), "--interpolation", "linear", "--perspective-size", "64", "--perspective-ext", "png",
+             "--input-lut", str(cube), "--lut-output-color-space", space, "--save-color-corrected-output", "--save-fisheye-output"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "[OK ][COLOR]    1/   1 frame_0000_X.png -> frame_0000_X.png" in r.stdout
+    assert r.stdout.splitlines()[-1] == "[DONE] processed=2 skipped=0 total=2 persp_outputs=10 mask_outputs=0 color_outputs=2 errors=0"
+    lut = color.load_cube_lut(cube)
+    conv = {k: color_np.color_pipeline(v, lut.table, lut.domain_min, lut.domain_max, space, red_index=0) for k, v in imgs.items()}
+    for lens in "XY":
+        got = imageio.read_image(d.resolve().with_name("shots_colorcorrected") / f"frame_0000_{lens}.png")
+        assert np.array_equal(got, conv[(0, lens)])
+    sensors, _ = fe.load_metashape_calibration(xml)
+    specs = fe.sfm10_specs(64, 14.0, "36 36", 40.0, 40.0)
+    tables = fe.choose_lens_tables(sensors, "0", "0", specs, 0.0, 180.0, 190.0)
+    for spec in specs:
+        t = tables[spec["view_id"]]
+        got = imageio.read_image(d.resolve().with_name("shots_perspective_colmap") / "Images" / f"frame_0000_{spec['view_id']}.png")
+        want = orc.valid_fill(orc.remap_u8(conv[(0, t["lens_key"])], t["map_x"], t["map_y"], interp=1, border_value=0.0), t["valid"], 0)
+        assert np.array_equal(got, want), spec["view_id"]
+    und = fe.undistort_tables(sensors["0"], None, 190.0)
+    got = imageio.read_image(d.resolve().with_name("shots_undistorted") / "frame_0000_X.png")
+    assert np.array_equal(got, orc.valid_fill(orc.remap_u8(conv[(0, "X")], und.map_x, und.map_y, interp=1, border_value=0.0), und.valid_mask, 0))
