@@ -516,8 +516,9 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
 struct gs360_color_plan {
     int device = 0;
     int lut_size = 0;
-    void* d_lut = nullptr;      // float4[size^3]
-    float* d_tables = nullptr;  // float[1024]
+    int fixups = 0;
+    void* d_rtab = nullptr;     // float3[n*n*256], see gs360_color.hip
+    float* d_tables = nullptr;  // level positions, thresholds, bin levels
 };
 
 int gs360_color_plan_create(gs360_ctx* c, const float* lut, int lut_size, const float* level_pos,
@@ -529,34 +530,35 @@ int gs360_color_plan_create(gs360_ctx* c, const float* lut, int lut_size, const 
     for (int i = 0; i < 768; ++i)   // positions index the table: refuse anything that would read outside it
         if (!(level_pos[i] >= 0.0f && level_pos[i] <= (float)nmax))
             return fail(GS360_ERR_ARG, "level_pos[%d] = %g outside [0,%d]", i, (double)level_pos[i], nmax);
-    for (int k = 2; k < 256; ++k)
-        if (!(out_thresholds[k] >= out_thresholds[k - 1]))
+    for (int k = 1; k < 256; ++k) {
+        if (!(out_thresholds[k] >= 0.0f)) return fail(GS360_ERR_ARG, "out_thresholds[%d] is negative or NaN", k);
+        if (k > 1 && !(out_thresholds[k] >= out_thresholds[k - 1]))
             return fail(GS360_ERR_ARG, "out_thresholds must be non-decreasing (entry %d)", k);
+    }
     HIP_TRY(hipSetDevice(c->device));
     gs360_color_plan* p = new (std::nothrow) gs360_color_plan();
     if (!p) return fail(GS360_ERR_NOMEM, "out of host memory");
     p->device = c->device;
     p->lut_size = lut_size;
     const size_t n3 = (size_t)lut_size * lut_size * lut_size;
-    std::vector<float> packed(n3 * 4);
-    for (size_t i = 0; i < n3; ++i) {
-        packed[4 * i + 0] = lut[3 * i + 0];
-        packed[4 * i + 1] = lut[3 * i + 1];
-        packed[4 * i + 2] = lut[3 * i + 2];
-        packed[4 * i + 3] = 0.0f;
-    }
-    float tables[1024];
-    std::memcpy(tables, level_pos, 768 * sizeof(float));
-    std::memcpy(tables + 768, out_thresholds, 256 * sizeof(float));
-    hipError_t e = hipMalloc(&p->d_lut, packed.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_tables, sizeof(tables));
-    if (e == hipSuccess) e = hipMemcpy(p->d_lut, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(p->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice);
+    std::vector<float> tables(color_tables_floats(), 0.0f);
+    std::memcpy(tables.data(), level_pos, 768 * sizeof(float));
+    std::memcpy(tables.data() + 768, out_thresholds, 256 * sizeof(float));
+    p->fixups = color_build_bins(out_thresholds, (uint8_t*)(tables.data() + 1024));
+    float* d_lut = nullptr;
+    hipError_t e = hipMalloc((void**)&d_lut, n3 * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&p->d_rtab, color_rtab_bytes(lut_size) + kSlack);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_tables, tables.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_lut, lut, n3 * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = build_color_rtab(d_lut, p->d_tables /* red positions come first */, p->d_rtab, lut_size, c->stream[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream[0]);
+    if (d_lut) (void)hipFree(d_lut);
     if (e != hipSuccess) {
-        if (p->d_lut) (void)hipFree(p->d_lut);
+        if (p->d_rtab) (void)hipFree(p->d_rtab);
         if (p->d_tables) (void)hipFree(p->d_tables);
         delete p;
-        return fail(GS360_ERR_HIP, "colour plan upload failed: %s", hipGetErrorString(e));
+        return fail(GS360_ERR_HIP, "colour plan setup failed: %s", hipGetErrorString(e));
     }
     *out = p;
     return GS360_OK;
@@ -567,7 +569,7 @@ int gs360_color_plan_destroy(gs360_ctx* c, gs360_color_plan* p) {
     if (!p) return GS360_OK;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (p->d_lut) HIP_TRY(hipFree(p->d_lut));
+    if (p->d_rtab) HIP_TRY(hipFree(p->d_rtab));
     if (p->d_tables) HIP_TRY(hipFree(p->d_tables));
     delete p;
     return GS360_OK;
@@ -588,8 +590,8 @@ int gs360_color_apply_u8(gs360_ctx* c, const gs360_color_plan* p, const void* sr
     if (src_stride < (size_t)W * C || dst_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
     HIP_TRY(hipSetDevice(c->device));
     ColorLaunch L;
-    L.src = (const uint8_t*)src; L.dst = (uint8_t*)dst; L.lut = p->d_lut; L.tables = p->d_tables;
-    L.H = H; L.W = W; L.lut_size = p->lut_size; L.red_index = red_index;
+    L.src = (const uint8_t*)src; L.dst = (uint8_t*)dst; L.rtab = p->d_rtab; L.tables = p->d_tables;
+    L.H = H; L.W = W; L.lut_size = p->lut_size; L.red_index = red_index; L.fixups = p->fixups;
     L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
     HIP_TRY(launch_color(L, C, c->stream[slot]));
     return GS360_OK;

@@ -1,13 +1,22 @@
 // gs360_color.hip -- the dual-fisheye tool's input colour stage on the GPU (include/gs360.h, "input colour stage").
 //
 // Reference: apply_input_color_pipeline, cli_tools/gs360_DualFisheyeDistortionCalibration.py:684-725 --
-// u8 -> float01 (DF:603-613) -> .cube trilinear (DF:620-681) -> rec709_to_srgb (DF:565-600, optional) -> u8 (DF:616-...).
+// u8 -> float01 (DF:603-613) -> .cube trilinear (DF:620-681) -> rec709_to_srgb (DF:565-600, optional) -> u8 (DF:616-618).
 // The two scalar ends (level -> grid position, LUT output -> 8-bit level) arrive as host-built tables (256 x 3 floats
-// and 255 thresholds, see the header); the kernel does the 8-texel interpolation in the reference's float32 operation
-// order (sub, mul, add -- never fused: the library is built with -ffp-contract=off), so the result is the byte the
-// NumPy pipeline produces.  A streaming kernel: HBM-bound for images with colour locality; the 8 LUT texel reads per
-// pixel come from L2 (a 33^3 table is 575 KB as float4).
+// and 255 thresholds, see the header); the interpolation in between is done here in the reference's float32
+// operation order (sub, mul, add -- never fused: the library is built with -ffp-contract=off), so the result is the
+// byte the NumPy pipeline produces.
+//
+// Layout.  The red channel has only 256 possible grid positions, so the first of the three interpolation stages
+// (along red, DF:672-675) is evaluated once per plan for every (blue node, green node, red LEVEL) with exactly the
+// reference's operations and stored as `rtab[b][g][level]` (float3, n*n*256 entries: 3.3 MB for a 33^3 cube).  The
+// per-pixel work is then 4 reads of 12 bytes (the two green nodes x two blue nodes around the pixel) and the green
+// and blue stages -- 48 B/pixel through the texture path instead of 128 B for eight float4 texels, and all pixels
+// of one (blue, green) cell share four 3 KB table rows.  The output quantiser is a 1024-bin lower-bound table plus
+// one or two threshold compares (exact: the bin table is derived from the thresholds), falling back to a binary
+// search when the thresholds are too dense for that.
 #include <cstring>
+#include <vector>
 
 #include "gs360_kernels.h"
 
@@ -16,19 +25,23 @@ namespace gs360 {
 namespace {
 
 constexpr int kColorThreads = 256;
+constexpr int kBins = 1024;
+constexpr int kColorBlocks = 2048;   // persistent blocks of the dword-aligned path: 256 CUs x 8
+
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 
 struct ColorArgs {
     const uint8_t* src;
     uint8_t* dst;
-    const float4* lut;      // [b][g][r] -> (R,G,B,0)
-    const float* tables;    // 768 level positions (R,G,B x 256) followed by 256 output thresholds
+    const F3* rtab;         // [b][g][red level]
+    const float* tables;    // 768 level positions (R,G,B x 256), 256 thresholds, then kBins/4 dwords of packed bin levels
     int32_t H, W;
     int32_t n;              // LUT edge length
     int32_t red;            // memory index of the red channel (0 or 2)
     int64_t src_stride, dst_stride;
 };
 
-struct Cell {               // one channel's LUT cell: lower index, upper index, weight of the upper texel
+struct Cell {               // one channel's LUT cell: lower index, upper index, weight of the upper node
     int i0, i1;
     float f;
 };
@@ -45,147 +58,236 @@ __device__ __forceinline__ Cell cell_of(float pos, int nmax) {
 
 __device__ __forceinline__ float lerp_ref(float a, float b, float t) { return a + (b - a) * t; }   // DF:672-679
 
-__device__ __forceinline__ int level_of(const float* thr, float x) {
-    // number of thresholds <= x among thr[1..255] (non-decreasing); NaN compares false everywhere -> 0
-    int lv = 0;
+struct Lds {
+    float pos[768];
+    float thr[260];          // [0] unused, [1..255] thresholds, [256..] = +inf sentinels
+    uint8_t bin[kBins];
+};
+
+// number of thresholds <= clip(x, 0, 1) among thr[1..255] (non-decreasing); NaN counts as 0
+template <int FIX>
+__device__ __forceinline__ int level_of(const Lds& S, float x) {
+    const float xc = fminf(fmaxf(x, 0.0f), 1.0f);                       // fmaxf(NaN, 0) = 0
+    if (FIX == 0) {          // general: binary search
+        int lv = 0;
 #pragma unroll
-    for (int bit = 128; bit > 0; bit >>= 1) {
-        const int cand = lv | bit;
-        lv = (x >= thr[cand]) ? cand : lv;
+        for (int bit = 128; bit > 0; bit >>= 1) {
+            const int cand = lv | bit;
+            lv = (xc >= S.thr[cand]) ? cand : lv;
+        }
+        return lv;
     }
+    int lv = S.bin[min((int)(xc * (float)kBins), kBins - 1)];           // thresholds <= the bin's lower edge
+#pragma unroll
+    for (int k = 0; k < FIX; ++k) lv += (xc >= S.thr[lv + 1]) ? 1 : 0;  // at most FIX thresholds lie inside a bin
     return lv;
 }
 
 struct Rgb8 { int r, g, b; };
 
-// the whole pipeline for one pixel: three 8-bit levels in, three out
-__device__ __forceinline__ Rgb8 color_px(const ColorArgs& A, const float* s_pos, const float* s_thr, int vr, int vg, int vb) {
+struct Taps {               // the four red-interpolated table entries around a pixel and its green/blue weights
+    F3 c00, c10, c01, c11;
+    float gf, bf;
+};
+
+// first half of the pipeline for one pixel: locate the cell and issue the four table reads
+__device__ __forceinline__ Taps color_fetch(const ColorArgs& A, const Lds& S, int vr, int vg, int vb) {
     const int n = A.n, nmax = n - 1;
-    const Cell r = cell_of(s_pos[vr], nmax);
-    const Cell g = cell_of(s_pos[256 + vg], nmax);
-    const Cell b = cell_of(s_pos[512 + vb], nmax);
-    const int row00 = (b.i0 * n + g.i0) * n, row10 = (b.i0 * n + g.i1) * n;
-    const int row01 = (b.i1 * n + g.i0) * n, row11 = (b.i1 * n + g.i1) * n;
-    // all eight texel reads are issued before the arithmetic starts
-    const float4 c000 = A.lut[row00 + r.i0], c100 = A.lut[row00 + r.i1];
-    const float4 c010 = A.lut[row10 + r.i0], c110 = A.lut[row10 + r.i1];
-    const float4 c001 = A.lut[row01 + r.i0], c101 = A.lut[row01 + r.i1];
-    const float4 c011 = A.lut[row11 + r.i0], c111 = A.lut[row11 + r.i1];
-    float o[3];
-    int k = 0;
-#define GS360_TRI(ch)                                                   \
-    {                                                                   \
-        const float c00 = lerp_ref(c000.ch, c100.ch, r.f);              \
-        const float c10 = lerp_ref(c010.ch, c110.ch, r.f);              \
-        const float c01 = lerp_ref(c001.ch, c101.ch, r.f);              \
-        const float c11 = lerp_ref(c011.ch, c111.ch, r.f);              \
-        const float c0 = lerp_ref(c00, c10, g.f);                       \
-        const float c1 = lerp_ref(c01, c11, g.f);                       \
-        o[k++] = lerp_ref(c0, c1, b.f);                                 \
-    }
-    GS360_TRI(x) GS360_TRI(y) GS360_TRI(z)
-#undef GS360_TRI
+    const Cell g = cell_of(S.pos[256 + vg], nmax);
+    const Cell b = cell_of(S.pos[512 + vb], nmax);
+    const uint32_t r0 = (uint32_t)(b.i0 * n), r1 = (uint32_t)(b.i1 * n);
+    const char* base = (const char*)A.rtab;        // the table is < 4 GiB: 32-bit byte offsets from a scalar base
+    Taps t;
+    t.c00 = *(const F3*)(base + (((r0 + g.i0) << 8) + vr) * 12u);
+    t.c10 = *(const F3*)(base + (((r0 + g.i1) << 8) + vr) * 12u);
+    t.c01 = *(const F3*)(base + (((r1 + g.i0) << 8) + vr) * 12u);
+    t.c11 = *(const F3*)(base + (((r1 + g.i1) << 8) + vr) * 12u);
+    t.gf = g.f;
+    t.bf = b.f;
+    return t;
+}
+
+// second half: green stage, blue stage (DF:676-679), quantise
+template <int FIX>
+__device__ __forceinline__ Rgb8 color_finish(const Lds& S, const Taps& t) {
     Rgb8 q;
-    q.r = level_of(s_thr, o[0]);
-    q.g = level_of(s_thr, o[1]);
-    q.b = level_of(s_thr, o[2]);
+    q.r = level_of<FIX>(S, lerp_ref(lerp_ref(t.c00.x, t.c10.x, t.gf), lerp_ref(t.c01.x, t.c11.x, t.gf), t.bf));
+    q.g = level_of<FIX>(S, lerp_ref(lerp_ref(t.c00.y, t.c10.y, t.gf), lerp_ref(t.c01.y, t.c11.y, t.gf), t.bf));
+    q.b = level_of<FIX>(S, lerp_ref(lerp_ref(t.c00.z, t.c10.z, t.gf), lerp_ref(t.c01.z, t.c11.z, t.gf), t.bf));
     return q;
 }
 
-__device__ __forceinline__ void load_tables(const ColorArgs& A, float* s_pos, float* s_thr) {
-    for (int i = threadIdx.x; i < 1024; i += kColorThreads) {
-        const float v = A.tables[i];
-        if (i < 768) s_pos[i] = v; else s_thr[i - 768] = v;
+template <int FIX>
+__device__ __forceinline__ Rgb8 color_px(const ColorArgs& A, const Lds& S, int vr, int vg, int vb) {
+    return color_finish<FIX>(S, color_fetch(A, S, vr, vg, vb));
+}
+
+__device__ __forceinline__ void load_tables(const ColorArgs& A, Lds& S) {
+    constexpr int kPer = (1024 + kBins / 4) / kColorThreads;               // 5 dwords per thread, all in flight at once
+    static_assert((1024 + kBins / 4) % kColorThreads == 0, "table size");
+    float v[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) v[j] = A.tables[j * kColorThreads + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = j * kColorThreads + threadIdx.x;
+        if (i < 768) S.pos[i] = v[j];
+        else if (i < 1024) S.thr[i - 768] = v[j];
+        else ((float*)S.bin)[i - 1024] = v[j];
     }
+    if (threadIdx.x < 4) S.thr[256 + threadIdx.x] = __builtin_inff();
     __syncthreads();
 }
 
 // Any alignment: one thread per pixel, byte loads and stores.
-template <int C>
+template <int C, int FIX>
 __global__ __launch_bounds__(kColorThreads) void color_lut_bytes_kernel(ColorArgs A) {
-    __shared__ float s_pos[768];
-    __shared__ float s_thr[256];
-    load_tables(A, s_pos, s_thr);
+    __shared__ Lds S;
+    load_tables(A, S);
     const int x = blockIdx.x * kColorThreads + threadIdx.x;
     if (x >= A.W) return;
     const uint8_t* sp = A.src + (int64_t)blockIdx.y * A.src_stride + (int64_t)x * C;
     uint8_t* dp = A.dst + (int64_t)blockIdx.y * A.dst_stride + (int64_t)x * C;
     const int iR = A.red, iB = 2 - A.red;
     const int alpha = (C == 4) ? sp[3] : 0;
-    const Rgb8 q = color_px(A, s_pos, s_thr, sp[iR], sp[1], sp[iB]);
+    const Rgb8 q = color_px<FIX>(A, S, sp[iR], sp[1], sp[iB]);
     dp[iR] = (uint8_t)q.r; dp[1] = (uint8_t)q.g; dp[iB] = (uint8_t)q.b;
     if (C == 4) dp[3] = (uint8_t)alpha;
 }
 
 // Rows that start on a dword boundary: one thread per 4 pixels = C dwords in, C dwords out, so a wavefront moves
-// 768 (C=3) or 1024 (C=4) contiguous bytes per row segment.
-template <int C>
+// 768 (C=3) or 1024 (C=4) contiguous bytes per row segment.  Blocks are persistent (the LDS tables are loaded once
+// per block) and walk 1024-pixel row segments in row-major order.
+template <int C, int FIX>
 __global__ __launch_bounds__(kColorThreads) void color_lut_quad_kernel(ColorArgs A) {
-    __shared__ float s_pos[768];
-    __shared__ float s_thr[256];
-    load_tables(A, s_pos, s_thr);
-    const int x = (blockIdx.x * kColorThreads + threadIdx.x) * 4;
-    if (x >= A.W) return;
-    const uint8_t* sp = A.src + (int64_t)blockIdx.y * A.src_stride + (int64_t)x * C;
-    uint8_t* dp = A.dst + (int64_t)blockIdx.y * A.dst_stride + (int64_t)x * C;
+    __shared__ Lds S;
+    load_tables(A, S);
     const int iR = A.red, iB = 2 - A.red;
     const bool bgr = A.red != 0;
-    if (x + 4 <= A.W) {
-        uint32_t w[C];
-        const uint32_t* s32 = (const uint32_t*)sp;
+    const int segs = (A.W + 4 * kColorThreads - 1) / (4 * kColorThreads);
+    const int total = segs * A.H;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int y = t / segs;
+        const int x = ((t - y * segs) * kColorThreads + threadIdx.x) * 4;
+        if (x >= A.W) continue;
+        const uint8_t* sp = A.src + (int64_t)y * A.src_stride + (int64_t)x * C;
+        uint8_t* dp = A.dst + (int64_t)y * A.dst_stride + (int64_t)x * C;
+        if (x + 4 <= A.W) {
+            uint32_t w[C];
+            const uint32_t* s32 = (const uint32_t*)sp;
 #pragma unroll
-        for (int i = 0; i < C; ++i) w[i] = s32[i];
-        uint32_t o[C];
+            for (int i = 0; i < C; ++i) w[i] = s32[i];
+            Taps taps[4];                          // all 16 table reads of the four pixels are in flight together
 #pragma unroll
-        for (int i = 0; i < C; ++i) o[i] = (C == 4) ? (w[i] & 0xff000000u) : 0u;
+            for (int p = 0; p < 4; ++p) {
+                int v[3];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int v[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int byte = p * C + c;
-                v[c] = (w[byte >> 2] >> (8 * (byte & 3))) & 0xff;
+                for (int c = 0; c < 3; ++c) {
+                    const int byte = p * C + c;
+                    v[c] = (w[byte >> 2] >> (8 * (byte & 3))) & 0xff;
+                }
+                taps[p] = color_fetch(A, S, bgr ? v[2] : v[0], v[1], bgr ? v[0] : v[2]);
             }
-            const Rgb8 q = color_px(A, s_pos, s_thr, bgr ? v[2] : v[0], v[1], bgr ? v[0] : v[2]);
-            const int out3[3] = {bgr ? q.b : q.r, q.g, bgr ? q.r : q.b};
+            __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from sinking reads below the first blend
+            uint32_t o[C];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int byte = p * C + c;
-                o[byte >> 2] |= (uint32_t)out3[c] << (8 * (byte & 3));
+            for (int i = 0; i < C; ++i) o[i] = (C == 4) ? (w[i] & 0xff000000u) : 0u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const Rgb8 q = color_finish<FIX>(S, taps[p]);
+                const int out3[3] = {bgr ? q.b : q.r, q.g, bgr ? q.r : q.b};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int byte = p * C + c;
+                    o[byte >> 2] |= (uint32_t)out3[c] << (8 * (byte & 3));
+                }
+            }
+            uint32_t* d32 = (uint32_t*)dp;
+#pragma unroll
+            for (int i = 0; i < C; ++i) d32[i] = o[i];
+        } else {
+            for (int p = 0; x + p < A.W; ++p) {
+                const uint8_t* s1 = sp + p * C;
+                uint8_t* d1 = dp + p * C;
+                const int alpha = (C == 4) ? s1[3] : 0;
+                const Rgb8 q = color_px<FIX>(A, S, s1[iR], s1[1], s1[iB]);
+                d1[iR] = (uint8_t)q.r; d1[1] = (uint8_t)q.g; d1[iB] = (uint8_t)q.b;
+                if (C == 4) d1[3] = (uint8_t)alpha;
             }
         }
-        uint32_t* d32 = (uint32_t*)dp;
-#pragma unroll
-        for (int i = 0; i < C; ++i) d32[i] = o[i];
+    }
+}
+
+// Plan creation: the red stage of DF:672-675 for every (blue node, green node, red level).
+__global__ void color_rtab_kernel(const float* lut /* [b][g][r][3] */, const float* pos_r /* 256 */, F3* rtab, int n) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n * 256) return;
+    const int level = idx & 255, row = idx >> 8;          // row = b*n + g
+    const Cell r = cell_of(pos_r[level], n - 1);
+    const float* lo = lut + ((size_t)row * n + r.i0) * 3;
+    const float* hi = lut + ((size_t)row * n + r.i1) * 3;
+    F3 o;
+    o.x = lerp_ref(lo[0], hi[0], r.f);
+    o.y = lerp_ref(lo[1], hi[1], r.f);
+    o.z = lerp_ref(lo[2], hi[2], r.f);
+    rtab[idx] = o;
+}
+
+template <int C, int FIX>
+void launch_variant(const ColorArgs& A, bool aligned, hipStream_t s) {
+    if (aligned) {
+        const long total = (long)((A.W + 4 * kColorThreads - 1) / (4 * kColorThreads)) * A.H;
+        dim3 grid((unsigned)(total < kColorBlocks ? total : kColorBlocks));
+        hipLaunchKernelGGL((color_lut_quad_kernel<C, FIX>), grid, dim3(kColorThreads), 0, s, A);
     } else {
-        for (int p = 0; x + p < A.W; ++p) {
-            const uint8_t* s1 = sp + p * C;
-            uint8_t* d1 = dp + p * C;
-            const int alpha = (C == 4) ? s1[3] : 0;
-            const Rgb8 q = color_px(A, s_pos, s_thr, s1[iR], s1[1], s1[iB]);
-            d1[iR] = (uint8_t)q.r; d1[1] = (uint8_t)q.g; d1[iB] = (uint8_t)q.b;
-            if (C == 4) d1[3] = (uint8_t)alpha;
-        }
+        dim3 grid((unsigned)((A.W + kColorThreads - 1) / kColorThreads), (unsigned)A.H);
+        hipLaunchKernelGGL((color_lut_bytes_kernel<C, FIX>), grid, dim3(kColorThreads), 0, s, A);
     }
 }
 
 }  // namespace
 
+size_t color_rtab_bytes(int lut_size) { return (size_t)lut_size * lut_size * 256 * sizeof(F3); }
+size_t color_tables_floats() { return 1024 + kBins / 4; }
+
+// Host: derive the bin table from the thresholds; returns the number of in-bin fix-up compares needed (1 or 2),
+// or 0 when some bin holds more than two thresholds (binary search variant).
+int color_build_bins(const float* thr /* 256, [0] unused */, uint8_t* bins /* kBins */) {
+    int worst = 0;
+    for (int i = 0; i < kBins; ++i) {
+        const float lo = (float)i / (float)kBins;                        // exact
+        const float hi = (float)(i + 1) / (float)kBins;
+        int below = 0, inside = 0;
+        for (int k = 1; k < 256; ++k) {
+            if (thr[k] <= lo) ++below;
+            else if (i == kBins - 1 ? thr[k] <= 1.0f : thr[k] < hi) ++inside;
+        }
+        bins[i] = (uint8_t)below;
+        if (inside > worst) worst = inside;
+    }
+    return worst <= 1 ? 1 : (worst == 2 ? 2 : 0);
+}
+
+hipError_t build_color_rtab(const float* d_lut, const float* d_pos_r, void* d_rtab, int lut_size, hipStream_t s) {
+    const int total = lut_size * lut_size * 256;
+    hipLaunchKernelGGL(color_rtab_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_lut, d_pos_r, (F3*)d_rtab, lut_size);
+    return hipGetLastError();
+}
+
 hipError_t launch_color(const ColorLaunch& L, int C, hipStream_t s) {
     ColorArgs A;
-    A.src = L.src; A.dst = L.dst; A.lut = (const float4*)L.lut; A.tables = L.tables;
+    A.src = L.src; A.dst = L.dst; A.rtab = (const F3*)L.rtab; A.tables = L.tables;
     A.H = L.H; A.W = L.W; A.n = L.lut_size; A.red = L.red_index;
     A.src_stride = L.src_stride; A.dst_stride = L.dst_stride;
     const bool aligned = (((uintptr_t)L.src | (uintptr_t)L.dst | (uint64_t)L.src_stride | (uint64_t)L.dst_stride) & 3u) == 0;
-    if (aligned) {
-        const int quads = (L.W + 3) / 4;
-        dim3 grid((unsigned)((quads + kColorThreads - 1) / kColorThreads), (unsigned)L.H);
-        if (C == 3) hipLaunchKernelGGL(color_lut_quad_kernel<3>, grid, dim3(kColorThreads), 0, s, A);
-        else hipLaunchKernelGGL(color_lut_quad_kernel<4>, grid, dim3(kColorThreads), 0, s, A);
+    if (C == 3) {
+        if (L.fixups == 1) launch_variant<3, 1>(A, aligned, s);
+        else if (L.fixups == 2) launch_variant<3, 2>(A, aligned, s);
+        else launch_variant<3, 0>(A, aligned, s);
     } else {
-        dim3 grid((unsigned)((L.W + kColorThreads - 1) / kColorThreads), (unsigned)L.H);
-        if (C == 3) hipLaunchKernelGGL(color_lut_bytes_kernel<3>, grid, dim3(kColorThreads), 0, s, A);
-        else hipLaunchKernelGGL(color_lut_bytes_kernel<4>, grid, dim3(kColorThreads), 0, s, A);
+        if (L.fixups == 1) launch_variant<4, 1>(A, aligned, s);
+        else if (L.fixups == 2) launch_variant<4, 2>(A, aligned, s);
+        else launch_variant<4, 0>(A, aligned, s);
     }
     return hipGetLastError();
 }

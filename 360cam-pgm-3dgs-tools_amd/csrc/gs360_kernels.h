@@ -103,11 +103,16 @@ struct FeLaunch {          // host-side batch description; launch_fisheye() issu
 struct ColorLaunch {
     const uint8_t* src;
     uint8_t* dst;
-    const void* lut;        // device float4[size^3], [b][g][r] -> (R,G,B,0)
-    const float* tables;    // device float[1024]: level positions R,G,B x 256, then 256 output thresholds
+    const void* rtab;       // device float3[n*n*256]: LUT pre-interpolated along red for every red level
+    const float* tables;    // device: level positions R,G,B x 256, 256 output thresholds, packed bin levels
     int32_t H, W, lut_size, red_index;
+    int32_t fixups;         // 1 or 2 in-bin threshold compares, 0 = binary search (color_build_bins)
     int64_t src_stride, dst_stride;
 };
+size_t color_rtab_bytes(int lut_size);
+size_t color_tables_floats();
+int color_build_bins(const float* thresholds, uint8_t* bins);
+hipError_t build_color_rtab(const float* d_lut, const float* d_pos_r, void* d_rtab, int lut_size, hipStream_t s);
 hipError_t launch_color(const ColorLaunch& L, int C, hipStream_t s);
 
 // kernel launchers (gs360_kernels.hip)

@@ -162,8 +162,8 @@ int gs360_fisheye_views_u8(gs360_ctx *ctx, const void *const *src_lens, const gs
  *   level_pos[c*256 + v]  LUT-grid position `clip((v/255 - domain_min[c]) / span[c], 0, 1) * (size-1)` of input
  *                         level v on channel c (c = 0,1,2 = R,G,B)
  *   out_thresholds[k]     k = 1..255: the smallest float32 LUT output x for which the encoded 8-bit result is >= k
- *                         (entry 0 is ignored; +inf = never reached).  The encode step is monotone, so the output
- *                         level is the number of thresholds <= x.
+ *                         (entry 0 is ignored; entries are >= 0, non-decreasing; +inf = never reached).  The encode
+ *                         step is monotone, so the output level is the number of thresholds <= clip(x, 0, 1).
  *   lut                   size^3 RGB float32 triples, red fastest ([b][g][r][3], the .cube order, DF:556-562)
  * All three are HOST pointers, copied at plan creation.
  */

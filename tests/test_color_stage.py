@@ -127,7 +127,7 @@ def emulate_plan(stage, image, red_index):
         rows = [lerp(T[bi, gi, i0[:, 0]], T[bi, gi, i1[:, 0]], t[:, 0:1]) for gi in (i0[:, 1], i1[:, 1])]
         acc.append(lerp(rows[0], rows[1], t[:, 1:2]))
     x = lerp(acc[0], acc[1], t[:, 2:3])
-    q = np.searchsorted(stage.thresholds[1:], x, side="right").astype(np.uint8).reshape(image.shape[:2] + (3,))[..., order]
+    q = np.searchsorted(stage.thresholds[1:], np.clip(x, 0.0, 1.0), side="right").astype(np.uint8).reshape(image.shape[:2] + (3,))[..., order]
     out = image.copy()
     out[..., :3] = q
     return out
@@ -225,6 +225,31 @@ def test_gpu_full_size_lens_image_33_cube(ctx):
     want = color_np.color_pipeline(image[rows], table, dmin, dmax, "srgb", red_index=0)
     assert np.array_equal(got[rows], want)
     stage.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,thr_of_k", [("one_per_bin", lambda k: k / 520.0), ("two_per_bin", lambda k: 0.3 + k / 1800.0),
+                                            ("dense", lambda k: 0.5 + k * 1e-5), ("ties_and_never", lambda k: np.where(k < 200, (k // 4) / 64.0, np.inf)),
+                                            ("zero_start", lambda k: np.maximum(k - 3, 0) / 300.0)])
+def test_gpu_output_quantiser_variants(ctx, name, thr_of_k):
+    """the bin-table quantiser (1 or 2 compares) and the binary-search fallback count thresholds exactly"""
+    table, dmin, dmax = lut_of("id2")                      # identity cube: LUT output = level / 255
+    pos = color.level_positions(color.CubeLUT(2, table, dmin, dmax))
+    thr = np.empty(256, np.float32)
+    thr[0] = -np.inf
+    thr[1:] = thr_of_k(np.arange(1, 256))
+    plan = ctx.color_plan(table, pos, thr)
+    img = np.random.default_rng(2).integers(0, 256, (33, 64, 3), dtype=np.uint8)
+    img[0, :, 0] = np.arange(64) * 4
+    img[1, :, 1] = 255 - np.arange(64)
+    d = ctx.to_device(img)
+    ctx.color_apply_dev(plan, d, 33, 64, 3)
+    got = ctx.download(d, img.shape)
+    x = color_np.trilinear(img.astype(np.float32) / np.float32(255.0), table, dmin, dmax)
+    want = np.searchsorted(thr[1:], np.clip(x, 0, 1), side="right").astype(np.uint8)
+    assert np.array_equal(got, want), name
+    ctx.free(d)
+    ctx.color_plan_free(plan)
 
 
 @pytest.mark.gpu
