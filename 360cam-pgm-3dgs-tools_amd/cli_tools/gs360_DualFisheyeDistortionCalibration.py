@@ -453,10 +453,7 @@ def main() -> None:
             processed += 2
     else:
         from gs360 import capi, imageio
-        from gs360.dualfisheye import PairRenderer, engine_interpolation
-        if engine_interpolation(interpolation) != interpolation:
-            say("[INFO] gs360 engine: --interpolation {} is not implemented; sampling with cv2-compatible cubic".format(
-                args.interpolation))
+        from gs360.dualfisheye import PairRenderer
         n_dev = capi.device_count()
         if n_dev <= 0:
             _die("[ERR] no MI355X visible: the gs360 engine has no CPU fallback", 2)

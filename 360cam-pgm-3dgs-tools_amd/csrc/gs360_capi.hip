@@ -54,6 +54,7 @@ struct gs360_ctx {
     Staging stage[kMaxSlots];
     hipDeviceProp_t prop;
     int16_t* d_cubic = nullptr;   // 32*32*16 int16 cubic weight table, uploaded at context creation
+    int16_t* d_lanczos = nullptr; // 32*32*64 int16 Lanczos4 weight table
 };
 
 namespace {
@@ -126,34 +127,28 @@ void make_fe_view(const gs360_calib& cal, const gs360_view& v, double lens_fov_d
 
 }  // namespace
 
-// OpenCV imgproc initInterTab2D(INTER_CUBIC, fixed point), restated: Keys kernel A = -0.75 in float32 per 1/32 phase,
-// outer product scaled by 2^15 and rounded to short, then the entries are patched so each 4x4 kernel sums to 2^15.
-void gs360::build_cubic_table(int16_t* out) {
-    float c1[32][4];
-    const float A = -0.75f;
-    for (int i = 0; i < 32; ++i) {
-        const float x = (float)i * (1.0f / 32.0f);
-        c1[i][0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
-        c1[i][1] = ((A + 2) * x - (A + 3)) * x * x + 1;
-        c1[i][2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
-        c1[i][3] = 1.f - c1[i][0] - c1[i][1] - c1[i][2];
-    }
+// OpenCV imgproc initInterTab2D(fixed point), restated: per-phase 1-D coefficients in float32, outer product scaled
+// by 2^15 and rounded to short, then the entries are patched so each ks x ks kernel sums to 2^15 (the patch goes to
+// the largest / smallest entry of rows/cols ks/2 .. ks/2+1, the block OpenCV inspects).
+namespace {
+void build_tab2d(const float* c1, int ks, int16_t* out) {
+    const int h = ks / 2;
     for (int fy = 0; fy < 32; ++fy)
         for (int fx = 0; fx < 32; ++fx) {
-            int16_t* k = out + (fy * 32 + fx) * 16;
+            int16_t* k = out + (fy * 32 + fx) * ks * ks;
             int sum = 0;
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b) {
-                    long r = std::lrintf(c1[fy][a] * c1[fx][b] * 32768.0f);
+            for (int a = 0; a < ks; ++a)
+                for (int b = 0; b < ks; ++b) {
+                    long r = std::lrintf(c1[fy * ks + a] * c1[fx * ks + b] * 32768.0f);
                     r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
-                    k[a * 4 + b] = (int16_t)r;
+                    k[a * ks + b] = (int16_t)r;
                     sum += (int)r;
                 }
-            if (sum != 32768) {   // patch the largest / smallest entry of the block OpenCV inspects (rows/cols 2..3)
-                int hi = 10, lo = 10;
-                for (int a = 2; a < 4; ++a)
-                    for (int b = 2; b < 4; ++b) {
-                        const int idx = a * 4 + b;
+            if (sum != 32768) {
+                int hi = h * ks + h, lo = hi;
+                for (int a = h; a < h + 2; ++a)
+                    for (int b = h; b < h + 2; ++b) {
+                        const int idx = a * ks + b;
                         if (k[idx] < k[lo]) lo = idx;
                         else if (k[idx] > k[hi]) hi = idx;
                     }
@@ -162,6 +157,45 @@ void gs360::build_cubic_table(int16_t* out) {
                 else k[lo] = (int16_t)(k[lo] - diff);
             }
         }
+}
+}  // namespace
+
+void gs360::build_cubic_table(int16_t* out) {   // Keys kernel, A = -0.75
+    float c1[32 * 4];
+    const float A = -0.75f;
+    for (int i = 0; i < 32; ++i) {
+        const float x = (float)i * (1.0f / 32.0f);
+        float* c = c1 + i * 4;
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+    }
+    build_tab2d(c1, 4, out);
+}
+
+void gs360::build_lanczos4_table(int16_t* out) {   // OpenCV interpolateLanczos4: taps -3..+4, one sin/cos pair per phase
+    static const double r = 0.70710678118654752440084436210485;
+    static const double rot[8][2] = {{1, 0}, {-r, -r}, {0, 1}, {r, -r}, {-1, 0}, {r, r}, {0, -1}, {-r, r}};
+    float c1[32 * 8];
+    for (int i = 0; i < 32; ++i) {
+        const float x = (float)i * (1.0f / 32.0f);
+        float* c = c1 + i * 8;
+        if (x < 1.1920928955078125e-07f) {
+            for (int t = 0; t < 8; ++t) c[t] = (t == 3) ? 1.f : 0.f;
+            continue;
+        }
+        const double a0 = -(x + 3) * kPi * 0.25, s0 = std::sin(a0), c0 = std::cos(a0);
+        float sum = 0.f;
+        for (int t = 0; t < 8; ++t) {
+            const double a = -(x + 3 - t) * kPi * 0.25;
+            c[t] = (float)((rot[t][0] * s0 + rot[t][1] * c0) / (a * a));
+            sum += c[t];
+        }
+        sum = 1.f / sum;
+        for (int t = 0; t < 8; ++t) c[t] *= sum;
+    }
+    build_tab2d(c1, 8, out);
 }
 
 namespace {
@@ -230,8 +264,14 @@ int gs360_ctx_create(int device, int n_slots, gs360_ctx** out) {
         build_cubic_table(tab.data());
         e = hipMalloc((void**)&c->d_cubic, tab.size() * sizeof(int16_t));
         if (e == hipSuccess) e = hipMemcpy(c->d_cubic, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            tab.assign(32 * 32 * 64, 0);
+            build_lanczos4_table(tab.data());
+            e = hipMalloc((void**)&c->d_lanczos, tab.size() * sizeof(int16_t));
+            if (e == hipSuccess) e = hipMemcpy(c->d_lanczos, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
-            int rc = fail(GS360_ERR_HIP, "cubic table upload failed: %s", hipGetErrorString(e));
+            int rc = fail(GS360_ERR_HIP, "interpolation table upload failed: %s", hipGetErrorString(e));
             gs360_ctx_destroy(c);
             return rc;
         }
@@ -253,6 +293,7 @@ int gs360_ctx_destroy(gs360_ctx* c) {
         if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
     }
     if (c->d_cubic) (void)hipFree(c->d_cubic);
+    if (c->d_lanczos) (void)hipFree(c->d_lanczos);
     delete c;
     return GS360_OK;
 }
@@ -437,8 +478,9 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     if (H < 1 || W < 1 || H >= 32767 || W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", W, H);
     if (h < 0 || w < 0 || h >= 32767 || w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", w, h);
     if (h == 0 || w == 0) return GS360_OK;
-    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC)
-        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2)", interp);
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC &&
+        interp != GS360_INTERP_LANCZOS4)
+        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2, lanczos4=4)", interp);
     if (src_stride == 0) src_stride = (size_t)W * C;
     if (dst_stride == 0) dst_stride = (size_t)w * C;
     if (src_stride < (size_t)W * C || dst_stride < (size_t)w * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
@@ -451,7 +493,7 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     L.interp = interp;
     L.fill = fill_value < 0 ? 0 : (fill_value > 255 ? 255 : fill_value);
     for (int k = 0; k < 4; ++k) L.cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
-    L.cubic_tab = c->d_cubic;
+    L.cubic_tab = interp == GS360_INTERP_LANCZOS4 ? c->d_lanczos : c->d_cubic;
     L.pipelined = (W >= 8 && src_stride < ((size_t)1 << 24) && (uint64_t)src_stride * (uint64_t)H < ((uint64_t)1 << 32)) ? 1 : 0;
     HIP_TRY(launch_table(L, C, c->stream[slot]));
     return GS360_OK;
@@ -466,8 +508,9 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
     if (n_views < 0) return fail(GS360_ERR_ARG, "negative count");
     if (n_views == 0) return GS360_OK;
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
-    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC)
-        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2)", interp);
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC &&
+        interp != GS360_INTERP_LANCZOS4)
+        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2, lanczos4=4)", interp);
     for (int k = 0; k < n_views; ++k) {
         if (!src_lens[k] || !dst[k]) return fail(GS360_ERR_ARG, "NULL image pointer for view %d", k);
         if (calibs[k].width < 1 || calibs[k].height < 1 || calibs[k].width >= 32767 || calibs[k].height >= 32767)
@@ -502,7 +545,7 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
         L.src_stride = (int64_t)(src_stride ? src_stride : (size_t)calibs[v0].width * C);
         L.dst_stride = (int64_t)dst_stride;
         L.cval[0] = (uint8_t)mask_value;  // borderValue=float(mask_value) -> Scalar(v,0,0,0), DF:2007
-        L.cubic_tab = c->d_cubic;
+        L.cubic_tab = interp == GS360_INTERP_LANCZOS4 ? c->d_lanczos : c->d_cubic;
         L.pipelined = 1;
         for (int k = 0; k < nv; ++k)
             if (calibs[v0 + k].width < 8 || (uint64_t)L.src_stride * (uint64_t)calibs[v0 + k].height >= ((uint64_t)1 << 32)) L.pipelined = 0;

@@ -118,7 +118,8 @@ hipError_t launch_color(const ColorLaunch& L, int C, hipStream_t s);
 // kernel launchers (gs360_kernels.hip)
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s);
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);
-void build_cubic_table(int16_t* out);   // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated
+void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
+void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s);
 hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s);
 

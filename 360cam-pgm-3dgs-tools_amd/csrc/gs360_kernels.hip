@@ -590,6 +590,44 @@ __device__ __forceinline__ void cv_sample_cubic(const uint8_t* __restrict__ src,
     }
 }
 
+// remapLanczos4, BORDER_CONSTANT: 8x8 window at (ix-3, iy-3), same fixed-point scheme as the bicubic sampler with the
+// 32x32-phase x 64-entry int16 table (128 B per phase, one 16-byte read per window row).  Rarely selected
+// (`--interpolation lanczos4`, DF:229-234), so it is the straight-line form only.
+template <int C>
+__device__ __forceinline__ void cv_sample_lanczos4(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
+                                                   float mx, float my, const uint8_t (&cval)[4],
+                                                   const int16_t* __restrict__ tab, uint32_t (&out)[4]) {
+    int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
+    int fx = sx & 31, fy = sy & 31;
+    int x0 = sat_s16(sx >> 5) - 3, y0 = sat_s16(sy >> 5) - 3;
+    bool outside = x0 >= W || x0 + 8 <= 0 || y0 >= H || y0 + 8 <= 0;
+    const uint4* wq = reinterpret_cast<const uint4*>(tab + (fy * 32 + fx) * 64);
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll 2
+    for (int ky = 0; ky < 8; ++ky) {
+        const uint4 wr = wq[ky];
+        const uint32_t wpk[4] = {wr.x, wr.y, wr.z, wr.w};
+        int yy = y0 + ky;
+        bool yin = (unsigned)yy < (unsigned)H;
+        const uint8_t* row = src + (int64_t)min(max(yy, 0), H - 1) * stride;
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) {
+            int xx = x0 + kx;
+            bool in = yin && ((unsigned)xx < (unsigned)W);
+            const uint8_t* px = row + (int64_t)min(max(xx, 0), W - 1) * C;
+            uint32_t pk = wpk[kx >> 1];
+            int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += (int)(in ? (uint32_t)px[c] : (uint32_t)cval[c]) * w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        int r = (acc[c] + (1 << 14)) >> 15;
+        out[c] = outside ? (uint32_t)cval[c] : (uint32_t)min(max(r, 0), 255);
+    }
+}
+
 // Split bilinear fetch for cv2 semantics (same idea as eq_fetch): the two row reads are issued unconditionally from
 // a clamped, always-valid position so that a wavefront keeps all its gathers in flight; `fast` says the 2x2
 // footprint was fully inside the image and the wide read stayed in-row, otherwise the pixel is redone afterwards by
@@ -697,6 +735,7 @@ __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, i
         uint32_t px[4];
         if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
         else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
+        else if (L.interp == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
         else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
         if (L.valid && !L.valid[o]) {
 #pragma unroll
@@ -778,6 +817,7 @@ __global__ __launch_bounds__(256) void fe_views_kernel(const FeView V, const FeC
         for (int rr = 0; rr < kRowsPerWave; ++rr) {
             if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
             else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
+            else if (L.interp == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
             else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
         }
     }

@@ -16,6 +16,7 @@ LIB_PATH = pathlib.Path(os.environ.get("GS360_LIB", PKG_DIR / "lib" / "libgs360h
 INTERP_NEAREST = 0  # == cv2.INTER_NEAREST
 INTERP_LINEAR = 1   # == cv2.INTER_LINEAR
 INTERP_CUBIC = 2    # == cv2.INTER_CUBIC
+INTERP_LANCZOS4 = 4  # == cv2.INTER_LANCZOS4 (table remap / fused fisheye only)
 MAX_VIEWS = 16
 MAX_FRAMES = 16
 

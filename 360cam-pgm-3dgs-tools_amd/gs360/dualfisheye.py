@@ -18,8 +18,10 @@ INTERPOLATIONS = {"nearest": 0, "linear": 1, "cubic": 2, "lanczos4": 4}   # cv2.
 
 
 def engine_interpolation(flag: int) -> int:
-    """cv2 flag -> what the engine implements (nearest, linear, cubic); lanczos4 falls back to cubic."""
-    return flag if flag in (capi.INTERP_NEAREST, capi.INTERP_LINEAR, capi.INTERP_CUBIC) else capi.INTERP_CUBIC
+    """cv2 flag -> what the engine implements: all four of the tool's choices (nearest, linear, cubic, lanczos4)."""
+    if flag not in (capi.INTERP_NEAREST, capi.INTERP_LINEAR, capi.INTERP_CUBIC, capi.INTERP_LANCZOS4):
+        raise ValueError("unsupported interpolation flag {}".format(flag))
+    return flag
 
 
 class PairRenderer:

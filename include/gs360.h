@@ -44,10 +44,11 @@ typedef enum gs360_status {
     GS360_ERR_NOMEM = -5
 } gs360_status;
 
-/* values equal cv2.INTER_NEAREST / INTER_LINEAR / INTER_CUBIC (DF:59-64) */
+/* values equal cv2.INTER_NEAREST / INTER_LINEAR / INTER_CUBIC / INTER_LANCZOS4 (DF:59-64) */
 #define GS360_INTERP_NEAREST 0
 #define GS360_INTERP_LINEAR 1
 #define GS360_INTERP_CUBIC 2
+#define GS360_INTERP_LANCZOS4 4 /* table remap and fused fisheye only (8x8 taps) */
 
 /* limits of one batched launch (larger requests are split internally) */
 #define GS360_MAX_VIEWS 16

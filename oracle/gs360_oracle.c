@@ -118,35 +118,84 @@ static void cubic_coeffs(float x, float *c) {
     c[3] = 1.f - c[0] - c[1] - c[2];
 }
 
-static void cubic_init(void) {
-    if (g_cubic_ready) return;
-    float tab1[32][4];
-    for (int i = 0; i < 32; ++i) cubic_coeffs((float)i * (1.0f / 32.0f), tab1[i]);
+/* 2-D fixed-point table from a 1-D coefficient table (32 phases x ksize), with OpenCV's sum fix-up */
+static void build_tab2d(const float *tab1, int ks, int16_t *out) {
+    const int h = ks / 2;
     for (int i = 0; i < 32; ++i)
         for (int j = 0; j < 32; ++j) {
-            int16_t *it = g_cubic_tab + (i * 32 + j) * 16;
+            int16_t *it = out + (i * 32 + j) * ks * ks;
             int isum = 0;
-            for (int k1 = 0; k1 < 4; ++k1)
-                for (int k2 = 0; k2 < 4; ++k2) {
-                    float v = tab1[i][k1] * tab1[j][k2];
+            for (int k1 = 0; k1 < ks; ++k1)
+                for (int k2 = 0; k2 < ks; ++k2) {
+                    float v = tab1[i * ks + k1] * tab1[j * ks + k2];
                     long r = lrintf(v * 32768.0f);
                     r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
-                    it[k1 * 4 + k2] = (int16_t)r;
+                    it[k1 * ks + k2] = (int16_t)r;
                     isum += (int)r;
                 }
             if (isum != 32768) {
                 int diff = isum - 32768;
-                int Mk1 = 2, Mk2 = 2, mk1 = 2, mk2 = 2;
-                for (int k1 = 2; k1 < 4; ++k1)
-                    for (int k2 = 2; k2 < 4; ++k2) {
-                        if (it[k1 * 4 + k2] < it[mk1 * 4 + mk2]) { mk1 = k1; mk2 = k2; }
-                        else if (it[k1 * 4 + k2] > it[Mk1 * 4 + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                int Mk1 = h, Mk2 = h, mk1 = h, mk2 = h;
+                for (int k1 = h; k1 < h + 2; ++k1)
+                    for (int k2 = h; k2 < h + 2; ++k2) {
+                        if (it[k1 * ks + k2] < it[mk1 * ks + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (it[k1 * ks + k2] > it[Mk1 * ks + Mk2]) { Mk1 = k1; Mk2 = k2; }
                     }
-                if (diff < 0) it[Mk1 * 4 + Mk2] = (int16_t)(it[Mk1 * 4 + Mk2] - diff);
-                else it[mk1 * 4 + mk2] = (int16_t)(it[mk1 * 4 + mk2] - diff);
+                if (diff < 0) it[Mk1 * ks + Mk2] = (int16_t)(it[Mk1 * ks + Mk2] - diff);
+                else it[mk1 * ks + mk2] = (int16_t)(it[mk1 * ks + mk2] - diff);
             }
         }
+}
+
+static void cubic_init(void) {
+    if (g_cubic_ready) return;
+    float tab1[32 * 4];
+    for (int i = 0; i < 32; ++i) cubic_coeffs((float)i * (1.0f / 32.0f), tab1 + i * 4);
+    build_tab2d(tab1, 4, g_cubic_tab);
     g_cubic_ready = 1;
+}
+
+/*
+ * INTER_LANCZOS4 (OpenCV interpolateLanczos4 + the same 2-D table construction, ksize 8, taps ix-3 .. ix+4): the
+ * eight 1-D weights of phase x are sin(pi(x+3-i)/4)-based values computed in double from one sin/cos pair and the
+ * eighth-turn rotation table, divided by y^2, rounded to float, then normalised by their float sum; phase 0 is the
+ * unit impulse on tap 3.  RESTATED FROM MEMORY OF THE OPENCV SOURCE, parity unpinned.
+ */
+static int16_t g_lanczos_tab[32 * 32 * 64];
+static int g_lanczos_ready = 0;
+
+static void lanczos4_coeffs(float x, float *c) {
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-07f) { /* FLT_EPSILON */
+        for (int i = 0; i < 8; ++i) c[i] = 0.f;
+        c[3] = 1.f;
+        return;
+    }
+    float sum = 0.f;
+    double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; ++i) {
+        double y = -(x + 3 - i) * 3.1415926535897932384626433832795 * 0.25;
+        c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += c[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; ++i) c[i] *= sum;
+}
+
+static void lanczos_init(void) {
+    if (g_lanczos_ready) return;
+    float tab1[32 * 8];
+    for (int i = 0; i < 32; ++i) lanczos4_coeffs((float)i * (1.0f / 32.0f), tab1 + i * 8);
+    build_tab2d(tab1, 8, g_lanczos_tab);
+    g_lanczos_ready = 1;
+}
+
+/* copies the 32*32*64 int16 table (index (fy*32+fx)*64 + ky*8 + kx) */
+ORC_API int orc_lanczos4_table(int16_t *out) {
+    lanczos_init();
+    memcpy(out, g_lanczos_tab, sizeof(g_lanczos_tab));
+    return 0;
 }
 
 /* copies the 32*32*16 int16 table (index (fy*32+fx)*16 + ky*4 + kx) */
@@ -157,7 +206,7 @@ ORC_API int orc_cubic_table(int16_t *out) {
 }
 
 /*
- * interp: 0 = INTER_NEAREST, 1 = INTER_LINEAR, 2 = INTER_CUBIC.  border_val has 4 entries (cv::Scalar);
+ * interp: 0 = INTER_NEAREST, 1 = INTER_LINEAR, 2 = INTER_CUBIC, 4 = INTER_LANCZOS4.  border_val has 4 entries (cv::Scalar);
  * Python's borderValue=float(v) arrives as (v,0,0,0) -- channel c uses border_val[c & 3].
  * src: H x W x C interleaved u8, row stride src_stride bytes.  dst: h x w x C.
  */
@@ -167,8 +216,9 @@ ORC_API int orc_remap_u8(const uint8_t *src, int H, int W, int C, long src_strid
                          uint8_t *dst, long dst_stride, int n_threads) {
     if (!src || !map_x || !map_y || !dst || C < 1 || C > 4 || H < 1 || W < 1) return -1;
     if (H >= 32767 || W >= 32767) return -2; /* cv2.remap asserts on SHRT_MAX sizes */
-    if (interp != 0 && interp != 1 && interp != 2) return -3;
+    if (interp != 0 && interp != 1 && interp != 2 && interp != 4) return -3;
     if (interp == 2) cubic_init();
+    if (interp == 4) lanczos_init();
     uint8_t cval[4];
     for (int c = 0; c < 4; ++c) cval[c] = sat_u8_d(border_val ? border_val[c] : 0.0);
     int nt = pick_threads(n_threads);
@@ -191,21 +241,22 @@ ORC_API int orc_remap_u8(const uint8_t *src, int H, int W, int C, long src_strid
             int sx = cv_round_f(mx[x] * 32.0f), sy = cv_round_f(my[x] * 32.0f);
             int fx = sx & 31, fy = sy & 31;
             int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
-            if (interp == 2) { /* remapBicubic: 4x4 window starting at (ix-1, iy-1) */
-                int x0 = ix - 1, y0 = iy - 1;
-                if (x0 >= W || x0 + 4 <= 0 || y0 >= H || y0 + 4 <= 0) {
+            if (interp == 2 || interp == 4) { /* remapBicubic / remapLanczos4: ks x ks window at (ix-ks/2+1, iy-ks/2+1) */
+                const int ks = interp == 2 ? 4 : 8;
+                int x0 = ix - (ks / 2 - 1), y0 = iy - (ks / 2 - 1);
+                if (x0 >= W || x0 + ks <= 0 || y0 >= H || y0 + ks <= 0) {
                     for (int c = 0; c < C; ++c) d[c] = cval[c];
                     continue;
                 }
-                const int16_t *wt = g_cubic_tab + (fy * 32 + fx) * 16;
+                const int16_t *wt = (interp == 2 ? g_cubic_tab : g_lanczos_tab) + (fy * 32 + fx) * ks * ks;
                 for (int c = 0; c < C; ++c) {
                     int acc = 0;
-                    for (int ky = 0; ky < 4; ++ky)
-                        for (int kx = 0; kx < 4; ++kx) {
+                    for (int ky = 0; ky < ks; ++ky)
+                        for (int kx = 0; kx < ks; ++kx) {
                             int xx = x0 + kx, yy = y0 + ky;
                             int v = (xx >= 0 && xx < W && yy >= 0 && yy < H)
                                         ? src[(size_t)yy * src_stride + (size_t)xx * C + c] : cval[c];
-                            acc += v * wt[ky * 4 + kx];
+                            acc += v * wt[ky * ks + kx];
                         }
                     int r = (acc + (1 << 14)) >> 15;
                     d[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));

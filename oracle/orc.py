@@ -52,6 +52,7 @@ def lib():
         L.orc_equirect_views_u8_interp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(OrcView),
                                                    C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
         L.orc_cubic_table.argtypes = [C.c_void_p]
+        L.orc_lanczos4_table.argtypes = [C.c_void_p]
         L.orc_equirect_views_masked_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
                                                    C.POINTER(OrcView), C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
         L.orc_equirect_distinct_texels.argtypes = [C.POINTER(OrcView), C.c_int, C.c_int, C.c_void_p]
@@ -146,6 +147,13 @@ def cubic_table():
     t = np.zeros(32 * 32 * 16, np.int16)
     lib().orc_cubic_table(_ptr(t))
     return t.reshape(32, 32, 4, 4)
+
+
+def lanczos4_table():
+    """OpenCV's INTER_LANCZOS4 fixed-point table as restated by the oracle: int16 [fy][fx][ky][kx] (8x8 taps)."""
+    t = np.zeros(32 * 32 * 64, np.int16)
+    lib().orc_lanczos4_table(_ptr(t))
+    return t.reshape(32, 32, 8, 8)
 
 
 def equirect_views_u8(src, views, threads=1, interp=1, mask=None):

@@ -176,7 +176,7 @@ def _rand_maps(h, w, H, W, seed, spread=12.0):
 
 
 @pytest.mark.parametrize("channels", [1, 3, 4])
-@pytest.mark.parametrize("interp", [0, 1, 2])
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
 def test_table_remap_random_maps(ctx, orc, channels, interp):
     H, W, h, w = 97, 131, 75, 108
     src = rand_image(H, W, c=channels, seed=21)
@@ -227,7 +227,7 @@ def test_table_remap_fisheye_maps_from_oracle(ctx, orc):
 
 # ---- fused fisheye (FE-SPEC v1) ---------------------------------------------------------------
 @pytest.mark.parametrize("calib_kw,size", [(TEMPLATE_CALIB, 3840), (FULL_CALIB, None)])
-@pytest.mark.parametrize("interp", [0, 1, 2])
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
 def test_fisheye_fused_vs_oracle_spec(ctx, orc, calib_kw, size, interp):
     kw = dict(calib_kw)
     if size:  # shrink the template sensor 8x to keep the test light
@@ -341,13 +341,15 @@ def test_api_limits_are_reported_not_crashed(ctx):
     with pytest.raises(gs360.Gs360Error):
         ctx.remap(big_w, m, m)
     with pytest.raises(gs360.Gs360Error):
-        ctx.remap(rand_image(8, 8), m, m, interpolation=4)                        # lanczos4 is not implemented at the ABI
+        ctx.remap(rand_image(8, 8), m, m, interpolation=3)                        # INTER_AREA is not a remap mode
+    with pytest.raises(gs360.Gs360Error):
+        ctx.equirect_views(rand_image(8, 16), [gs360.View.make(0, 0, 90, 90, 8, 8)], interp=gs360.INTERP_LANCZOS4)
     with pytest.raises(gs360.Gs360Error):
         ctx.remap(rand_image(8, 8, c=1)[:, :, 0].reshape(8, 4, 2), m, m)          # 2 channels
     assert ctx.remap(rand_image(8, 8), np.zeros((0, 5), np.float32), np.zeros((0, 5), np.float32)).shape == (0, 5, 3)
     # 1x1 source, every interpolation: all taps are border or the single texel
     one = np.array([[[10, 20, 30]]], np.uint8)
     mm = np.array([[0.0, 0.5, -0.5, 3.0]], np.float32)
-    for interp in (0, 1, 2):
+    for interp in (0, 1, 2, 4):
         out = ctx.remap(one, mm, np.zeros_like(mm), interpolation=interp, border_value=(1, 2, 3, 4))
         assert out[0, 0].tolist() == [10, 20, 30] and out[0, 3].tolist() == [1, 2, 3]

@@ -174,3 +174,55 @@ def test_cubic_half_shift_known_answer_and_border(orc):
     assert int(orc.remap_u8(src, mx, my, interp=2)[0, 0, 0]) == want
     far = orc.remap_u8(src, np.array([[-3.0, 6.0, 2.0]], np.float32), np.array([[2.0, 2.0, 9.0]], np.float32), interp=2, border_value=77.0)
     assert far[0, :, 0].tolist() == [77, 77, 77]      # window fully outside: x0+4 <= 0, x0 >= W, y0 >= H
+
+
+# ---- INTER_LANCZOS4 (restated from the OpenCV source; parity unpinned, see oracle header) -------------------------
+def lanczos4_weights_f64(x):
+    """the defining formula: sinc(t)*sinc(t/4) on taps -3..4, normalised (float64, independent of the trig identity
+    the restatement uses)"""
+    t = x + 3 - np.arange(8)
+    w = np.sinc(t) * np.sinc(t / 4.0)
+    return w / w.sum()
+
+
+def test_lanczos4_table_properties(orc):
+    t = orc.lanczos4_table().astype(np.int64)
+    assert (t.reshape(1024, 64).sum(axis=1) == 32768).all()          # every phase kernel sums to 2^15 after the fix-up
+    assert t[0, 0, 3, 3] == 32767 and t[0, 0, 4, 4] == 1 and (t[0, 0] != 0).sum() == 2
+    for f in (1, 7, 16, 31):                                         # 1-D weights agree with the sinc definition
+        w = lanczos4_weights_f64(f / 32.0)
+        row = t[0, f, 3].astype(np.float64) / 32767.0                # fy = 0: the vertical impulse selects tap row 3
+        assert np.abs(row - w).max() < 2e-4, f
+    assert np.array_equal(t[16, 16], t[16, 16].T)
+    assert np.array_equal(t[5, 9], t[9, 5].T)
+
+
+def test_lanczos4_identity_constant_and_border(orc):
+    src = rand_image(23, 31)
+    xx, yy = grid(23, 31)
+    assert np.array_equal(orc.remap_u8(src, xx, yy, interp=4, border_value=(9, 9, 9, 9)), src)
+    const = np.full((20, 20, 3), 200, np.uint8)
+    rng = np.random.default_rng(3)
+    mx = rng.uniform(3.5, 14.5, (20, 20)).astype(np.float32)
+    my = rng.uniform(3.5, 14.5, (20, 20)).astype(np.float32)
+    assert (orc.remap_u8(const, mx, my, interp=4) == 200).all()       # kernels sum to exactly 2^15
+    far = orc.remap_u8(src, np.array([[-5.0, 34.0, 2.0, -4.5]], np.float32), np.array([[2.0, 2.0, 27.0, 2.0]], np.float32),
+                       interp=4, border_value=77.0)
+    assert far[0, :3, 0].tolist() == [77, 77, 77]     # window fully outside: x0+8 <= 0, x0 >= W, y0 >= H
+    assert far[0, 3, 0] == 77                          # ix = floor(-4.5) = -5: x0 + 8 = 0, still fully outside
+
+
+def test_lanczos4_known_answer_from_table(orc):
+    src = rand_image(16, 16, c=1)
+    mx = np.array([[7.25, 1.5]], np.float32)
+    my = np.array([[8.75, 0.25]], np.float32)
+    t = orc.lanczos4_table().astype(np.int64)
+    out = orc.remap_u8(src[:, :, 0], mx, my, interp=4, border_value=50.0)
+    win = src[8 - 3:8 + 5, 7 - 3:7 + 5, 0].astype(np.int64)
+    want = int(np.clip(((win * t[24, 8]).sum() + 16384) >> 15, 0, 255))
+    assert int(out[0, 0]) == want
+    pad = np.full((16 + 8, 16 + 8), 50, np.int64)                    # taps outside the image read the border constant
+    pad[4:20, 4:20] = src[:, :, 0]
+    win = pad[0 - 3 + 4:0 + 5 + 4, 1 - 3 + 4:1 + 5 + 4]
+    want = int(np.clip(((win * t[8, 16]).sum() + 16384) >> 15, 0, 255))
+    assert int(out[0, 1]) == want
