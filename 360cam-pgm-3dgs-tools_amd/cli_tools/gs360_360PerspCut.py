@@ -9,10 +9,11 @@ fov_from_focal_mm, v_fov_from_hfov.  Same flags, preset names, stdout lines, exi
 (reference cli_tools/gs360_360PerspCut.py:417-532, :983-1087).
 
 What changed underneath: run_one() no longer spawns one single-threaded `ffmpeg -vf v360=...` process per
-(source, view) (reference :569-590).  It parses the ffmpeg-shaped job argv and executes still-image
-equirect->rectilinear jobs in-process on the GPU through libgs360hip.so (hand-written HIP, gfx950).  Jobs the
-engine does not cover (video inputs, the fisheyeXY equisolid output) and `--engine ffmpeg` /
-GS360_ENGINE=ffmpeg keep the reference's subprocess path.
+(source, view) (reference :569-590).  It parses the ffmpeg-shaped job argv and executes equirect->rectilinear
+jobs in-process on the GPU through libgs360hip.so (hand-written HIP, gfx950).  Video inputs are decoded ONCE per
+video by a single ffmpeg process feeding device memory; every view job then samples the HBM-resident frames
+(gs360/video.py) instead of decoding the video again.  Jobs the engine does not cover (the fisheyeXY equisolid output,
+16-bit output) and `--engine ffmpeg` / GS360_ENGINE=ffmpeg keep the reference's subprocess path.
 """
 import argparse
 import json
@@ -221,22 +222,50 @@ def run_one(cmd: List[str]) -> Tuple[int, str]:
         job = parse_job_argv(list(cmd))
     except JobParseError as exc:
         return 2, f"gs360: cannot interpret job argv: {exc}"
-    if not job.is_still_image or job.output_projection != "rectilinear":
-        # video decode and the equisolid pair are outside the HIP engine's scope: reference path
-        return _run_subprocess(cmd)
+    if job.output_projection != "rectilinear":
+        return _run_subprocess(cmd)          # the equisolid pair (fisheyeXY) stays on the reference path
+    plan = None
+    if not job.is_still_image:
+        # video: one shared decoder process + HBM-resident frames (gs360/video.py); argv shapes it does not
+        # understand (16-bit output, foreign options) run as the reference's per-view subprocess
+        from gs360 import video as _video
+        plan = _video.build_decode_plan(job)
+        if plan is None:
+            return _run_subprocess(cmd)
     try:
         from gs360 import engine as _engine
-        _engine.get_engine().run_job(job)
-    except Exception as exc:  # noqa: BLE001  (boundary: HIP / IO errors become rc + text)
+        if plan is None:
+            _engine.get_engine().run_job(job)
+        else:
+            _engine.get_engine().run_video_job(job, plan, stop_event=stop_event, register_proc=_track_proc,
+                                               expected_jobs=_planned_video_jobs.get(str(job.src)))
+    except Exception as exc:  # noqa: BLE001  (boundary: HIP / IO / decoder errors become rc + text)
         return 1, f"gs360: {type(exc).__name__}: {exc}"
     if stop_event.is_set():
         return 130, ""
     return 0, ""
 
 
+_planned_video_jobs: dict = {}     # video path -> view jobs planned for it (lets the engine free a video's frames)
+
+
+def _track_proc(proc, add: bool) -> None:
+    """The shared video decoder is registered like the reference's per-view processes so a cancel reaches it."""
+    with procs_lock:
+        (running_procs.add if add else running_procs.discard)(proc)
+
+
 def build_view_jobs(args, files: List[pathlib.Path], out_dir: pathlib.Path) -> BuildResult:
     """Compose job definitions and view specifications (planning only, PC:593-980)."""
-    return _planner.build_view_jobs(args, files, out_dir, stop_event=stop_event)
+    result = _planner.build_view_jobs(args, files, out_dir, stop_event=stop_event)
+    if getattr(args, "input_is_video", False):
+        counts: dict = {}
+        for cmd, _src, _dst in result.jobs:
+            if "-i" in cmd:
+                key = str(pathlib.Path(cmd[cmd.index("-i") + 1]))
+                counts[key] = counts.get(key, 0) + 1
+        _planned_video_jobs.update(counts)
+    return result
 
 
 # ---- main (PC:983-1087) --------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ import zlib
 
 import numpy as np
 
-from . import capi, imageio
+from . import capi, imageio, video
 from .jobspec import JobSpec
 
 _FRAME_CACHE_BYTES = int(os.environ.get("GS360_FRAME_CACHE_MB", "4096")) << 20
@@ -52,8 +52,14 @@ class Engine:
         self.devices = list(devices) if devices is not None else list(range(n))
         self.states = [_DeviceState(d) for d in self.devices]
         self._warned_cubic = False
+        self.videos = {}                          # DecodePlan.key -> video.VideoSession
+        self.videos_lock = threading.Lock()
 
     def close(self):
+        with self.videos_lock:
+            sessions, self.videos = list(self.videos.values()), {}
+        for sess in sessions:
+            sess.close()
         for st in self.states:
             st.ctx.close()
         self.states = []
@@ -110,13 +116,7 @@ class Engine:
             entry[4] -= 1
 
     # -- one job ----------------------------------------------------------------------------------
-    def run_job(self, job: JobSpec):
-        """Execute one (frame, view) job; returns the output array after writing job.dst."""
-        if job.input_projection != "equirect" or job.output_projection != "rectilinear":
-            raise capi.Gs360Error(-4, f"v360 {job.input_projection}->{job.output_projection} is not implemented by "
-                                      "the HIP engine (only equirect->rectilinear); use --engine ffmpeg")
-        if abs(job.fnum("roll", 0.0)) > 1e-12:
-            raise capi.Gs360Error(-4, "roll != 0 is not implemented by the HIP engine")
+    def _interp_for(self, job: JobSpec) -> int:
         if job.interp in ("linear", "bilinear", "line"):
             interp = capi.INTERP_LINEAR
         elif job.interp in ("cubic", "bicubic"):
@@ -129,23 +129,73 @@ class Engine:
         interp_env = os.environ.get("GS360_INTERP")           # additive override: linear | cubic
         if interp_env in ("linear", "cubic"):
             interp = capi.INTERP_LINEAR if interp_env == "linear" else capi.INTERP_CUBIC
-        view = capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"),
-                              job.width, job.height)
+        return interp
+
+    def _view_for(self, job: JobSpec) -> capi.View:
+        if job.input_projection != "equirect" or job.output_projection != "rectilinear":
+            raise capi.Gs360Error(-4, f"v360 {job.input_projection}->{job.output_projection} is not implemented by "
+                                      "the HIP engine (only equirect->rectilinear); use --engine ffmpeg")
+        if abs(job.fnum("roll", 0.0)) > 1e-12:
+            raise capi.Gs360Error(-4, "roll != 0 is not implemented by the HIP engine")
+        return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"), job.width, job.height)
+
+    def _render(self, st: _DeviceState, buf, H, W, C, view, interp):
+        with st.lock:
+            slot = next(st.slot_cycle)
+        out_bytes = view.height * view.width * C
+        with st.ctx.slot_locks[slot]:
+            dst = st.out_buffer(slot, out_bytes)
+            st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp)
+            return st.ctx.download(dst, (view.height, view.width, C), slot=slot)
+
+    def run_job(self, job: JobSpec):
+        """Execute one (frame, view) job; returns the output array after writing job.dst."""
+        view = self._view_for(job)
+        interp = self._interp_for(job)
         st = self.states[self.device_for(job.src)]
         entry = self.resident_frame(st, job.src)
         try:
             buf, H, W, C = entry[:4]
-            with st.lock:
-                slot = next(st.slot_cycle)
-            out_bytes = view.height * view.width * C
-            with st.ctx.slot_locks[slot]:
-                dst = st.out_buffer(slot, out_bytes)
-                st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp)
-                out = st.ctx.download(dst, (view.height, view.width, C), slot=slot)
+            out = self._render(st, buf, H, W, C, view, interp)
         finally:
             self.release_frame(st, entry)
         imageio.write_image(job.dst, out, jpeg_q=job.jpeg_q)
         return out
+
+    # -- video: one decode, frames resident in HBM, every view job walks them (gs360/video.py) -------------------
+    def _video_session(self, plan, stop_event, register_proc):
+        with self.videos_lock:
+            sess = self.videos.get(plan.key)
+            if sess is None:
+                for key in [k for k, s in self.videos.items() if s.active_jobs == 0 and s.finished]:
+                    self.videos.pop(key).close()          # idle sessions of other videos give their memory back
+                sess = self.videos[plan.key] = video.VideoSession(self.states, plan, stop_event, register_proc)
+            sess.active_jobs += 1
+            return sess
+
+    def run_video_job(self, job: JobSpec, plan, stop_event=None, register_proc=None, expected_jobs=None) -> int:
+        """All frames of one view of a video; returns the number of frames written."""
+        view = self._view_for(job)
+        interp = self._interp_for(job)
+        sess = self._video_session(plan, stop_event, register_proc)
+        written = 0
+        try:
+            while True:
+                fr = sess.frame(written)
+                if fr is None:
+                    break
+                st, buf, H, W = fr
+                out = self._render(st, buf, H, W, 3, view, interp)
+                imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)
+                written += 1
+        finally:
+            with self.videos_lock:
+                sess.active_jobs -= 1
+                sess.done_jobs += 1
+                if expected_jobs and sess.done_jobs >= expected_jobs and sess.active_jobs == 0:
+                    self.videos.pop(plan.key, None)
+                    sess.close()
+        return written
 
 
 _engine = None

@@ -25,6 +25,9 @@ class JobSpec:
     filters: List[str] = field(default_factory=list)     # the other filters of the -vf chain, in order
     options: Dict[str, str] = field(default_factory=dict)  # remaining "-key value" pairs
     flags: List[str] = field(default_factory=list)
+    filters_after: List[str] = field(default_factory=list)    # the members of `filters` that follow v360 in the chain
+    input_options: List[str] = field(default_factory=list)    # "-key", "value" tokens that precede -i (order kept)
+    output_options: List[str] = field(default_factory=list)   # "-key", "value" tokens that follow -i (except -vf)
 
     # ---- v360 parameters ------------------------------------------------------------------------
     @property
@@ -108,6 +111,8 @@ def parse_job_argv(argv: List[str]) -> JobSpec:
     chain = None
     options: Dict[str, str] = {}
     flags: List[str] = []
+    before_i: List[str] = []
+    after_i: List[str] = []
     i = 0
     while i < len(body):
         tok = body[i]
@@ -124,6 +129,7 @@ def parse_job_argv(argv: List[str]) -> JobSpec:
             chain = val
         else:
             options[tok] = val
+            (before_i if src is None else after_i).extend([tok, val])
         i += 2
     if src is None:
         raise JobParseError("job argv has no -i <input>")
@@ -131,6 +137,7 @@ def parse_job_argv(argv: List[str]) -> JobSpec:
         raise JobParseError("job argv has no -vf filter chain")
     v360: Optional[Dict[str, str]] = None
     others: List[str] = []
+    after: List[str] = []
     for flt in split_filter_chain(chain):
         if flt.startswith("v360="):
             if v360 is not None:
@@ -143,6 +150,8 @@ def parse_job_argv(argv: List[str]) -> JobSpec:
                 v360[k] = v
         else:
             others.append(flt)
+            if v360 is not None:
+                after.append(flt)
     if v360 is None:
         raise JobParseError("filter chain has no v360 filter")
-    return JobSpec(program, pathlib.Path(src), pathlib.Path(dst), v360, others, options, flags)
+    return JobSpec(program, pathlib.Path(src), pathlib.Path(dst), v360, others, options, flags, after, before_i, after_i)

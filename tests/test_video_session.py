@@ -1,0 +1,184 @@
+"""Video inputs: one shared decode, HBM-resident frames (gs360/video.py).
+
+CPU: the decoder command derived from the planner's / the GUI's job argv, and the PPM stream reader.
+GPU: the whole path with a test double standing in for the ffmpeg binary (tests/fake_ffmpeg.py): clip -> PPM pipe ->
+device frames -> HIP views -> numbered files, compared with the oracle frame by frame."""
+import argparse
+import io
+import os
+import pathlib
+import stat
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gs360 import imageio, planner, video
+from gs360.jobspec import parse_job_argv
+from util import HFOV_12MM
+
+FAKE = ROOT / "tests" / "fake_ffmpeg.py"
+
+
+def plan_jobs(tmp_path, extra, ffmpeg="ffmpeg", name="clip.mp4"):
+    import gs360_360PerspCut as cut
+    args = cut.create_arg_parser().parse_args(["-i", str(tmp_path / name), "--ffmpeg", ffmpeg] + extra)
+    for attr in ("size", "hfov", "focal_mm"):
+        setattr(args, f"{attr}_explicit", getattr(args, f"{attr}_explicit", False))
+    args.input_is_video, args.video_bit_depth = True, 8
+    return cut.build_view_jobs(args, [tmp_path / name], tmp_path / "out")
+
+
+def gui_select_rewrite(cmd, indices):
+    """what gs360_GUI.py:19081-19148 does to a planned argv for a CSV frame selection (restated for the test)"""
+    cmd = list(cmd)
+    seek = []
+    for flag in ("-ss", "-to"):
+        while flag in cmd:
+            i = cmd.index(flag)
+            cmd.pop(i)
+            seek += [flag, cmd.pop(i)]
+    v = cmd.index("-vf") + 1
+    parts = [p for p in cmd[v].split(",") if not p.strip().startswith("fps=")]
+    cmd[v] = ",".join(["select='" + "+".join(f"eq(n\\,{i})" for i in indices) + "'"] + parts)
+    cmd[-1:-1] = ["-frame_pts", "1"]
+    while "-start_number" in cmd:
+        i = cmd.index("-start_number")
+        del cmd[i:i + 2]
+    cmd.insert(1, "-copyts")
+    i = cmd.index("-i") + 2
+    cmd[i:i] = seek
+    return cmd
+
+
+def test_decode_plan_from_planner_argv(tmp_path):
+    res = plan_jobs(tmp_path, ["-f", "2", "--ext", "png", "--start", "3", "--end", "12.5", "--count", "4"])
+    plans = [video.build_decode_plan(parse_job_argv(cmd)) for cmd, _s, _d in res.jobs]
+    assert all(p is not None for p in plans) and len({p.key for p in plans}) == 1      # every view shares one decode
+    p = plans[0]
+    src = str(tmp_path / "clip.mp4")
+    assert list(p.argv) == ["ffmpeg", "-hide_banner", "-loglevel", "error", "-nostdin", "-ss", "3.0", "-i", src, "-to", "12.5",
+                            "-vsync", "vfr", "-vf", "fps=2.0,colorspace=iall=bt709:all=smpte170m:trc=iec61966-2-1:format=yuv444p,format=rgb24",
+                            "-an", "-f", "image2pipe", "-c:v", "ppm", "pipe:1"]
+    assert p.numbers is None and p.start_number == 0
+    job = parse_job_argv(res.jobs[1][0])
+    assert video.output_path(job, p, 0).endswith("clip_0000000_B.png") and video.output_path(job, p, 41).endswith("clip_0000041_B.png")
+
+
+def test_decode_plan_jpeg_and_gui_selection(tmp_path):
+    res = plan_jobs(tmp_path, ["-f", "1", "--count", "2"])                    # jpg output: mjpeg/yuvj444p encoder options
+    cmd = res.jobs[0][0]
+    p = video.build_decode_plan(parse_job_argv(cmd))
+    assert p is not None and "range=jpeg:format=yuv444p,format=rgb24" in p.argv[p.argv.index("-vf") + 1]
+    assert "-q:v" not in p.argv and "-c:v" in p.argv and p.argv[p.argv.index("-c:v") + 1] == "ppm"
+    sel = gui_select_rewrite(cmd, [40, 7, 19])
+    job = parse_job_argv(sel)
+    q = video.build_decode_plan(job)
+    assert q is not None and q.numbers == (7, 19, 40) and q.key != p.key
+    assert q.argv[5] == "-copyts" and "fps=" not in q.argv[q.argv.index("-vf") + 1]
+    assert q.argv[q.argv.index("-vf") + 1].startswith("select='eq(n\\,40)+eq(n\\,7)+eq(n\\,19)',colorspace=")
+    assert [pathlib.Path(video.output_path(job, q, k)).name for k in range(3)] == ["clip_0000007_A.jpg", "clip_0000019_A.jpg", "clip_0000040_A.jpg"]
+
+
+def test_decode_plan_refuses_what_it_does_not_understand(tmp_path):
+    cmd = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "2"]).jobs[0][0]
+    assert video.build_decode_plan(parse_job_argv(cmd)) is not None
+
+    def mutate(fn):
+        c = list(cmd)
+        fn(c)
+        return video.build_decode_plan(parse_job_argv(c))
+    assert mutate(lambda c: c.__setitem__(c.index("-pix_fmt") + 1, "rgb48le")) is None          # 16-bit output
+    assert mutate(lambda c: c.__setitem__(c.index("-vf") + 1, c[c.index("-vf") + 1] + ",hflip")) is None   # filter after v360
+    assert mutate(lambda c: c.__setitem__(slice(-1, -1), ["-metadata", "x=y"])) is None          # foreign option
+    assert mutate(lambda c: c.__setitem__(slice(-1, -1), ["-frame_pts", "1"])) is None           # pts numbering without a select list
+    assert mutate(lambda c: c.__setitem__(c.index("-vf") + 1, "select='gt(scene\\,0.4)'," + c[c.index("-vf") + 1])) is None
+    still = ["ffmpeg", "-y", "-i", "a.png", "-vf", "v360=input=equirect:output=rectilinear:w=8:h=8:yaw=0:pitch=0:roll=0:h_fov=90:v_fov=90:interp=cubic", "o.png"]
+    assert video.build_decode_plan(parse_job_argv(still)) is None
+
+
+def test_ppm_stream_reader():
+    fr = np.arange(2 * 3 * 3, dtype=np.uint8)
+    data = b"P6\n# made by a test\n3 2\n255\n" + fr.tobytes() + b"P6 3 2 255\n" + fr[::-1].tobytes()
+    s = io.BufferedReader(io.BytesIO(data))
+    for want in (fr, fr[::-1]):
+        assert video.read_ppm_header(s) == (3, 2, 255)
+        buf = bytearray(18)
+        video.read_exact_into(s, memoryview(buf))
+        assert bytes(buf) == want.tobytes()
+    assert video.read_ppm_header(s) is None
+    with pytest.raises(video.PpmError):
+        video.read_ppm_header(io.BufferedReader(io.BytesIO(b"P5\n3 2\n255\n")))
+    with pytest.raises(video.PpmError):
+        video.read_ppm_header(io.BufferedReader(io.BytesIO(b"P6\n3 ")))
+    with pytest.raises(video.PpmError):
+        video.read_exact_into(io.BufferedReader(io.BytesIO(b"abc")), memoryview(bytearray(5)))
+
+
+# ---- GPU, with the decoder test double ---------------------------------------------------------------------------
+def fake_ffmpeg_program(tmp_path):
+    p = tmp_path / "ffmpeg_double"
+    p.write_text("#!/bin/sh\nexec {} {} \"$@\"\n".format(sys.executable, FAKE))
+    p.chmod(p.stat().st_mode | stat.S_IXUSR)
+    return str(p)
+
+
+def make_clip(path, n=6, h=64, w=128):
+    rng = np.random.default_rng(31)
+    clip = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    np.save(path, clip)
+    return clip
+
+
+@pytest.mark.gpu
+def test_video_views_through_shared_decode(tmp_path, orc):
+    import gs360_360PerspCut as cut
+    from gs360 import engine
+    clip = make_clip(tmp_path / "clip.npy")
+    res = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "3", "--size", "40", "--start", "1"],
+                    ffmpeg=fake_ffmpeg_program(tmp_path), name="clip.npy")
+    (tmp_path / "out").mkdir()
+    cut.stop_event.clear()
+    os.environ["GS360_INTERP"] = "linear"
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            results = list(pool.map(cut.run_one, [cmd for cmd, _s, _d in res.jobs]))
+    finally:
+        os.environ.pop("GS360_INTERP")
+    assert results == [(0, "")] * 3, results
+    eng = engine.get_engine()
+    assert not eng.videos                                   # all planned view jobs done -> frames released
+    for k, (y, tag) in enumerate(((0.0, "A"), (120.0, "B"), (-120.0, "C"))):
+        for n in range(5):                                  # frames 1..5 of the clip, numbered from 0
+            got = imageio.read_image(tmp_path / "out" / f"clip_{n:07d}_{tag}.png")
+            want = orc.equirect_views_u8(clip[n + 1], [orc.make_view(y, 0.0, HFOV_12MM, HFOV_12MM, 40, 40)])[0]
+            assert np.array_equal(got, want), (tag, n)
+    assert not (tmp_path / "out" / "clip_0000005_A.png").exists()
+
+
+@pytest.mark.gpu
+def test_video_gui_selection_numbering_and_decoder_failure(tmp_path, orc):
+    import gs360_360PerspCut as cut
+    clip = make_clip(tmp_path / "clip.npy")
+    prog = fake_ffmpeg_program(tmp_path)
+    res = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "2", "--size", "32"], ffmpeg=prog, name="clip.npy")
+    (tmp_path / "out").mkdir()
+    cut.stop_event.clear()
+    cmd = gui_select_rewrite(res.jobs[1][0], [4, 0, 2])
+    assert cut.run_one(cmd) == (0, "")
+    names = sorted(p.name for p in (tmp_path / "out").glob("*.png"))
+    assert names == ["clip_0000000_B.png", "clip_0000002_B.png", "clip_0000004_B.png"]
+    got = imageio.read_image(tmp_path / "out" / "clip_0000004_B.png")
+    want = orc.equirect_views_u8(clip[4], [orc.make_view(180.0, 0.0, HFOV_12MM, HFOV_12MM, 32, 32)], interp=2)[0]
+    assert np.array_equal(got, want)
+    np.save(tmp_path / "broken.npy", clip[:1])
+    bad = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "2"], ffmpeg=prog, name="broken.npy").jobs[0][0]
+    rc, text = cut.run_one(bad)
+    assert rc == 1 and "decoder exited with code 1" in text and "cannot open input" in text
+    # a 16-bit request is not the engine's: it goes to the per-view subprocess, which the double refuses (rc 3)
+    deep = list(res.jobs[0][0])
+    deep[deep.index("-pix_fmt") + 1] = "rgb48le"
+    rc, text = cut.run_one(deep)
+    assert rc == 3 and "only the PPM pipe decoder role" in text
