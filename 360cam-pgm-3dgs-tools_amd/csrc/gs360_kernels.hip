@@ -52,6 +52,11 @@ __device__ __forceinline__ uint2 ld_u64_via_aligned96(const uint8_t* p) {
     return v;
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#ifndef GS360_PAIRED_FETCH
+#define GS360_PAIRED_FETCH 1
+#endif
+
 // bilinear blend of one channel, weights a0+a1 = 32, b0+b1 = 32  ->  (sum + 512) >> 10
 __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s10, uint32_t s11,
                                           uint32_t w00, uint32_t w01, uint32_t w10, uint32_t w11) {
@@ -166,8 +171,31 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
         t.t0 = make_uint2(a, 0);
         t.t1 = make_uint2(b, 0);
     } else if constexpr (C == 3) {
+#if GS360_PAIRED_FETCH
+        // Row-paired gathers.  Issued naively, one instruction reads row y0 of all 64 pixels and the next one row y1;
+        // where the view bends across source rows, row Y is "y0" for one run of lanes and "y1" for the neighbouring
+        // run, so the second instruction asks for lines the first one has just missed on and the L1 stalls on the
+        // pending fill.  Here lanes 0-31 of the first instruction read row y0 and lanes 32-63 row y1 of the SAME 32
+        // pixels (second instruction: the other 32 pixels), so both uses of a line meet in one instruction and are
+        // merged by the address coalescer.  v_permlane32_swap (gfx950) builds the two address vectors from (o0, o1)
+        // in one operation and puts the returned dwords back in pixel order.
+        const uint32_t s0 = o0 & 3u, s1 = o1 & 3u;
+        const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0 & ~3u, o1 & ~3u, false, false);
+        const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
+        const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
+        const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2];
+        const uint32_t b0 = qb[0], b1 = qb[1], b2 = qb[2];
+        const u32x2 d0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);   // .x = row y0, .y = row y1, own pixel
+        const u32x2 d1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x2 d2 = __builtin_amdgcn_permlane32_swap(a2, b2, false, false);
+        t.t0.x = __builtin_amdgcn_alignbyte(d1.x, d0.x, s0);
+        t.t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, s0);
+        t.t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, s1);
+        t.t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, s1);
+#else
         t.t0 = ld_u64_via_aligned96(r0);
         t.t1 = ld_u64_via_aligned96(r1);
+#endif
     } else {
         t.t0 = ld_u64(r0);
         t.t1 = ld_u64(r1);
@@ -391,7 +419,7 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 // more resident wavefronts their gathers evict each other's lines from the 32 KiB vector L1 (6 blocks/CU: 24.3 us per
 // frame, 4: 23.1, 3: 27.4, 1: 45.5).
 template <int C, bool CUBIC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void eq_views_kernel(const EqLaunch L) {
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void eq_views_kernel(const EqLaunch L) {
     // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk)
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
@@ -679,7 +707,7 @@ __device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
+__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
     int b = blockIdx.x;
     int t = (b & 7) * chunk + (b >> 3);
     if (t >= total_tiles) return;
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(256) void table_remap_kernel(const TableLaunch L, i
 // array of these 148-byte blocks dynamically made the compiler spill the whole argument struct to scratch
 // (2368 B/lane, 13x slower), so the host loops over views instead.
 template <int C>
-__global__ __launch_bounds__(256) void fe_views_kernel(const FeView V, const FeCommon L) {
+__global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeView V, const FeCommon L) {
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
     if (t >= L.total_tiles) return;
@@ -838,7 +866,7 @@ __global__ __launch_bounds__(256) void fe_views_kernel(const FeView V, const FeC
 // launchers
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
-    dim3 grid((unsigned)(L.chunk * 8)), block(256);
+    dim3 grid((unsigned)(L.chunk * 8)), block(64 * kWaves);
     switch (C) {
         case 1: hipLaunchKernelGGL((eq_views_kernel<1, false>), grid, block, 0, s, L); break;
         case 3: hipLaunchKernelGGL((eq_views_kernel<3, false>), grid, block, 0, s, L); break;
@@ -849,7 +877,7 @@ hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
 }
 
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
-    dim3 grid((unsigned)(L.chunk * 8)), block(256);
+    dim3 grid((unsigned)(L.chunk * 8)), block(64 * kWaves);
     switch (C) {
         case 1: hipLaunchKernelGGL((eq_views_kernel<1, true>), grid, block, 0, s, L); break;
         case 3: hipLaunchKernelGGL((eq_views_kernel<3, true>), grid, block, 0, s, L); break;
@@ -862,7 +890,7 @@ hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
     int tiles_x = (L.w + kTileW - 1) / kTileW, tiles_y = (L.h + kTileH - 1) / kTileH;
     int total = tiles_x * tiles_y, chunk = (total + 7) / 8;
-    dim3 grid((unsigned)(chunk * 8)), block(256);
+    dim3 grid((unsigned)(chunk * 8)), block(64 * kWaves);
     switch (C) {
         case 1: hipLaunchKernelGGL(table_remap_kernel<1>, grid, block, 0, s, L, tiles_x, total, chunk); break;
         case 3: hipLaunchKernelGGL(table_remap_kernel<3>, grid, block, 0, s, L, tiles_x, total, chunk); break;
@@ -882,7 +910,7 @@ hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s) {
         for (int i = 0; i < 4; ++i) K.cval[i] = L.cval[i];
         K.cubic_tab = L.cubic_tab;
         K.pipelined = L.pipelined;
-        dim3 grid((unsigned)(K.chunk * 8)), block(256);
+        dim3 grid((unsigned)(K.chunk * 8)), block(64 * kWaves);
         switch (C) {
             case 1: hipLaunchKernelGGL(fe_views_kernel<1>, grid, block, 0, s, L.view[k], K); break;
             case 3: hipLaunchKernelGGL(fe_views_kernel<3>, grid, block, 0, s, L.view[k], K); break;
