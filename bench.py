@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct HBM-resident frames per step (one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-over-ranks (gloo: control-flow tests on a box "
+                         "with fewer GPUs than ranks; ranks then share devices round-robin)")
     ap.add_argument("--stride-pad", type=int, default=0, help="experiments only: extra bytes per source row")
     ap.add_argument("--src-width", type=int, default=7680, help="experiments only: equirect width (height = width/2); "
                     "any value other than 7680 is NOT the BASELINE workload and is labelled as such")
@@ -123,6 +126,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        n_dev = max(1, torch.cuda.device_count())
+        if args.backend == "gloo":
+            local_rank %= n_dev
         torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on stdout when the first communicator comes up; stdout must carry exactly one
         # JSON line, so fd 1 points at stderr while the group is created and warmed up.
@@ -130,8 +136,11 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -179,7 +188,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ctx.event_elapsed_ms(0, 0, 1) / max(1, args.steps)   # HIP events on the launch stream
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -187,7 +196,12 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu, want = cpu_baseline(np, frames_host[0])
+        if world == 1:
+            cpu, want = cpu_baseline(np, frames_host[0])
+        else:   # the timed CPU sample is an N=1 item; at N>1 rank 0 only checks what it rendered (one oracle pass)
+            from oracle import orc
+            orc.build()
+            want = orc.equirect_views_u8(frames_host[0], [orc.make_view(*v) for v in view_table()], threads=0)
         got = [ctx.download(d_out[k], (SIZE, SIZE, C)) for k in range(N_VIEWS)]
         parity = all(np.array_equal(g, w) for g, w in zip(got, want))
         if not parity:
