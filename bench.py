@@ -235,6 +235,8 @@ def main():
                        "parity_vs_oracle": parity},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         # same launch time against the bytes the PMC counters saw move (whole 128-B lines), for context
+                         "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                          "kernel": "eq_views_kernel<3>", "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu,
