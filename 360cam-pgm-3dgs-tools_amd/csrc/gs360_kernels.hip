@@ -256,12 +256,12 @@ struct EqCubicTaps {
     bool fix;
 };
 
-__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const uint8_t* __restrict__ src, int sx, int sy) {
+__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy) {
     const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
     EqCubicTaps t;
     const int x0 = min(max(ix - 1, 0), L.W - 6);            // 16-byte aligned read of 12 tap bytes stays in-row
     t.fix = (x0 != ix - 1);
-    const uint4* wq = reinterpret_cast<const uint4*>(L.cubic_tab + (fy * 32 + fx) * 16);
+    const uint4* wq = reinterpret_cast<const uint4*>(wtab + (fy * 32 + fx) * 16);
     t.wa = wq[0];
     t.wb = wq[1];
     const uint32_t col = (uint32_t)x0 * 3u;
@@ -300,9 +300,9 @@ __device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, uint32_t (&
 
 // generic cubic sample: columns wrap, rows clamp (any channel count; also the repair path of the RGB fast path)
 template <int C>
-__device__ __forceinline__ void eq_cubic_slow(const EqLaunch& L, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
+__device__ __forceinline__ void eq_cubic_slow(const EqLaunch& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
     const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
-    const uint4* wq = reinterpret_cast<const uint4*>(L.cubic_tab + (fy * 32 + fx) * 16);
+    const uint4* wq = reinterpret_cast<const uint4*>(wtab + (fy * 32 + fx) * 16);
     const uint4 wa = wq[0], wb = wq[1];
     const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
     int cols[4];
@@ -344,25 +344,26 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
                                         uint8_t* dst, int64_t dstride,
                                         const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
                                         const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
-                                        int col0, int n_px, bool reversed, bool aligned4, bool skip_first) {
+                                        int col0, int n_px, bool reversed, bool aligned4, bool skip_first,
+                                        const int16_t* wtab) {
     if constexpr (CUBIC) {
         uint32_t px[kRowsPerWave][4];
         if constexpr (C == 3) {
             // two row slots at a time: 8 tap reads + 4 weight reads in flight, 24 tap dwords live
 #pragma unroll
             for (int s0 = 0; s0 < kRowsPerWave; s0 += 2) {
-                EqCubicTaps ta = eq_cubic_fetch(L, src, sxs[s0], sys[s0]);
-                EqCubicTaps tb = eq_cubic_fetch(L, src, sxs[s0 + 1], sys[s0 + 1]);
+                EqCubicTaps ta = eq_cubic_fetch(L, wtab, src, sxs[s0], sys[s0]);
+                EqCubicTaps tb = eq_cubic_fetch(L, wtab, src, sxs[s0 + 1], sys[s0 + 1]);
                 eq_cubic_blend(ta, px[s0]);
                 eq_cubic_blend(tb, px[s0 + 1]);
                 if (__any(ta.fix | tb.fix)) {
-                    if (ta.fix) eq_cubic_slow<C>(L, src, sxs[s0], sys[s0], px[s0]);
-                    if (tb.fix) eq_cubic_slow<C>(L, src, sxs[s0 + 1], sys[s0 + 1], px[s0 + 1]);
+                    if (ta.fix) eq_cubic_slow<C>(L, wtab, src, sxs[s0], sys[s0], px[s0]);
+                    if (tb.fix) eq_cubic_slow<C>(L, wtab, src, sxs[s0 + 1], sys[s0 + 1], px[s0 + 1]);
                 }
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < kRowsPerWave; ++s) eq_cubic_slow<C>(L, src, sxs[s], sys[s], px[s]);
+            for (int s = 0; s < kRowsPerWave; ++s) eq_cubic_slow<C>(L, wtab, src, sxs[s], sys[s], px[s]);
         }
         if (mask) {                                       // wave-uniform
 #pragma unroll
@@ -424,6 +425,16 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
     if (t >= L.total_tiles) return;
+    // cubic: the 32 KiB weight table would otherwise occupy the whole vector L1 and every lane reads a different
+    // 32-byte entry of it; one coalesced copy per workgroup into LDS keeps the L1 for source lines
+    __shared__ __attribute__((aligned(16))) int16_t s_wtab[CUBIC ? 32 * 32 * 16 : 8];
+    if constexpr (CUBIC) {
+        const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
+        uint4* l = reinterpret_cast<uint4*>(s_wtab);
+#pragma unroll
+        for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+        __syncthreads();
+    }
     int f = t / L.tiles_per_frame;
     int r = t - f * L.tiles_per_frame;
     int k = 0;
@@ -504,14 +515,14 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     }
 
     // ---- left half, then the mirrored half ---------------------------------------------------------
-    eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false);
+    eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false, s_wtab);
     // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
     // centre column is its own mirror and was already written: drop it from the segment.
     const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
     if (n_px > (centre_dup ? 1 : 0)) {
         const int col0 = V.out_w - x0 - n_px;
         const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
-        eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup);
+        eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab);
     }
 }
 

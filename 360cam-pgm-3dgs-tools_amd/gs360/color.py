@@ -156,16 +156,15 @@ class ColorStage:
         self.space = normalize_lut_output_color_space(output_space)
         self.level_pos = level_positions(lut)
         self.thresholds = output_thresholds(self.space)
-        self._plans: Dict[int, tuple] = {}
+        self._plans: Dict[object, object] = {}      # Context -> plan handle (the key keeps the context object alive)
         self._lock = threading.Lock()
 
     def _plan(self, ctx):
         with self._lock:
-            entry = self._plans.get(id(ctx))
-            if entry is None:
-                entry = (ctx, ctx.color_plan(self.lut.table, self.level_pos, self.thresholds))
-                self._plans[id(ctx)] = entry
-            return entry[1]
+            plan = self._plans.get(ctx)
+            if plan is None:
+                plan = self._plans[ctx] = ctx.color_plan(self.lut.table, self.level_pos, self.thresholds)
+            return plan
 
     @staticmethod
     def check_image(shape, dtype) -> None:
@@ -195,7 +194,7 @@ class ColorStage:
 
     def close(self) -> None:
         with self._lock:
-            for ctx, plan in self._plans.values():
+            for ctx, plan in self._plans.items():
                 if ctx.handle:
                     ctx.color_plan_free(plan)
             self._plans.clear()
