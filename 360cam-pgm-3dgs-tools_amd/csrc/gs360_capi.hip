@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -97,6 +98,19 @@ void make_eq_view(const gs360_view& v, int W, EqView* o) {
     o->out_h = v.height;
     // The kernel computes the left half of every row and mirrors it; level views also mirror top/bottom.
     o->level = (o->sp == 0.0f && o->cp == 1.0f) ? 1 : 0;
+#ifdef GS360_FORCE_GENERAL   // probe builds: every view takes the general (non-level) path
+    o->level = 0;
+#endif
+    // Lane map (gs360_kernels.hip): source pixels stepped per output pixel at the view centre.  Above ~3 the view
+    // bends across so many source rows per 64-pixel output row that compact 4x16 gather patches touch fewer cache
+    // lines (cfg2: 4.6 -> blocked, -3 %); below it full rows coalesce better and need less arithmetic (cfg1 1.7,
+    // cfg3 2.0, cfg5 1.25: blocked would cost 7-19 %).  GS360_LANEMAP=rows|blocked overrides (tests, probes).
+    const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)v.width;
+    o->blocked = step >= 3.0 ? 1 : 0;
+    if (const char* e = std::getenv("GS360_LANEMAP")) {
+        if (!std::strcmp(e, "rows")) o->blocked = 0;
+        else if (!std::strcmp(e, "blocked")) o->blocked = 1;
+    }
     const int half_w = (v.width + 1) / 2;
     o->tiles_x = (half_w + kTileW - 1) / kTileW;
     o->tiles_y = o->level ? ((v.height + 1) / 2 + kTileH / 2 - 1) / (kTileH / 2) : (v.height + kTileH - 1) / kTileH;

@@ -13,7 +13,10 @@
 // issues ALL tap reads with no control flow in between (dword-aligned 12-byte reads + v_alignbyte: the texture-address
 // path merges aligned lane accesses into line requests, misaligned ones are looked up lane by lane), then blends.
 // Each lane packs its RGB result into a dword and the row is written as whole dwords after a two-shuffle
-// (ds_bpermute) repack, i.e. 192 contiguous bytes per wavefront row.  Tiles are numbered row-major per
+// (ds_bpermute) repack, i.e. 192 contiguous bytes per wavefront row.  For strongly minified RGB views the equirect
+// kernel switches (per view, host decision) to a BLOCKED lane map: every gather covers a 4-row x 16-column patch,
+// which touches about half the cache lines where a view row bends across many source rows; results are then
+// transposed through LDS into row-segment stores (store_patch_rgb).  Tiles are numbered row-major per
 // view and handed to XCDs in contiguous chunks (block b runs on XCD b % 8) so that neighbouring tiles --
 // which share source cache lines -- hit the same per-XCD L2.  DESIGN.md section 5 has the measurements behind
 // each of these choices.
@@ -98,6 +101,70 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
     if (lane < n_px && !(skip_first && pos == 0))
         for (int c = 0; c < C; ++c) row[pos * C + c] = (uint8_t)px[c];
 }
+
+// Store for the blocked lane map (RGB).  A wavefront holds a patch of 4 rows x (16 NS) columns in NS slots -- lane l of
+// slot s0+s is pixel (row l>>4, column 16 s + (l&15)).  Pixels are written as packed dwords into the wavefront's LDS
+// slice in memory order (mirrored passes write mirrored positions) and read back as the 3-byte-packed dword stream
+// of each row, so a store instruction writes 256 contiguous bytes of the patch.  Row r of the patch is image row
+// y0 + ystep r (ystep = -1 for the horizon-mirrored patch of a level view); rows >= nrows and columns >= n_w are
+// not written.  Falls back to per-lane byte stores when the row segment is not dword-aligned.
+template <int NS>
+__device__ __forceinline__ void store_patch_rgb(uint8_t* dst, int64_t dstride, uint32_t* lds, const uint32_t (&px)[kRowsPerWave][4],
+                                                int s0, int y0, int ystep, int nrows, int col0, int n_w, bool aligned4,
+                                                bool reversed, bool skip_first) {
+    const int lane = threadIdx.x & 63, r = lane >> 4, c16 = lane & 15;
+    if (aligned4 && (n_w & 3) == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int col = 16 * s + c16;
+            const int pos = reversed ? n_w - 1 - col : col;
+            if (col < n_w) lds[r * 64 + pos] = px[s0 + s][0] | (px[s0 + s][1] << 8) | (px[s0 + s][2] << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int dpr = (3 * n_w) >> 2;                    // dwords per row segment
+#pragma unroll
+        for (int j = 0; j < (NS * 48 + 63) / 64; ++j) {
+            const int d = lane + 64 * j;
+            const int rr = (d >= dpr ? 1 : 0) + (d >= 2 * dpr ? 1 : 0) + (d >= 3 * dpr ? 1 : 0);
+            const int k = d - rr * dpr;
+            const int k3 = (k * 21846) >> 16;              // k / 3 for k < 2^15
+            const int a = k + k3, sh = 8 * (k - 3 * k3);   // (4k)/3, 8*((4k)%3)
+            const bool live = d < 4 * dpr && rr < nrows;
+            const int idx = live ? rr * 64 + a : 0;
+            const uint32_t pa = lds[idx], pb = lds[idx + 1];
+            const uint32_t dw = (pa >> sh) | (pb << (24 - sh));
+#if GS360_EXPERIMENT == 1
+            if (live && dw == 0x12345678u)
+#else
+            if (live)
+#endif
+                __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(dst + (int64_t)(y0 + ystep * rr) * dstride + (int64_t)col0 * 3) + k);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int col = 16 * s + c16;
+        const int pos = reversed ? n_w - 1 - col : col;
+        if (col < n_w && r < nrows && !(skip_first && pos == 0)) {
+            uint8_t* q = dst + (int64_t)(y0 + ystep * r) * dstride + (int64_t)(col0 + pos) * 3;
+            q[0] = (uint8_t)px[s0 + s][0]; q[1] = (uint8_t)px[s0 + s][1]; q[2] = (uint8_t)px[s0 + s][2];
+        }
+    }
+}
+
+// How eq_pass hands its pixels to the blocked store (wave-uniform).  mode 0: row-per-slot map (store_row).
+struct BlkStore {
+    uint32_t* lds;       // this wavefront's 256-dword slice
+    int mode;            // 1: general view, 4 slots = one 4x64 patch;  2: level view, slots {0,1} top patch, {2,3} its horizon mirror
+    int y0, nrows;       // first image row of the (top) patch, valid rows
+    int yb, nrows_b;     // mode 2: first row of the mirrored patch (rows run upwards), valid rows
+    int sub;             // mode 2: first tile column of this wavefront's 32-column half
+};
 
 // ------------------------------------------------------------------------------------------------
 // EQ-SPEC v1
@@ -345,7 +412,7 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
                                         const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
                                         const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
                                         int col0, int n_px, bool reversed, bool aligned4, bool skip_first,
-                                        const int16_t* wtab) {
+                                        const int16_t* wtab, bool use_blk, const BlkStore blk) {
     if constexpr (CUBIC) {
         uint32_t px[kRowsPerWave][4];
         if constexpr (C == 3) {
@@ -402,6 +469,24 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
         for (int s = 0; s < kRowsPerWave; ++s)
             if (keep[s] < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
     }
+    if constexpr (C == 3 && !CUBIC && kRowsPerWave == 4 && kWaves == 4) {   // == kBlocked of the kernel
+      if (use_blk) {                                      // wave-uniform: this view uses the blocked lane map
+        if (blk.mode == 1) {
+            store_patch_rgb<4>(dst, dstride, blk.lds, px, 0, blk.y0, 1, blk.nrows, col0, n_px, aligned4, reversed, skip_first);
+            return;
+        }
+        {
+            // this wavefront owns tile columns [sub, sub + n_w); in the mirrored pass they sit at the other end of the segment
+            const int n_w = min(max(n_px - blk.sub, 0), 32);
+            const int c0 = reversed ? col0 + n_px - blk.sub - n_w : col0 + blk.sub;
+            const bool al = aligned4 && (((c0 * 3) & 3) == 0);
+            const bool skip = skip_first && n_w > 0 && blk.sub + n_w == n_px;   // the centre column is this half's last one
+            store_patch_rgb<2>(dst, dstride, blk.lds, px, 0, blk.y0, 1, blk.nrows, c0, n_w, al, reversed, skip);
+            store_patch_rgb<2>(dst, dstride, blk.lds, px, 2, blk.yb, -1, blk.nrows_b, c0, n_w, al, reversed, skip);
+            return;
+        }
+      }
+    }
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s)
 #if GS360_EXPERIMENT == 1   // load-path probe: only one lane-row in a million is written
@@ -435,6 +520,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
         for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
         __syncthreads();
     }
+    constexpr bool kBlocked = (C == 3) && !CUBIC && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map, see below
+    __shared__ uint32_t s_blk[kBlocked ? kWaves * 256 + 4 : 4];
     int f = t / L.tiles_per_frame;
     int r = t - f * L.tiles_per_frame;
     int k = 0;
@@ -481,7 +568,30 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
 
     // ---- coordinates (EQ-SPEC v1) ------------------------------------------------------------------
     int sxl[kRowsPerWave], sxm[kRowsPerWave], sys[kRowsPerWave];
-    if (level) {
+    const bool blocked = kBlocked && V.blocked != 0;      // wave-uniform, chosen per view on the host
+    if (level && blocked) {
+        // level view, blocked lane map: the wavefront owns 4 top rows x 32 columns (slots 0,1 = its two 16-column
+        // groups) and their horizon mirrors (slots 2,3).  Longitude is per column, latitude per (column, row) and
+        // shared with the mirrored row with its sign flipped, as in the row-per-slot form below.
+        const int top_h = (V.out_h + 1) >> 1;
+        const int yt = min(tile_y * (kTileH / 2) + (wave >> 1) * 4 + (lane >> 4), top_h - 1);
+        const float yv = (float)(2 * yt + 1 - V.out_h) * V.syv;
+        const float cy = __builtin_fmaf(-V.cp, yv, V.sp);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int xs = min(x0 + (wave & 1) * 32 + 16 * s + (lane & 15), half_w - 1);
+            const float xx = (float)(2 * xs + 1 - V.out_w) * V.sxu;
+            int Kl, Kt;
+            const float rl = eq_atan2_red(xx, 1.0f, Kl);
+            const float h = __builtin_sqrtf(__builtin_fmaf(xx, xx, 1.0f));
+            const float rt = eq_atan2_red(cy, h, Kt);
+            const int q = Kt * 8 * L.H + (int)__builtin_rintf(rt * L.ky32);
+            sys[s] = L.y0i32 - q;
+            sys[s + 2] = L.y0i32 + q;
+            sxl[s] = sxl[s + 2] = eq_quant_lon(rl, Kl, L, V);
+            sxm[s] = sxm[s + 2] = eq_quant_lon(-rl, -Kl, L, V);
+        }
+    } else if (level) {
         int Kl;
         const float rl = eq_atan2_red(x, 1.0f, Kl);       // b = fma(0, yv, 1) = 1 for every row
         const int sx_left = eq_quant_lon(rl, Kl, L, V), sx_mirror = eq_quant_lon(-rl, -Kl, L, V);
@@ -499,6 +609,28 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
             sxm[s] = sxm[s + kHalfRows] = sx_mirror;
         }
     } else {
+        if (blocked) {
+        // Blocked lane map: slot s is a 16-column group and lane>>4 the row, so every gather instruction covers a
+        // compact 4-row x 16-column patch of the view instead of 64 pixels of one row.  Where the view bends across
+        // source rows this halves the cache lines an instruction touches (CPU model of a cfg2 view: 0.78 instead of
+        // 1.41 lines per pixel) -- the vector L1's tag pipeline is the limiter of this kernel.
+        const int yl = min(tile_y * kTileH + wave * kRowsPerWave + (lane >> 4), V.out_h - 1);
+        const float yvl = (float)(2 * yl + 1 - V.out_h) * V.syv;
+        const float bzl = __builtin_fmaf(V.sp, yvl, V.cp);
+        const float cyl = __builtin_fmaf(-V.cp, yvl, V.sp);
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const int xs = min(x0 + 16 * s + (lane & 15), half_w - 1);
+            const float xx = (float)(2 * xs + 1 - V.out_w) * V.sxu;
+            const float h = __builtin_sqrtf(__builtin_fmaf(xx, xx, bzl * bzl));
+            int Kl, Kt;
+            const float rl = eq_atan2_red(xx, bzl, Kl);
+            const float rt = eq_atan2_red(cyl, h, Kt);
+            sxl[s] = eq_quant_lon(rl, Kl, L, V);
+            sxm[s] = eq_quant_lon(-rl, -Kl, L, V);
+            sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+        }
+        } else {
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s) {
             const float yv = (float)(2 * ys[s] + 1 - V.out_h) * V.syv;
@@ -512,17 +644,37 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
             sxm[s] = eq_quant_lon(-rl, -Kl, L, V);
             sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
         }
+        }
     }
 
     // ---- left half, then the mirrored half ---------------------------------------------------------
-    eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false, s_wtab);
+    BlkStore bs;
+    bs.lds = nullptr; bs.mode = 0; bs.y0 = bs.nrows = bs.yb = bs.nrows_b = bs.sub = 0;
+    if (blocked) {
+        bs.lds = s_blk + wave * 256;
+        if (level) {
+            const int top_h = (V.out_h + 1) >> 1;
+            bs.mode = 2;
+            bs.y0 = tile_y * (kTileH / 2) + (wave >> 1) * 4;
+            bs.nrows = min(max(top_h - bs.y0, 0), 4);
+            bs.yb = V.out_h - 1 - bs.y0;
+            // with an odd height the last top row is the horizon row itself: it has no mirror
+            bs.nrows_b = bs.nrows - (((V.out_h & 1) && bs.nrows > 0 && bs.y0 + bs.nrows == top_h) ? 1 : 0);
+            bs.sub = (wave & 1) * 32;
+        } else {
+            bs.mode = 1;
+            bs.y0 = tile_y * kTileH + wave * kRowsPerWave;
+            bs.nrows = min(max(V.out_h - bs.y0, 0), 4);
+        }
+    }
+    eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false, s_wtab, blocked, bs);
     // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
     // centre column is its own mirror and was already written: drop it from the segment.
     const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
     if (n_px > (centre_dup ? 1 : 0)) {
         const int col0 = V.out_w - x0 - n_px;
         const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
-        eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab);
+        eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab, blocked, bs);
     }
 }
 

@@ -27,7 +27,18 @@ def _assert_same(got, want, what):
 
 
 # ---- equirect ---------------------------------------------------------------------------------
-def test_equirect_cfg2_ring_small_source(ctx, orc):
+@pytest.fixture(params=["rows", "blocked", "auto"])
+def lanemap(request, monkeypatch):
+    """the equirect kernel has two lane maps (64-pixel rows / 4x16 patches) chosen per view on the host by the
+    minification; GS360_LANEMAP forces one so that every shape below is checked under both"""
+    if request.param == "auto":
+        monkeypatch.delenv("GS360_LANEMAP", raising=False)
+    else:
+        monkeypatch.setenv("GS360_LANEMAP", request.param)
+    return request.param
+
+
+def test_equirect_cfg2_ring_small_source(ctx, orc, lanemap):
     src = rand_image(480, 960)
     got, want = _eq_both(ctx, orc, src, ring_views(6, 200, HFOV_12MM))
     _assert_same(got, want, "cfg2-shaped ring on 960x480")
@@ -35,14 +46,14 @@ def test_equirect_cfg2_ring_small_source(ctx, orc):
 
 @pytest.mark.parametrize("name,layout,hfov", [("full360coverage", PRESET_FULL360, HFOV_14MM),
                                               ("fisheyelike", PRESET_FISHEYELIKE, HFOV_17MM)])
-def test_equirect_presets_pitched(ctx, orc, name, layout, hfov):
+def test_equirect_presets_pitched(ctx, orc, name, layout, hfov, lanemap):
     src = rand_image(512, 1024, seed=7)
     specs = [(y, p, hfov, hfov, 160, 160) for y, p in layout]
     got, want = _eq_both(ctx, orc, src, specs)
     _assert_same(got, want, name)
 
 
-def test_equirect_poles_seam_and_odd_shapes(ctx, orc):
+def test_equirect_poles_seam_and_odd_shapes(ctx, orc, lanemap):
     src = rand_image(301, 602, seed=3)  # odd height, width not a multiple of 4
     specs = [(0, 90, 100, 100, 96, 96), (0, -90, 100, 100, 96, 96), (180, 0, 120, 90, 130, 70),
              (-179.9, 45, 60, 60, 33, 47), (37.3, -62.1, 150, 140, 101, 99), (12, 5, 1, 1, 16, 16),
@@ -59,14 +70,14 @@ def test_equirect_channels(ctx, orc, channels):
     _assert_same(got, want, f"C={channels}")
 
 
-def test_equirect_full_size_8k_default6(ctx, orc):
+def test_equirect_full_size_8k_default6(ctx, orc, lanemap):
     """BASELINE cfg2 at full size: 7680x3840 -> 6 x 800^2, every byte."""
     src = rand_image(3840, 7680)
     got, want = _eq_both(ctx, orc, src, ring_views(6, 800, HFOV_12MM))
     _assert_same(got, want, "cfg2 full size")
 
 
-def test_equirect_mirror_symmetry_edge_shapes(ctx, orc):
+def test_equirect_mirror_symmetry_edge_shapes(ctx, orc, lanemap):
     """the kernel computes half of each row and mirrors it (and the top half of level views): odd widths/heights,
     widths around the 64/128 tile edges, 1-pixel views, level and pitched"""
     src = rand_image(257, 514, seed=17)
@@ -84,7 +95,7 @@ def test_equirect_mirror_symmetry_edge_shapes(ctx, orc):
 
 
 @pytest.mark.parametrize("interp", [1, 2])
-def test_equirect_fused_keep_mask(ctx, orc, interp):
+def test_equirect_fused_keep_mask(ctx, orc, interp, lanemap):
     """BASELINE config 5's fused mask multiply (SegmentationMaskTool convention: 0 = masked, 255 = keep)"""
     H, W = 240, 480
     frames = [rand_image(H, W, seed=500 + f) for f in range(2)]
@@ -114,7 +125,7 @@ def test_equirect_fused_keep_mask(ctx, orc, interp):
         ctx.free(b)
 
 
-def test_equirect_batched_frames_device_api(ctx, orc):
+def test_equirect_batched_frames_device_api(ctx, orc, lanemap):
     """n_frames x n_views in ONE launch through the device-pointer entry point."""
     H, W = 300, 600
     frames = [rand_image(H, W, seed=100 + f) for f in range(3)]
