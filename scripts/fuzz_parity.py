@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign: HIP kernels (through the C ABI) against the CPU oracle on random shapes, strides,
+channel counts, views, maps and interpolation modes.  Bit-exact uint8 is the bar; the first mismatch is printed with
+the seed that reproduces it and the exit code is 1.
+
+    python scripts/fuzz_parity.py --seconds 120 [--seed 1]
+"""
+import argparse
+import ctypes as C
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "360cam-pgm-3dgs-tools_amd"))
+
+import numpy as np  # noqa: E402
+
+import gs360  # noqa: E402
+from oracle import orc  # noqa: E402  (checker)
+
+
+def padded(rng, img, pad):
+    """copy of img with `pad` junk bytes after every row; returns (buffer, stride)"""
+    h, w, c = img.shape
+    stride = w * c + pad
+    buf = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    buf[:, :w * c] = img.reshape(h, w * c)
+    return buf, stride
+
+
+def fuzz_equirect(ctx, rng, case):
+    c = int(rng.choice([1, 3, 3, 3, 4]))
+    W = int(rng.integers(8, 700))
+    H = int(rng.integers(2, 360))
+    src = rng.integers(0, 256, (H, W, c), dtype=np.uint8)
+    nv = int(rng.integers(1, 5))
+    specs = []
+    for _ in range(nv):
+        level = rng.random() < 0.4
+        specs.append((float(rng.uniform(-400, 400)), 0.0 if level else float(rng.uniform(-95, 95)),
+                      float(rng.uniform(5, 179)), float(rng.uniform(5, 179)), int(rng.integers(1, 200)), int(rng.integers(1, 120))))
+    interp = int(rng.choice([1, 1, 2]))
+    spad = int(rng.choice([0, 0, 1, 3, 4, 64]))
+    dpad = int(rng.choice([0, 0, 1, 2, 4]))
+    use_mask = rng.random() < 0.3
+    sbuf, sstride = padded(rng, src, spad)
+    d_src = ctx.to_device(sbuf)
+    views = [gs360.View.make(*s) for s in specs]
+    # one common dst stride for all views of the call (ABI): widest view row + pad
+    dstride = max(s[4] for s in specs) * c + dpad if dpad else 0
+    d_out = [ctx.alloc((dstride or s[4] * c) * s[5] + 64) for s in specs]
+    for b in d_out:
+        ctx.memset(b, 0xAB)
+    mask = d_mask = None
+    if use_mask:
+        mask = (rng.integers(0, 2, (H, W), dtype=np.uint8) * 255)
+        d_mask = ctx.to_device(mask)
+    ctx.equirect_views_dev([d_src], W, H, c, views, d_out, src_stride=sstride if spad else 0, dst_stride=dstride, interp=interp,
+                           masks=[d_mask] if use_mask else None)
+    want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], interp=interp, mask=mask, threads=0)
+    ok = True
+    for k, s in enumerate(specs):
+        row = dstride or s[4] * c
+        raw = ctx.download(d_out[k], (s[5], row))
+        got = raw[:, :s[4] * c].reshape(s[5], s[4], c)
+        if not np.array_equal(got, want[k]):
+            ok = False
+            bad = np.argwhere(got != want[k])
+            print(f"[equirect] case {case}: view {k} {s} C={c} src {W}x{H} interp={interp} spad={spad} dpad={dpad} mask={use_mask}: "
+                  f"{len(bad)} bytes differ, first at {bad[0].tolist()}")
+        if dstride and not np.all(raw[:, s[4] * c:] == 0xAB):
+            ok = False
+            print(f"[equirect] case {case}: view {k} wrote into the row padding")
+    for b in d_out + [d_src] + ([d_mask] if d_mask else []):
+        ctx.free(b)
+    return ok
+
+
+def fuzz_table(ctx, rng, case):
+    c = int(rng.choice([1, 3, 3, 4]))
+    W = int(rng.integers(1, 300))
+    H = int(rng.integers(1, 200))
+    w = int(rng.integers(1, 260))
+    h = int(rng.integers(1, 100))
+    src = rng.integers(0, 256, (H, W, c), dtype=np.uint8)
+    kind = rng.integers(0, 4)
+    if kind == 0:      # smooth affine-ish map
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        a = rng.uniform(-1.5, 1.5, 6).astype(np.float32)
+        mx = a[0] * xx + a[1] * yy + np.float32(rng.uniform(-20, W))
+        my = a[2] * xx + a[3] * yy + np.float32(rng.uniform(-20, H))
+    elif kind == 1:    # uniform random incl. outside
+        mx = rng.uniform(-8, W + 8, (h, w)).astype(np.float32)
+        my = rng.uniform(-8, H + 8, (h, w)).astype(np.float32)
+    elif kind == 2:    # exact 1/32 grid points and half-way ties
+        mx = (rng.integers(-64, 32 * W + 64, (h, w)) / 32.0 + rng.choice([0.0, 1 / 64.0], (h, w))).astype(np.float32)
+        my = (rng.integers(-64, 32 * H + 64, (h, w)) / 32.0 + rng.choice([0.0, 1 / 64.0], (h, w))).astype(np.float32)
+    else:              # specials
+        mx = rng.uniform(-2, W + 2, (h, w)).astype(np.float32)
+        my = rng.uniform(-2, H + 2, (h, w)).astype(np.float32)
+        sel = rng.random((h, w))
+        mx[sel < 0.05] = np.nan
+        my[(sel > 0.05) & (sel < 0.1)] = np.inf
+        mx[(sel > 0.1) & (sel < 0.15)] = -np.inf
+        mx[(sel > 0.15) & (sel < 0.2)] = 1e9
+        my[(sel > 0.2) & (sel < 0.25)] = -40000.0
+    interp = int(rng.choice([0, 1, 1, 2, 4]))
+    bv = tuple(float(v) for v in rng.integers(0, 256, 4))
+    valid = (rng.random((h, w)) > 0.2) if rng.random() < 0.5 else None
+    fill = int(rng.integers(0, 256))
+    got = ctx.remap(src, mx, my, interpolation=interp, border_value=bv, valid=valid, fill_value=fill)
+    want = orc.remap_u8(src, mx, my, interp=interp, border_value=bv, threads=0)
+    if valid is not None:
+        want = orc.valid_fill(want.copy(), valid, fill)
+    if not np.array_equal(got.reshape(want.shape), want):
+        bad = np.argwhere(got.reshape(want.shape) != want)
+        print(f"[table] case {case}: src {W}x{H}x{c} map {w}x{h} kind={kind} interp={interp}: {len(bad)} bytes differ, first at {bad[0].tolist()}")
+        return False
+    return True
+
+
+def fuzz_fisheye(ctx, rng, case):
+    c = int(rng.choice([1, 3, 3, 4]))
+    W = int(rng.integers(40, 400))
+    H = int(rng.integers(40, 400))
+    f = float(rng.uniform(0.2, 0.5) * min(W, H))
+    kw = dict(width=W, height=H, f=f, cx=float(rng.uniform(-5, 5)), cy=float(rng.uniform(-5, 5)), k1=float(rng.uniform(-0.1, 0.15)),
+              k2=float(rng.uniform(-0.02, 0.02)), k3=float(rng.uniform(-0.003, 0.003)), k4=float(rng.uniform(-0.0005, 0.0005)))
+    if rng.random() < 0.5:
+        kw.update(p1=float(rng.uniform(-0.002, 0.002)), p2=float(rng.uniform(-0.002, 0.002)), b1=float(rng.uniform(-2, 2)), b2=float(rng.uniform(-1, 1)))
+    src = rng.integers(0, 256, (H, W, c), dtype=np.uint8)
+    spec = (float(rng.uniform(-200, 200)), float(rng.uniform(-80, 80)), float(rng.uniform(20, 150)), float(rng.uniform(20, 150)),
+            int(rng.integers(1, 150)), int(rng.integers(1, 100)))
+    lens_fov = float(rng.uniform(120, 220))
+    interp = int(rng.choice([0, 1, 1, 2, 4]))
+    mask_outside = bool(rng.random() < 0.7)
+    mval = int(rng.integers(0, 256))
+    d_src = ctx.to_device(src)
+    d_out = ctx.alloc(spec[4] * spec[5] * c)
+    d_val = ctx.alloc(spec[4] * spec[5])
+    ctx.fisheye_views_dev([d_src], [gs360.Calib.make(**kw)], c, [gs360.View.make(*spec)], lens_fov, [d_out], valid_outs=[d_val],
+                          interp=interp, mask_outside=mask_outside, mask_value=mval)
+    got = ctx.download(d_out, (spec[5], spec[4], c))
+    gval = ctx.download(d_val, (spec[5], spec[4]))
+    mx, my, valid = orc.fisheye_spec_map(orc.make_calib(**kw), *spec, lens_fov)
+    want = orc.remap_u8(src, mx, my, interp=interp, border_value=float(mval), threads=0)
+    if mask_outside:
+        want = orc.valid_fill(want.copy(), valid, mval)
+    for b in (d_src, d_out, d_val):
+        ctx.free(b)
+    if not np.array_equal(got, want.reshape(got.shape)) or not np.array_equal(gval.astype(bool), valid):
+        bad = np.argwhere(got != want.reshape(got.shape))
+        print(f"[fisheye] case {case}: lens {W}x{H}x{c} view {spec} fov={lens_fov:.1f} interp={interp} mask={mask_outside}: "
+              f"{len(bad)} bytes differ, valid differs at {int((gval.astype(bool) != valid).sum())} px")
+        return False
+    return True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    ctx = gs360.Context(0, n_slots=2)
+    t0 = time.time()
+    counts = {"equirect": 0, "table": 0, "fisheye": 0}
+    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye}
+    case, failures = 0, 0
+    while time.time() - t0 < args.seconds and failures < 5:
+        name = ("equirect", "table", "fisheye")[case % 3]
+        rng = np.random.default_rng([args.seed, case])
+        if not fns[name](ctx, rng, f"{args.seed}:{case}"):
+            failures += 1
+        counts[name] += 1
+        case += 1
+    print(f"fuzz_parity: {case} cases in {time.time() - t0:.1f} s {counts}, failures={failures}")
+    ctx.close()
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
