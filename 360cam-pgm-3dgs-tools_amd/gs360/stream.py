@@ -38,22 +38,34 @@ class FramePipeline:
         self.slots = [_Slot(ctx, i, self.frame_bytes, vb) for i in range(n_slots)]
         self._next = 0
 
-    def submit(self, frame: np.ndarray, tag=None):
-        """Enqueue one frame on the next slot (blocks only if that slot is still busy).  Returns results of the
-        frame that previously occupied the slot, or None."""
+    def acquire(self):
+        """Claim the next slot and hand out its PINNED input buffer as a writable uint8 array, so a producer (a
+        decoder's readinto, see gs360/video.py) fills it in place and no staging copy is needed.  Returns
+        (done, array): `done` = results of the frame that previously occupied the slot, or None.  Follow with commit()."""
+        s = self.slots[self._next]
+        done = self._collect(s) if s.busy else None
+        return done, np.frombuffer(s.h_in.view, dtype=np.uint8, count=self.frame_bytes)
+
+    def commit(self, tag=None) -> None:
+        """Enqueue upload -> all-views launch -> downloads for the slot handed out by acquire()."""
         s = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
-        done = self._collect(s) if s.busy else None
-        a = np.ascontiguousarray(frame, dtype=np.uint8)
-        if a.nbytes != self.frame_bytes:
-            raise ValueError("frame size mismatch")
-        np.frombuffer(s.h_in.view, dtype=np.uint8)[:] = a.reshape(-1)      # stage into pinned memory
         L, h = self.ctx.L, self.ctx.handle
         capi._check(L.gs360_upload(h, s.d_in.ptr, s.h_in.ptr, self.frame_bytes, s.idx), L)
         self.ctx.equirect_views_dev([s.d_in], self.W, self.H, self.C, self.views, s.d_out, slot=s.idx)
         for d, hbuf in zip(s.d_out, s.h_out):
             capi._check(L.gs360_download(h, hbuf.ptr, d.ptr, hbuf.nbytes, s.idx), L)
         s.busy, s.tag = True, tag
+
+    def submit(self, frame: np.ndarray, tag=None):
+        """Enqueue one frame held in ordinary host memory (copied into the slot's pinned buffer first; blocks only if
+        that slot is still busy).  Returns results of the frame that previously occupied the slot, or None."""
+        a = np.ascontiguousarray(frame, dtype=np.uint8)
+        if a.nbytes != self.frame_bytes:
+            raise ValueError("frame size mismatch")
+        done, staging = self.acquire()
+        staging[:] = a.reshape(-1)
+        self.commit(tag)
         return done
 
     def _collect(self, s):
