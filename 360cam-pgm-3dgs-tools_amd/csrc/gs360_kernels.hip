@@ -59,6 +59,38 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_PAIRED_FETCH
 #define GS360_PAIRED_FETCH 1
 #endif
+#ifndef GS360_TABLE_NT
+#define GS360_TABLE_NT 0
+#endif
+
+// The 8 tap bytes (two RGB pixels + 2) of rows y0 and y1 of one pixel, at byte offsets o0 / o1 from `src`.
+// Row-paired gathers: issued naively, one instruction reads row y0 of all 64 pixels and the next one row y1; where the
+// view bends across source rows, row Y is "y0" for one run of lanes and "y1" for the neighbouring run, so the second
+// instruction asks for lines the first one has just missed on and the L1 stalls on the pending fill.  Here lanes 0-31
+// of the first instruction read row y0 and lanes 32-63 row y1 of the SAME 32 pixels (second instruction: the other 32
+// pixels), so both uses of a line meet in one instruction and are merged by the address coalescer.
+// v_permlane32_swap (gfx950) builds the two address vectors from (o0, o1) in one operation and puts the returned
+// dwords back in pixel order.  Each read is a dword-aligned 12-byte access shifted into place with v_alignbyte.
+__device__ __forceinline__ void ld_rows_rgb(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1, uint2& t0, uint2& t1) {
+#if GS360_PAIRED_FETCH
+    const uint32_t s0 = o0 & 3u, s1 = o1 & 3u;
+    const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0 & ~3u, o1 & ~3u, false, false);
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
+    const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2];
+    const uint32_t b0 = qb[0], b1 = qb[1], b2 = qb[2];
+    const u32x2 d0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);   // .x = row y0, .y = row y1, own pixel
+    const u32x2 d1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    const u32x2 d2 = __builtin_amdgcn_permlane32_swap(a2, b2, false, false);
+    t0.x = __builtin_amdgcn_alignbyte(d1.x, d0.x, s0);
+    t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, s0);
+    t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, s1);
+    t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, s1);
+#else
+    t0 = ld_u64_via_aligned96(src + o0);
+    t1 = ld_u64_via_aligned96(src + o1);
+#endif
+}
 
 // bilinear blend of one channel, weights a0+a1 = 32, b0+b1 = 32  ->  (sum + 512) >> 10
 __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s10, uint32_t s11,
@@ -238,31 +270,7 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
         t.t0 = make_uint2(a, 0);
         t.t1 = make_uint2(b, 0);
     } else if constexpr (C == 3) {
-#if GS360_PAIRED_FETCH
-        // Row-paired gathers.  Issued naively, one instruction reads row y0 of all 64 pixels and the next one row y1;
-        // where the view bends across source rows, row Y is "y0" for one run of lanes and "y1" for the neighbouring
-        // run, so the second instruction asks for lines the first one has just missed on and the L1 stalls on the
-        // pending fill.  Here lanes 0-31 of the first instruction read row y0 and lanes 32-63 row y1 of the SAME 32
-        // pixels (second instruction: the other 32 pixels), so both uses of a line meet in one instruction and are
-        // merged by the address coalescer.  v_permlane32_swap (gfx950) builds the two address vectors from (o0, o1)
-        // in one operation and puts the returned dwords back in pixel order.
-        const uint32_t s0 = o0 & 3u, s1 = o1 & 3u;
-        const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0 & ~3u, o1 & ~3u, false, false);
-        const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
-        const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
-        const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2];
-        const uint32_t b0 = qb[0], b1 = qb[1], b2 = qb[2];
-        const u32x2 d0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);   // .x = row y0, .y = row y1, own pixel
-        const u32x2 d1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        const u32x2 d2 = __builtin_amdgcn_permlane32_swap(a2, b2, false, false);
-        t.t0.x = __builtin_amdgcn_alignbyte(d1.x, d0.x, s0);
-        t.t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, s0);
-        t.t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, s1);
-        t.t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, s1);
-#else
-        t.t0 = ld_u64_via_aligned96(r0);
-        t.t1 = ld_u64_via_aligned96(r1);
-#endif
+        ld_rows_rgb(src, o0, o1, t.t0, t.t1);
     } else {
         t.t0 = ld_u64(r0);
         t.t1 = ld_u64(r1);
@@ -842,8 +850,9 @@ __device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__
     t.fast = ix >= 0 && iy >= 0 && ix <= W - kBack && iy < H - 1;
     const int xa = min(max(ix, 0), W - kBack), ya = min(max(iy, 0), H - 1), yb = min(ya + 1, H - 1);
     const uint32_t col = (uint32_t)xa * C;
-    const uint8_t* r0 = src + (__umul24((uint32_t)ya, (uint32_t)stride) + col);
-    const uint8_t* r1 = src + (__umul24((uint32_t)yb, (uint32_t)stride) + col);
+    const uint32_t o0 = __umul24((uint32_t)ya, (uint32_t)stride) + col, o1 = __umul24((uint32_t)yb, (uint32_t)stride) + col;
+    const uint8_t* r0 = src + o0;
+    const uint8_t* r1 = src + o1;
     if constexpr (C == 1) {
         uint16_t a, b;
         __builtin_memcpy(&a, r0, 2);
@@ -851,8 +860,7 @@ __device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__
         t.t0 = make_uint2(a, 0);
         t.t1 = make_uint2(b, 0);
     } else if constexpr (C == 3) {
-        t.t0 = ld_u64_via_aligned96(r0);
-        t.t1 = ld_u64_via_aligned96(r1);
+        ld_rows_rgb(src, o0, o1, t.t0, t.t1);
     } else {
         t.t0 = ld_u64(r0);
         t.t1 = ld_u64(r1);
@@ -869,8 +877,18 @@ __device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out
     eq_blend<C>(e, t.fx, t.fy, out);     // same 1/32-px weights: only the fractional bits of sx, sy are used
 }
 
-template <int C>
-__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
+// One instantiation per interpolation: the 8x8 Lanczos window would otherwise set the register budget (and with it the
+// occupancy) of the bilinear path.
+#ifndef GS360_TABLE_WAVES
+#define GS360_TABLE_WAVES 0
+#endif
+#if GS360_TABLE_WAVES
+#define GS360_TABLE_OCC __attribute__((amdgpu_waves_per_eu(GS360_TABLE_WAVES, GS360_TABLE_WAVES)))
+#else
+#define GS360_TABLE_OCC
+#endif
+template <int C, int INTERP>
+__global__ __launch_bounds__(64 * kWaves) GS360_TABLE_OCC void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
     int b = blockIdx.x;
     int t = (b & 7) * chunk + (b >> 3);
     if (t >= total_tiles) return;
@@ -880,7 +898,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLau
     const int n_px = min(kTileW, L.w - x0);
     const int xc = min(x0 + lane, L.w - 1);
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
-    if (L.interp == GS360_INTERP_LINEAR && L.pipelined) {
+    if (INTERP == GS360_INTERP_LINEAR && L.pipelined) {
         // maps of the wavefront's 4 rows -> all 8 gathers in flight -> blend -> border/valid fix-ups -> packed stores
         const int ybase = tile_y * kTileH + wave * kRowsPerWave;
         float mxs[kRowsPerWave], mys[kRowsPerWave];
@@ -888,9 +906,15 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLau
 #pragma unroll
         for (int rr = 0; rr < kRowsPerWave; ++rr) {
             const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
+#if GS360_TABLE_NT   // the maps are read exactly once: keep them out of the way of the source lines in L1/L2
+            mxs[rr] = __builtin_nontemporal_load(L.map_x + o);
+            mys[rr] = __builtin_nontemporal_load(L.map_y + o);
+            inval[rr] = L.valid && !__builtin_nontemporal_load(L.valid + o);
+#else
             mxs[rr] = L.map_x[o];
             mys[rr] = L.map_y[o];
             inval[rr] = L.valid && !L.valid[o];
+#endif
         }
         CvTaps<C> taps[kRowsPerWave];
         bool any_slow = false;
@@ -924,9 +948,9 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLau
         int64_t o = (int64_t)y * L.w + xc;
         float mx = L.map_x[o], my = L.map_y[o];      // 256 B per wavefront row, coalesced
         uint32_t px[4];
-        if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
-        else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
-        else if (L.interp == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
+        if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
+        else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
+        else if constexpr (INTERP == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
         else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
         if (L.valid && !L.valid[o]) {
 #pragma unroll
@@ -942,7 +966,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLau
 // One launch per view: the view block travels as a plain by-value kernel argument (SGPR-resident).  Indexing an
 // array of these 148-byte blocks dynamically made the compiler spill the whole argument struct to scratch
 // (2368 B/lane, 13x slower), so the host loops over views instead.
-template <int C>
+template <int C, int INTERP>
 __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeView V, const FeCommon L) {
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
@@ -957,7 +981,7 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeView V, c
     const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
 
     const int ybase = tile_y * kTileH + wave * kRowsPerWave;
-    const bool pipelined = (L.interp == GS360_INTERP_LINEAR) && L.pipelined;
+    const bool pipelined = (INTERP == GS360_INTERP_LINEAR) && L.pipelined;
     float mxs[kRowsPerWave], mys[kRowsPerWave];
     bool oks[kRowsPerWave];
 #pragma unroll
@@ -1006,9 +1030,9 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeView V, c
         }
     } else {
         for (int rr = 0; rr < kRowsPerWave; ++rr) {
-            if (L.interp == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
-            else if (L.interp == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
-            else if (L.interp == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
+            if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
+            else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
+            else if constexpr (INTERP == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
             else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
         }
     }
@@ -1050,14 +1074,38 @@ hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
     return hipGetLastError();
 }
 
+namespace {
+
+template <int C>
+void launch_table_c(const TableLaunch& L, dim3 grid, dim3 block, hipStream_t s, int tiles_x, int total, int chunk) {
+    switch (L.interp) {
+        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, L, tiles_x, total, chunk); break;
+        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, L, tiles_x, total, chunk); break;
+        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, L, tiles_x, total, chunk); break;
+        default: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, L, tiles_x, total, chunk); break;
+    }
+}
+
+template <int C>
+void launch_fisheye_c(const FeView& V, const FeCommon& K, dim3 grid, dim3 block, hipStream_t s) {
+    switch (K.interp) {
+        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, V, K); break;
+        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, V, K); break;
+        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, V, K); break;
+        default: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, V, K); break;
+    }
+}
+
+}  // namespace
+
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
     int tiles_x = (L.w + kTileW - 1) / kTileW, tiles_y = (L.h + kTileH - 1) / kTileH;
     int total = tiles_x * tiles_y, chunk = (total + 7) / 8;
     dim3 grid((unsigned)(chunk * 8)), block(64 * kWaves);
     switch (C) {
-        case 1: hipLaunchKernelGGL(table_remap_kernel<1>, grid, block, 0, s, L, tiles_x, total, chunk); break;
-        case 3: hipLaunchKernelGGL(table_remap_kernel<3>, grid, block, 0, s, L, tiles_x, total, chunk); break;
-        case 4: hipLaunchKernelGGL(table_remap_kernel<4>, grid, block, 0, s, L, tiles_x, total, chunk); break;
+        case 1: launch_table_c<1>(L, grid, block, s, tiles_x, total, chunk); break;
+        case 3: launch_table_c<3>(L, grid, block, s, tiles_x, total, chunk); break;
+        case 4: launch_table_c<4>(L, grid, block, s, tiles_x, total, chunk); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1075,9 +1123,9 @@ hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s) {
         K.pipelined = L.pipelined;
         dim3 grid((unsigned)(K.chunk * 8)), block(64 * kWaves);
         switch (C) {
-            case 1: hipLaunchKernelGGL(fe_views_kernel<1>, grid, block, 0, s, L.view[k], K); break;
-            case 3: hipLaunchKernelGGL(fe_views_kernel<3>, grid, block, 0, s, L.view[k], K); break;
-            case 4: hipLaunchKernelGGL(fe_views_kernel<4>, grid, block, 0, s, L.view[k], K); break;
+            case 1: launch_fisheye_c<1>(L.view[k], K, grid, block, s); break;
+            case 3: launch_fisheye_c<3>(L.view[k], K, grid, block, s); break;
+            case 4: launch_fisheye_c<4>(L.view[k], K, grid, block, s); break;
             default: return hipErrorInvalidValue;
         }
         hipError_t e = hipGetLastError();
