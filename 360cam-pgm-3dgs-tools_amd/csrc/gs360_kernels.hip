@@ -59,9 +59,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_PAIRED_FETCH
 #define GS360_PAIRED_FETCH 1
 #endif
-#ifndef GS360_TABLE_NT
-#define GS360_TABLE_NT 0
-#endif
+
 
 // The 8 tap bytes (two RGB pixels + 2) of rows y0 and y1 of one pixel, at byte offsets o0 / o1 from `src`.
 // Row-paired gathers: issued naively, one instruction reads row y0 of all 64 pixels and the next one row y1; where the
@@ -879,16 +877,8 @@ __device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out
 
 // One instantiation per interpolation: the 8x8 Lanczos window would otherwise set the register budget (and with it the
 // occupancy) of the bilinear path.
-#ifndef GS360_TABLE_WAVES
-#define GS360_TABLE_WAVES 0
-#endif
-#if GS360_TABLE_WAVES
-#define GS360_TABLE_OCC __attribute__((amdgpu_waves_per_eu(GS360_TABLE_WAVES, GS360_TABLE_WAVES)))
-#else
-#define GS360_TABLE_OCC
-#endif
 template <int C, int INTERP>
-__global__ __launch_bounds__(64 * kWaves) GS360_TABLE_OCC void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
+__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
     int b = blockIdx.x;
     int t = (b & 7) * chunk + (b >> 3);
     if (t >= total_tiles) return;
@@ -906,15 +896,9 @@ __global__ __launch_bounds__(64 * kWaves) GS360_TABLE_OCC void table_remap_kerne
 #pragma unroll
         for (int rr = 0; rr < kRowsPerWave; ++rr) {
             const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
-#if GS360_TABLE_NT   // the maps are read exactly once: keep them out of the way of the source lines in L1/L2
-            mxs[rr] = __builtin_nontemporal_load(L.map_x + o);
-            mys[rr] = __builtin_nontemporal_load(L.map_y + o);
-            inval[rr] = L.valid && !__builtin_nontemporal_load(L.valid + o);
-#else
-            mxs[rr] = L.map_x[o];
+            mxs[rr] = L.map_x[o];         // (non-temporal map loads were measured: no difference)
             mys[rr] = L.map_y[o];
             inval[rr] = L.valid && !L.valid[o];
-#endif
         }
         CvTaps<C> taps[kRowsPerWave];
         bool any_slow = false;
