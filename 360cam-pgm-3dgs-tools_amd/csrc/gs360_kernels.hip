@@ -56,6 +56,9 @@ __device__ __forceinline__ uint2 ld_u64_via_aligned96(const uint8_t* p) {
 }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#ifndef GS360_EQ_WAVES
+#define GS360_EQ_WAVES 5     // wavefronts per SIMD of the bilinear equirect kernel (measured optimum, see the kernel comment)
+#endif
 #ifndef GS360_PAIRED_FETCH
 #define GS360_PAIRED_FETCH 1
 #endif
@@ -513,11 +516,13 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 // changes sign before the final fma/rint.  Level views (pitch 0) are also symmetric about the horizon:
 // yv(h-1-j) = -yv(j) exactly, latitude flips sign (rint is odd) -> one atan2 serves four pixels, and the
 // longitude term depends on the column only.  All of this is bit-identical to evaluating EQ-SPEC v1 per pixel.
-// Occupancy is capped at 4 wavefronts per SIMD (4 workgroups per CU): measured optimum for the 8K workload -- with
-// more resident wavefronts their gathers evict each other's lines from the 32 KiB vector L1 (6 blocks/CU: 24.3 us per
-// frame, 4: 23.1, 3: 27.4, 1: 45.5).
+// Occupancy is pinned (GS360_EQ_WAVES wavefronts per SIMD): with more resident wavefronts their gathers evict each
+// other's lines from the 32 KiB vector L1, with fewer the miss queue runs dry.  Measured on cfg2, us per frame --
+// row-per-slot lane map: 3 / 4 / 6 wavefronts: 27.4 / 23.1 / 24.3; blocked lane map: 3 / 4 / 5 / 6: 22.1 / 20.8 / 20.3 /
+// 23.3 (6 spills).  5 is also the better choice for the arithmetic-bound large-view configs (cfg1/3/5).  The cubic
+// variant needs 128 VGPRs and stays at 4.
 template <int C, bool CUBIC>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void eq_views_kernel(const EqLaunch L) {
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUBIC ? 4 : GS360_EQ_WAVES, CUBIC ? 4 : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
     // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk)
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
