@@ -285,21 +285,37 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
     return t;
 }
 
+// Integer multiply-adds as v_dot2_i32_i16: v_perm_b32 gathers two tap bytes into a zero-extended 16-bit pair and one
+// dot instruction multiplies both by a packed pair of weights and accumulates.  Exact integer arithmetic.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2_i16(uint32_t taps, uint32_t weights, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, taps), __builtin_bit_cast(s16x2, weights), acc, false);
+}
+// v_perm_b32(a, b, sel) selector: result = (0, hi, 0, lo) where lo / hi index the bytes of {a (4..7), b (0..3)}
+#define GS360_PAIR(lo, hi) (0x0c000c00u | ((uint32_t)(hi) << 16) | (uint32_t)(lo))
+
 template <int C>
 __device__ __forceinline__ void eq_blend(const EqTaps<C>& t, int sx, int sy, uint32_t (&out)[4]) {
     const int fx = sx & 31, fy = sy & 31;
-    const uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
-    const uint32_t w00 = a0 * b0, w01 = a1 * b0, w10 = a0 * b1, w11 = a1 * b1;
-    if constexpr (C == 3) {
-        out[0] = blend(byte_of(t.t0.x, 0), byte_of(t.t0.x, 3), byte_of(t.t1.x, 0), byte_of(t.t1.x, 3), w00, w01, w10, w11);
-        out[1] = blend(byte_of(t.t0.x, 1), byte_of(t.t0.y, 0), byte_of(t.t1.x, 1), byte_of(t.t1.y, 0), w00, w01, w10, w11);
-        out[2] = blend(byte_of(t.t0.x, 2), byte_of(t.t0.y, 1), byte_of(t.t1.x, 2), byte_of(t.t1.y, 1), w00, w01, w10, w11);
-    } else if constexpr (C == 4) {
+    // (sum S a b + 512) >> 10 with a in {32-fx, fx}, b in {32-fy, fy}: the weights of one row, a0 b | (a1 b) << 16, are
+    // one multiply of the packed horizontal pair (a1 b <= 1024 cannot carry into the upper half)
+    const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);
+    const uint32_t wr0 = ah * (uint32_t)(32 - fy), wr1 = ah * (uint32_t)fy;
+    if constexpr (C == 3) {          // row bytes: r0 g0 b0 r1 | g1 b1 . .
+        out[0] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.x, t.t1.x, GS360_PAIR(0, 3)), wr1,
+                                    dot2_i16(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 3)), wr0, 512)) >> 10;
+        out[1] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(1, 4)), wr1,
+                                    dot2_i16(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(1, 4)), wr0, 512)) >> 10;
+        out[2] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(2, 5)), wr1,
+                                    dot2_i16(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(2, 5)), wr0, 512)) >> 10;
+    } else if constexpr (C == 4) {   // row bytes: r0 g0 b0 a0 | r1 g1 b1 a1
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            out[c] = blend(byte_of(t.t0.x, c), byte_of(t.t0.y, c), byte_of(t.t1.x, c), byte_of(t.t1.y, c), w00, w01, w10, w11);
-    } else {
-        out[0] = blend(byte_of(t.t0.x, 0), byte_of(t.t0.x, 1), byte_of(t.t1.x, 0), byte_of(t.t1.x, 1), w00, w01, w10, w11);
+            out[c] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(c, 4 + c)), wr1,
+                                        dot2_i16(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(c, 4 + c)), wr0, 512)) >> 10;
+    } else {                         // row bytes: v0 v1
+        out[0] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.x, t.t1.x, GS360_PAIR(0, 1)), wr1,
+                                    dot2_i16(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 1)), wr0, 512)) >> 10;
     }
 }
 
@@ -361,21 +377,24 @@ __device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const i
     return t;
 }
 
+// 48 multiply-adds per pixel as 24 v_dot2_i32_i16 (see eq_blend): constant selectors -- the 12 tap bytes of a row are
+// b0..b11, channel c owns b[c], b[3+c], b[6+c], b[9+c] -- and the table already stores the weights as int16 pairs.
+
 __device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, uint32_t (&out)[4]) {
     const uint32_t wpk[8] = {t.wa.x, t.wa.y, t.wa.z, t.wa.w, t.wb.x, t.wb.y, t.wb.z, t.wb.w};
     int acc[3] = {0, 0, 0};
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const uint32_t pk = wpk[(ky * 4 + kx) >> 1];
-            const int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int bi = kx * 3 + c;
-                acc[c] += (int)byte_of(t.row[ky][bi >> 2], bi & 3) * w;
-            }
-        }
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint32_t d0 = t.row[ky][0], d1 = t.row[ky][1], d2 = t.row[ky][2];
+        const uint32_t w01 = wpk[2 * ky], w23 = wpk[2 * ky + 1];
+        // perm(a, b, sel): bytes 0..3 come from b, 4..7 from a
+        acc[0] = dot2_i16(__builtin_amdgcn_perm(d0, d0, GS360_PAIR(0, 3)), w01, acc[0]);            // b0, b3
+        acc[0] = dot2_i16(__builtin_amdgcn_perm(d2, d1, GS360_PAIR(2, 5)), w23, acc[0]);            // b6 = d1.2, b9 = d2.1
+        acc[1] = dot2_i16(__builtin_amdgcn_perm(d1, d0, GS360_PAIR(1, 4)), w01, acc[1]);            // b1 = d0.1, b4 = d1.0
+        acc[1] = dot2_i16(__builtin_amdgcn_perm(d2, d1, GS360_PAIR(3, 6)), w23, acc[1]);            // b7 = d1.3, b10 = d2.2
+        acc[2] = dot2_i16(__builtin_amdgcn_perm(d1, d0, GS360_PAIR(2, 5)), w01, acc[2]);            // b2 = d0.2, b5 = d1.1
+        acc[2] = dot2_i16(__builtin_amdgcn_perm(d2, d2, GS360_PAIR(0, 3)), w23, acc[2]);            // b8 = d2.0, b11 = d2.3
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((acc[c] + (1 << 14)) >> 15, 0), 255);
 }
