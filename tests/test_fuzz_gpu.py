@@ -1,4 +1,4 @@
-"""A short run of the randomised parity campaign (scripts/fuzz_parity.py): random shapes, strides, channel counts,
+"""A short run of the randomised parity campaign (tests/tools/fuzz_parity.py): random shapes, strides, channel counts,
 views, maps (incl. NaN/inf), masks and interpolation modes for all three kernels, bit-exact against the oracle."""
 import subprocess
 import sys
@@ -16,7 +16,7 @@ def test_fuzz_parity_short(lanemap):
     env.pop("GS360_LANEMAP", None)
     if lanemap:
         env["GS360_LANEMAP"] = lanemap
-    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "fuzz_parity.py"), "--seconds", "8", "--seed", "77"],
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "fuzz_parity.py"), "--seconds", "8", "--seed", "77"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "failures=0" in r.stdout

@@ -5,7 +5,7 @@ shared decode of a video; here the frames are synthetic (image B rolled 13 px pe
 once.  Timed: the 600 x 12 view renders (batched 16 frames per launch, HIP events on the launch stream); a few frames
 are checked against the oracle.  Informational -- bench.py (cfg2) is the headline.
 
-    python scripts/bench_cfg3_resident.py [--frames 600]
+    python tests/tools/bench_cfg3_resident.py [--frames 600]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ import pathlib
 import sys
 import time
 
-ROOT = pathlib.Path(__file__).resolve().parent.parent
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "360cam-pgm-3dgs-tools_amd"))
 sys.path.insert(0, str(ROOT / "tests"))

@@ -2,7 +2,7 @@
 """Secondary measurements: the other BASELINE.json configs (device-resident, HIP-event timed, parity-checked on one
 view each).  Informational -- bench.py (cfg2) is the headline.  Prints one JSON object per config.
 
-    python scripts/bench_configs.py [--steps 50]
+    python tests/tools/bench_configs.py [--steps 50]
 """
 import argparse
 import json
@@ -10,7 +10,7 @@ import pathlib
 import sys
 import time
 
-ROOT = pathlib.Path(__file__).resolve().parent.parent
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "360cam-pgm-3dgs-tools_amd"))
 sys.path.insert(0, str(ROOT / "tests"))

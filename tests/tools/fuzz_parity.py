@@ -3,7 +3,7 @@
 channel counts, views, maps and interpolation modes.  Bit-exact uint8 is the bar; the first mismatch is printed with
 the seed that reproduces it and the exit code is 1.
 
-    python scripts/fuzz_parity.py --seconds 120 [--seed 1]
+    python tests/tools/fuzz_parity.py --seconds 120 [--seed 1]
 """
 import argparse
 import ctypes as C
@@ -11,7 +11,7 @@ import pathlib
 import sys
 import time
 
-ROOT = pathlib.Path(__file__).resolve().parent.parent
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "360cam-pgm-3dgs-tools_amd"))
 

@@ -2,7 +2,7 @@
 # CPU-only sanitizer pass over the oracle (GPU ASan is unavailable on the pool): builds the ASan+UBSan variant and
 # drives every exported function once through ctypes.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 make -C oracle asan >/dev/null
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
 python - <<'PY'
