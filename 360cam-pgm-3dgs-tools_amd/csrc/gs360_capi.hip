@@ -483,34 +483,58 @@ int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, 
 }
 
 // ---- table remap -------------------------------------------------------------------------------
-int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, size_t src_stride, const float* map_x,
-                         const float* map_y, const uint8_t* valid, int h, int w, int interp,
-                         const double* border_value, int fill_value, void* dst, size_t dst_stride, int slot) {
+namespace {
+
+int fill_table_job(gs360_ctx* c, const gs360_remap_job& J, int C, int interp, const double* border_value, TableLaunch* L) {
+    if (!J.src || !J.map_x || !J.map_y || !J.dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (J.H < 1 || J.W < 1 || J.H >= 32767 || J.W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", J.W, J.H);
+    if (J.h < 0 || J.w < 0 || J.h >= 32767 || J.w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", J.w, J.h);
+    size_t src_stride = J.src_stride ? J.src_stride : (size_t)J.W * C;
+    size_t dst_stride = J.dst_stride ? J.dst_stride : (size_t)J.w * C;
+    if (src_stride < (size_t)J.W * C || dst_stride < (size_t)J.w * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
+    std::memset(L, 0, sizeof(*L));
+    L->src = (const uint8_t*)J.src; L->map_x = J.map_x; L->map_y = J.map_y; L->valid = J.valid; L->dst = (uint8_t*)J.dst;
+    L->H = J.H; L->W = J.W; L->h = J.h; L->w = J.w;
+    L->src_stride = (int64_t)src_stride; L->dst_stride = (int64_t)dst_stride;
+    L->interp = interp;
+    L->fill = J.fill_value < 0 ? 0 : (J.fill_value > 255 ? 255 : J.fill_value);
+    for (int k = 0; k < 4; ++k) L->cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
+    L->cubic_tab = interp == GS360_INTERP_LANCZOS4 ? c->d_lanczos : c->d_cubic;
+    L->pipelined = (J.W >= 8 && src_stride < ((size_t)1 << 24) && (uint64_t)src_stride * (uint64_t)J.H < ((uint64_t)1 << 32)) ? 1 : 0;
+    return 0;
+}
+
+}  // namespace
+
+int gs360_remap_tables_u8(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs, int C, int interp,
+                          const double* border_value, int slot) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
-    if (!src || !map_x || !map_y || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(GS360_ERR_ARG, "bad job list");
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
-    if (H < 1 || W < 1 || H >= 32767 || W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", W, H);
-    if (h < 0 || w < 0 || h >= 32767 || w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", w, h);
-    if (h == 0 || w == 0) return GS360_OK;
     if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC &&
         interp != GS360_INTERP_LANCZOS4)
         return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2, lanczos4=4)", interp);
-    if (src_stride == 0) src_stride = (size_t)W * C;
-    if (dst_stride == 0) dst_stride = (size_t)w * C;
-    if (src_stride < (size_t)W * C || dst_stride < (size_t)w * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
     HIP_TRY(hipSetDevice(c->device));
-    TableLaunch L;
-    std::memset(&L, 0, sizeof(L));
-    L.src = (const uint8_t*)src; L.map_x = map_x; L.map_y = map_y; L.valid = valid; L.dst = (uint8_t*)dst;
-    L.H = H; L.W = W; L.h = h; L.w = w;
-    L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
-    L.interp = interp;
-    L.fill = fill_value < 0 ? 0 : (fill_value > 255 ? 255 : fill_value);
-    for (int k = 0; k < 4; ++k) L.cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
-    L.cubic_tab = interp == GS360_INTERP_LANCZOS4 ? c->d_lanczos : c->d_cubic;
-    L.pipelined = (W >= 8 && src_stride < ((size_t)1 << 24) && (uint64_t)src_stride * (uint64_t)H < ((uint64_t)1 << 32)) ? 1 : 0;
-    HIP_TRY(launch_table(L, C, c->stream[slot]));
+    for (int j0 = 0; j0 < n_jobs; j0 += GS360_MAX_VIEWS) {
+        TableBatch B;
+        B.n_jobs = 0;
+        for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
+            if (jobs[j].h == 0 || jobs[j].w == 0) continue;
+            if (int rc = fill_table_job(c, jobs[j], C, interp, border_value, &B.job[B.n_jobs])) return rc;
+            ++B.n_jobs;
+        }
+        if (B.n_jobs) HIP_TRY(launch_table_batch(B, C, c->stream[slot]));
+    }
     return GS360_OK;
+}
+
+int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                         const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                         const double* border_value, int fill_value, void* dst, size_t dst_stride, int slot) {
+    gs360_remap_job J;
+    J.src = src; J.H = H; J.W = W; J.src_stride = src_stride; J.map_x = map_x; J.map_y = map_y; J.valid = valid;
+    J.h = h; J.w = w; J.fill_value = fill_value; J.dst = dst; J.dst_stride = dst_stride;
+    return gs360_remap_tables_u8(c, &J, 1, C, interp, border_value, slot);
 }
 
 // ---- fused fisheye -> views --------------------------------------------------------------------

@@ -69,6 +69,14 @@ struct TableLaunch {
     uint8_t cval[4];
     const int16_t* cubic_tab;
     int32_t pipelined;   // W >= 8 and 32-bit tap offsets: split fetch/blend path allowed
+    int32_t tiles_x;     // filled by launch_table_batch
+    int32_t tile_base;   // first tile of this job inside the batched launch
+};
+
+// One launch for several remaps (e.g. the views of a dual-fisheye pair): no per-view launch tails.
+struct TableBatch {
+    TableLaunch job[GS360_MAX_VIEWS];
+    int32_t n_jobs, total_tiles, chunk;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -86,8 +94,8 @@ struct FeView {
     int32_t tiles_x, tiles_y, tile_base;
 };
 
-struct FeCommon {          // per-launch constants of fe_views_kernel (one launch per view)
-    int32_t total_tiles, chunk;
+struct FeCommon {          // per-launch constants of fe_views_kernel
+    int32_t total_tiles, chunk, n_views;
     int32_t interp, mask_outside, mask_value;
     int64_t src_stride, dst_stride;
     uint8_t cval[4];
@@ -95,7 +103,12 @@ struct FeCommon {          // per-launch constants of fe_views_kernel (one launc
     int32_t pipelined;
 };
 
-struct FeLaunch {          // host-side batch description; launch_fisheye() issues one kernel per view
+struct FeBatch {           // kernel argument: all views of one launch + the common block
+    FeView view[GS360_MAX_VIEWS];
+    FeCommon common;
+};
+
+struct FeLaunch {          // host-side batch description
     FeView view[GS360_MAX_VIEWS];
     int32_t n_views, total_tiles, chunk;
     int32_t interp, mask_outside, mask_value;
@@ -129,6 +142,7 @@ hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s);
+hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s);   // all jobs share C and interp (job[0].interp)
 hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s);
 
 }  // namespace gs360

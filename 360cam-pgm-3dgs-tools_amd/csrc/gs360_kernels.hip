@@ -908,10 +908,15 @@ __device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out
 // One instantiation per interpolation: the 8x8 Lanczos window would otherwise set the register budget (and with it the
 // occupancy) of the bilinear path.
 template <int C, int INTERP>
-__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLaunch L, int tiles_x, int total_tiles, int chunk) {
+__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBatch B) {
     int b = blockIdx.x;
-    int t = (b & 7) * chunk + (b >> 3);
-    if (t >= total_tiles) return;
+    int t = (b & 7) * B.chunk + (b >> 3);
+    if (t >= B.total_tiles) return;
+    int j = 0;
+    while (j + 1 < B.n_jobs && t >= B.job[j + 1].tile_base) ++j;
+    const TableLaunch& L = B.job[j];          // wave-uniform: fields are read from the kernel argument on demand
+    t -= L.tile_base;
+    const int tiles_x = L.tiles_x;
     int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = tile_x * kTileW;
@@ -977,14 +982,19 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableLau
 // ------------------------------------------------------------------------------------------------
 // FE-SPEC v1: fused fisheye -> perspective
 // ------------------------------------------------------------------------------------------------
-// One launch per view: the view block travels as a plain by-value kernel argument (SGPR-resident).  Indexing an
-// array of these 148-byte blocks dynamically made the compiler spill the whole argument struct to scratch
-// (2368 B/lane, 13x slower), so the host loops over views instead.
+// All views of a call in one launch.  The view block is used through a REFERENCE into the by-value kernel argument
+// (scalar loads on demand): copying a dynamically indexed 148-byte block into a local made the compiler spill the whole
+// argument array to scratch (2368 B/lane, 13x slower).
 template <int C, int INTERP>
-__global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeView V, const FeCommon L) {
+__global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) {
+    const FeCommon& L = B.common;
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
     if (t >= L.total_tiles) return;
+    int j = 0;
+    while (j + 1 < L.n_views && t >= B.view[j + 1].tile_base) ++j;
+    const FeView& V = B.view[j];              // a reference: fields are fetched from the kernel argument on demand
+    t -= V.tile_base;
     int tile_y = t / V.tiles_x, tile_x = t - tile_y * V.tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = tile_x * kTileW;
@@ -1091,61 +1101,81 @@ hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
 namespace {
 
 template <int C>
-void launch_table_c(const TableLaunch& L, dim3 grid, dim3 block, hipStream_t s, int tiles_x, int total, int chunk) {
-    switch (L.interp) {
-        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, L, tiles_x, total, chunk); break;
-        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, L, tiles_x, total, chunk); break;
-        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, L, tiles_x, total, chunk); break;
-        default: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, L, tiles_x, total, chunk); break;
+void launch_table_c(const TableBatch& B, dim3 grid, dim3 block, hipStream_t s) {
+    switch (B.job[0].interp) {
+        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, B); break;
+        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, B); break;
+        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, B); break;
+        default: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, B); break;
     }
 }
 
 template <int C>
-void launch_fisheye_c(const FeView& V, const FeCommon& K, dim3 grid, dim3 block, hipStream_t s) {
-    switch (K.interp) {
-        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, V, K); break;
-        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, V, K); break;
-        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, V, K); break;
-        default: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, V, K); break;
+void launch_fisheye_c(const FeBatch& B, dim3 grid, dim3 block, hipStream_t s) {
+    switch (B.common.interp) {
+        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, B); break;
+        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, B); break;
+        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, B); break;
+        default: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, B); break;
     }
 }
 
 }  // namespace
 
-hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
-    int tiles_x = (L.w + kTileW - 1) / kTileW, tiles_y = (L.h + kTileH - 1) / kTileH;
-    int total = tiles_x * tiles_y, chunk = (total + 7) / 8;
-    dim3 grid((unsigned)(chunk * 8)), block(64 * kWaves);
+hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s) {
+    int base = 0;
+    for (int j = 0; j < B.n_jobs; ++j) {
+        TableLaunch& L = B.job[j];
+        L.tiles_x = (L.w + kTileW - 1) / kTileW;
+        L.tile_base = base;
+        base += L.tiles_x * ((L.h + kTileH - 1) / kTileH);
+    }
+    B.total_tiles = base;
+    B.chunk = (base + 7) / 8;
+    if (base == 0) return hipSuccess;
+    dim3 grid((unsigned)(B.chunk * 8)), block(64 * kWaves);
     switch (C) {
-        case 1: launch_table_c<1>(L, grid, block, s, tiles_x, total, chunk); break;
-        case 3: launch_table_c<3>(L, grid, block, s, tiles_x, total, chunk); break;
-        case 4: launch_table_c<4>(L, grid, block, s, tiles_x, total, chunk); break;
+        case 1: launch_table_c<1>(B, grid, block, s); break;
+        case 3: launch_table_c<3>(B, grid, block, s); break;
+        case 4: launch_table_c<4>(B, grid, block, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
+hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
+    TableBatch B;
+    B.job[0] = L;
+    B.n_jobs = 1;
+    return launch_table_batch(B, C, s);
+}
+
 hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s) {
+    FeBatch B;
+    int base = 0;
     for (int k = 0; k < L.n_views; ++k) {
-        FeCommon K;
-        K.total_tiles = L.view[k].tiles_x * L.view[k].tiles_y;
-        K.chunk = (K.total_tiles + 7) / 8;
-        K.interp = L.interp; K.mask_outside = L.mask_outside; K.mask_value = L.mask_value;
-        K.src_stride = L.src_stride; K.dst_stride = L.dst_stride;
-        for (int i = 0; i < 4; ++i) K.cval[i] = L.cval[i];
-        K.cubic_tab = L.cubic_tab;
-        K.pipelined = L.pipelined;
-        dim3 grid((unsigned)(K.chunk * 8)), block(64 * kWaves);
-        switch (C) {
-            case 1: launch_fisheye_c<1>(L.view[k], K, grid, block, s); break;
-            case 3: launch_fisheye_c<3>(L.view[k], K, grid, block, s); break;
-            case 4: launch_fisheye_c<4>(L.view[k], K, grid, block, s); break;
-            default: return hipErrorInvalidValue;
-        }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        B.view[k] = L.view[k];
+        B.view[k].tile_base = base;
+        base += L.view[k].tiles_x * L.view[k].tiles_y;
     }
-    return hipSuccess;
+    FeCommon& K = B.common;
+    K.n_views = L.n_views;
+    K.total_tiles = base;
+    K.chunk = (base + 7) / 8;
+    K.interp = L.interp; K.mask_outside = L.mask_outside; K.mask_value = L.mask_value;
+    K.src_stride = L.src_stride; K.dst_stride = L.dst_stride;
+    for (int i = 0; i < 4; ++i) K.cval[i] = L.cval[i];
+    K.cubic_tab = L.cubic_tab;
+    K.pipelined = L.pipelined;
+    if (base == 0) return hipSuccess;
+    dim3 grid((unsigned)(K.chunk * 8)), block(64 * kWaves);
+    switch (C) {
+        case 1: launch_fisheye_c<1>(B, grid, block, s); break;
+        case 3: launch_fisheye_c<3>(B, grid, block, s); break;
+        case 4: launch_fisheye_c<4>(B, grid, block, s); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 }  // namespace gs360

@@ -25,7 +25,7 @@ EXPORTS = (
     "gs360_device_info", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
     "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_sync", "gs360_event_record",
     "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_equirect_views_masked_u8", "gs360_remap_table_u8",
-    "gs360_fisheye_views_u8",
+    "gs360_fisheye_views_u8", "gs360_remap_tables_u8",
     "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
 )
@@ -56,6 +56,13 @@ class Calib(C.Structure):
     @classmethod
     def make(cls, width, height, f, cx=0.0, cy=0.0, k1=0.0, k2=0.0, k3=0.0, k4=0.0, p1=0.0, p2=0.0, b1=0.0, b2=0.0):
         return cls(int(width), int(height), *[float(v) for v in (f, cx, cy, k1, k2, k3, k4, p1, p2, b1, b2)])
+
+
+class RemapJob(C.Structure):
+    """gs360_remap_job: one cv2.remap call of a batched launch (device pointers)."""
+    _fields_ = [("src", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("src_stride", C.c_size_t),
+                ("map_x", C.c_void_p), ("map_y", C.c_void_p), ("valid", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32),
+                ("fill_value", C.c_int32), ("dst", C.c_void_p), ("dst_stride", C.c_size_t)]
 
 
 _lib = None
@@ -96,6 +103,7 @@ def load_library(path=None):
         L.gs360_remap_table_u8.argtypes = [vp, vp, i, i, i, sz, vp, vp, vp, i, i, i, C.POINTER(C.c_double), i, vp, sz, i]
         L.gs360_fisheye_views_u8.argtypes = [vp, pvp, C.POINTER(Calib), i, sz, C.POINTER(View), i, C.c_double, i, i, i,
                                              pvp, sz, pvp, i]
+        L.gs360_remap_tables_u8.argtypes = [vp, C.POINTER(RemapJob), i, i, i, C.POINTER(C.c_double), i]
         L.gs360_color_plan_create.argtypes = [vp, vp, i, vp, vp, pvp]
         L.gs360_color_plan_destroy.argtypes = [vp, vp]
         L.gs360_color_apply_u8.argtypes = [vp, vp, vp, i, i, i, sz, i, vp, sz, i]
@@ -286,6 +294,15 @@ class Context:
         _check(self.L.gs360_remap_table_u8(self.handle, src.ptr, H, W, Cn, 0, map_x.ptr, map_y.ptr,
                                            valid.ptr if valid is not None else None, h, w, interp, bv,
                                            int(fill_value), dst.ptr, 0, slot), self.L)
+
+    def remap_tables_dev(self, jobs, Cn, interp=INTERP_LINEAR, border_value=(0, 0, 0, 0), slot=0):
+        """Several remaps in one launch.  jobs: iterable of (src, H, W, map_x, map_y, valid_or_None, h, w, fill_value, dst)
+        with DeviceBuffer objects for src / maps / valid / dst."""
+        arr = (RemapJob * len(jobs))()
+        for k, (src, H, W, mx, my, valid, h, w, fill, dst) in enumerate(jobs):
+            arr[k] = RemapJob(src.ptr, H, W, 0, mx.ptr, my.ptr, valid.ptr if valid is not None else None, h, w, int(fill), dst.ptr, 0)
+        bv = (C.c_double * 4)(*[float(x) for x in border_value])
+        _check(self.L.gs360_remap_tables_u8(self.handle, arr, len(jobs), Cn, interp, bv, slot), self.L)
 
     def fisheye_views_dev(self, lens_bufs, calibs, Cn, views, lens_fov_deg, dsts, valid_outs=None,
                           interp=INTERP_LINEAR, mask_outside=True, mask_value=0, slot=0):

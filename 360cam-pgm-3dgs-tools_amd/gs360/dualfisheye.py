@@ -60,6 +60,36 @@ class PairRenderer:
                                  fill_value=valid_fill if valid_fill is not None else 0, slot=0)
         return self.ctx.download(self._scratch, (h, w, C), slot=0)
 
+    def _remap_views(self, dev, imgs, dmask, interp, border, valid_fill):
+        """All views of the pair in ONE batched launch (no per-view launch tails), then the downloads.  `dmask` set:
+        the per-lens mask images are the sources (DF:2031-2043), else the lens images."""
+        jobs, shapes, bufs = [], [], []
+        for spec in self.specs:
+            vid = str(spec["view_id"])
+            key = self.tables[vid]["lens_key"]
+            if dmask is not None:
+                if key not in dmask:
+                    raise RuntimeError("Mask source missing for lens {}".format(key))
+                d_src, (H, W, C) = dmask[key]
+            else:
+                d_src, (H, W, C) = dev[key], imgs[key].shape
+            h, w = int(spec["height"]), int(spec["width"])
+            d_dst = self.ctx.alloc(h * w * C)
+            bufs.append(d_dst)
+            mx, my, va = self.dev_tables[vid]
+            jobs.append((d_src, H, W, mx, my, va if valid_fill is not None else None, h, w,
+                         valid_fill if valid_fill is not None else 0, d_dst))
+            shapes.append((vid, (h, w, C)))
+        try:
+            channels = {s[1][2] for s in shapes}
+            if len(channels) != 1:
+                raise RuntimeError("the two lens images differ in channel count")
+            self.ctx.remap_tables_dev(jobs, channels.pop(), interp=interp, border_value=border, slot=0)
+            return {vid: self.ctx.download(b, shape, slot=0) for (vid, shape), b in zip(shapes, bufs)}
+        finally:
+            for b in bufs:
+                self.ctx.free(b)
+
     def render_pair(self, image_x: np.ndarray, image_y: np.ndarray, sensor_id_x: str, sensor_id_y: str, *,
                     interpolation: int, mask_outside_model: bool, mask_value: int,
                     mask_x: Optional[np.ndarray] = None, mask_y: Optional[np.ndarray] = None,
@@ -106,23 +136,12 @@ class PairRenderer:
                     if self.fused:
                         self._render_fused(out, imgs, dev, sensor_id_x, sensor_id_y, interp, mask_outside_model, mask_value)
                     else:
-                        for spec in self.specs:
-                            vid = str(spec["view_id"])
-                            key = self.tables[vid]["lens_key"]
-                            hw = (int(spec["height"]), int(spec["width"]))
-                            out["perspective"][vid] = self._remap(dev[key], imgs[key].shape, self.dev_tables[vid], hw,
-                                                                  interp, border, fill)
-                    for spec in self.specs if dmask else ():
-                        vid = str(spec["view_id"])
-                        key = self.tables[vid]["lens_key"]
-                        if key not in dmask:
-                            raise RuntimeError("Mask source missing for lens {}".format(key))
-                        d_m, mshape = dmask[key]
-                        hw = (int(spec["height"]), int(spec["width"]))
+                        out["perspective"] = self._remap_views(dev, imgs, None, interp, border, fill)
+                    if dmask:
                         if self.fused:   # masks always go through the table path (nearest, border 0, invalid -> 0)
                             raise RuntimeError("mask rendering needs table mode")
-                        out["masks"][vid] = self._remap(d_m, mshape, self.dev_tables[vid], hw, capi.INTERP_NEAREST,
-                                                        (0.0, 0.0, 0.0, 0.0), 0 if mask_outside_model else None)
+                        out["masks"] = self._remap_views(None, None, dmask, capi.INTERP_NEAREST, (0.0, 0.0, 0.0, 0.0),
+                                                         0 if mask_outside_model else None)
             finally:
                 for b in dev.values():
                     self.ctx.free(b)

@@ -139,6 +139,26 @@ int gs360_remap_table_u8(gs360_ctx *ctx, const void *src, int H, int W, int C, s
                          void *dst, size_t dst_stride, int slot);
 
 /*
+ * Several remaps in ONE launch (the 10 views of a dual-fisheye pair, DF:1993-2043: one cv2.remap per view): same
+ * semantics per job as gs360_remap_table_u8, common channel count / interpolation / border value.  A batched launch
+ * has no per-view launch tails (cfg4: -16 %).  n_jobs may exceed GS360_MAX_VIEWS (split internally).
+ */
+typedef struct gs360_remap_job {
+    const void *src;        /* H x W x C */
+    int32_t H, W;
+    size_t src_stride;      /* 0 = tight */
+    const float *map_x;     /* h x w */
+    const float *map_y;
+    const uint8_t *valid;   /* h x w or NULL */
+    int32_t h, w;
+    int32_t fill_value;     /* written where valid == 0 */
+    void *dst;              /* h x w x C */
+    size_t dst_stride;      /* 0 = tight */
+} gs360_remap_job;
+int gs360_remap_tables_u8(gs360_ctx *ctx, const gs360_remap_job *jobs, int n_jobs, int C, int interp,
+                          const double *border_value, int slot);
+
+/*
  * Dual-fisheye -> perspective views with the map evaluated in-kernel (FE-SPEC v1).  View k samples
  * src_lens[k] (H x W x C of calibs[k]) with views[k].yaw_deg measured RELATIVE to that lens
  * (DF:1883).  Pixels outside the lens model / sensor get mask_value on all channels when

@@ -204,6 +204,38 @@ def test_table_remap_random_maps(ctx, orc, channels, interp):
     _assert_same([got.reshape(h, w, channels)], [want.reshape(h, w, channels)], f"table C={channels} interp={interp}")
 
 
+def test_table_remap_batched_jobs(ctx, orc):
+    """gs360_remap_tables_u8: 19 jobs (more than one launch's 16) of different sizes, two sources, empty map included"""
+    rng = np.random.default_rng(23)
+    srcs = [rand_image(90, 120, seed=1), rand_image(33, 260, seed=2)]
+    d_srcs = [ctx.to_device(s) for s in srcs]
+    jobs, want, keep = [], [], []
+    for k in range(19):
+        si = k % 2
+        H, W, _ = srcs[si].shape
+        h, w = (0, 5) if k == 7 else (int(rng.integers(1, 70)), int(rng.integers(1, 150)))
+        mx = rng.uniform(-6, W + 6, (h, w)).astype(np.float32)
+        my = rng.uniform(-6, H + 6, (h, w)).astype(np.float32)
+        valid = (rng.random((h, w)) > 0.3) if k % 3 else None
+        fill = int(rng.integers(0, 256))
+        d = (ctx.to_device(mx) if h else ctx.alloc(4), ctx.to_device(my) if h else ctx.alloc(4),
+             ctx.to_device(np.ascontiguousarray(valid, np.uint8)) if valid is not None and h else None, ctx.alloc(max(h * w * 3, 4)))
+        keep.append(d)
+        jobs.append((d_srcs[si], H, W, d[0], d[1], d[2], h, w, fill, d[3]))
+        ref = orc.remap_u8(srcs[si], mx, my, interp=1, border_value=(9, 8, 7, 0)) if h else np.zeros((0, w, 3), np.uint8)
+        want.append(orc.valid_fill(ref.copy(), valid, fill) if valid is not None and h else ref)
+    ctx.remap_tables_dev(jobs, 3, interp=1, border_value=(9, 8, 7, 0))
+    for k, (job, w_) in enumerate(zip(jobs, want)):
+        if job[6]:
+            assert np.array_equal(ctx.download(job[9], w_.shape), w_), k
+    for d in keep:
+        for b in d:
+            if b is not None:
+                ctx.free(b)
+    for b in d_srcs:
+        ctx.free(b)
+
+
 def test_table_remap_gray_2d_and_scalar_border(ctx, orc):
     src = rand_image(64, 80, c=1, seed=31)[:, :, 0]
     mx, my = _rand_maps(50, 44, 64, 80, seed=32)

@@ -95,12 +95,11 @@ def fisheye_cfg(ctx, steps):
              for v, t in tables.items()}
     d_out = {v: ctx.alloc(1750 * 1750 * 3) for v in tables}
 
-    def table_call():
-        for spec in specs:
-            v = spec["view_id"]
-            t = tables[v]
-            ctx.remap_table_dev(dev[t["lens_key"]], 4000, 4000, 3, d_tab[v][0], d_tab[v][1], d_tab[v][2], 1750, 1750, d_out[v],
-                                interp=1, border_value=(0, 0, 0, 0), fill_value=0, slot=0)
+    jobs = [(dev[tables[s["view_id"]]["lens_key"]], 4000, 4000) + tuple(d_tab[s["view_id"]]) + (1750, 1750, 0, d_out[s["view_id"]])
+            for s in specs]
+
+    def table_call():          # the six views of the pair in one batched launch (gs360_remap_tables_u8)
+        ctx.remap_tables_dev(jobs, 3, interp=1, border_value=(0, 0, 0, 0), slot=0)
     ms = time_steps(ctx, table_call, steps)
     v0 = specs[1]["view_id"]
     t = tables[v0]
