@@ -157,7 +157,7 @@ class VideoSession:
         self.plan = plan
         self.stop_event = stop_event
         self.register_proc = register_proc       # callable(proc, add: bool): lets the caller's cancel handler see the decoder
-        self.budget = budget
+        self.budget = budget * max(1, len(states))    # the budget is per device; frames are dealt round-robin
         self.frames = []                          # (state, DeviceBuffer, H, W)
         self.bytes = 0
         self.finished = False
@@ -192,8 +192,9 @@ class VideoSession:
                     raise PpmError("decoder delivered {}-level samples; the engine is 8-bit".format(maxval + 1))
                 nbytes = w * h * 3
                 if self.bytes + nbytes > self.budget:
-                    raise PpmError("decoded frames exceed the HBM budget of {:.0f} GB (GS360_VIDEO_CACHE_GB); lower --fps, "
-                                   "cut the range with --start/--end, or use --engine ffmpeg".format(self.budget / (1 << 30)))
+                    raise PpmError("decoded frames exceed the HBM budget of {:.0f} GB per GPU (GS360_VIDEO_CACHE_GB); lower "
+                                   "--fps, cut the range with --start/--end, or use --engine ffmpeg".format(
+                                       self.budget / len(self.states) / (1 << 30)))
                 st = self.states[k % len(self.states)]
                 stage = pinned.get((id(st), nbytes))
                 if stage is None:
