@@ -12,8 +12,8 @@ What changed underneath: run_one() no longer spawns one single-threaded `ffmpeg 
 (source, view) (reference :569-590).  It parses the ffmpeg-shaped job argv and executes equirect->rectilinear
 jobs in-process on the GPU through libgs360hip.so (hand-written HIP, gfx950).  Video inputs are decoded ONCE per
 video by a single ffmpeg process feeding device memory; every view job then samples the HBM-resident frames
-(gs360/video.py) instead of decoding the video again.  Jobs the engine does not cover (the fisheyeXY equisolid output,
-16-bit output) and `--engine ffmpeg` / GS360_ENGINE=ffmpeg keep the reference's subprocess path.
+(gs360/video.py) instead of decoding the video again.  The `fisheyeXY` preset's `output=fisheye` jobs run on the GPU too.
+Jobs the engine does not cover (16-bit output, other v360 projections) and `--engine ffmpeg` / GS360_ENGINE=ffmpeg keep the reference's subprocess path.
 """
 import argparse
 import json
@@ -222,8 +222,8 @@ def run_one(cmd: List[str]) -> Tuple[int, str]:
         job = parse_job_argv(list(cmd))
     except JobParseError as exc:
         return 2, f"gs360: cannot interpret job argv: {exc}"
-    if job.output_projection != "rectilinear":
-        return _run_subprocess(cmd)          # the equisolid pair (fisheyeXY) stays on the reference path
+    if job.output_projection not in ("rectilinear", "fisheye"):
+        return _run_subprocess(cmd)          # anything else v360 can do stays on the reference path
     plan = None
     if not job.is_still_image:
         # video: one shared decoder process + HBM-resident frames (gs360/video.py); argv shapes it does not

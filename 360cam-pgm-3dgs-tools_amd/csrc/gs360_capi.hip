@@ -80,7 +80,7 @@ int ensure(gs360_ctx* ctx, void** p, size_t* cap, size_t need) {
 double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // EQ-SPEC v1 per-view constants.  Convention: gs360_GUI.py:377-395 / :419-424 of the reference.
-void make_eq_view(const gs360_view& v, int W, EqView* o) {
+void make_eq_view(const gs360_view& v, int W, bool fisheye_out, EqView* o) {
     double hf = clampd(v.hfov_deg, 1e-3, 179.9) * kPi / 180.0;
     double vf = clampd(v.vfov_deg, 1e-3, 179.9) * kPi / 180.0;
     o->sxu = (float)(std::tan(hf * 0.5) / (double)v.width);
@@ -110,6 +110,15 @@ void make_eq_view(const gs360_view& v, int W, EqView* o) {
     if (const char* e = std::getenv("GS360_LANEMAP")) {
         if (!std::strcmp(e, "rows")) o->blocked = 0;
         else if (!std::strcmp(e, "blocked")) o->blocked = 1;
+    }
+    o->fish = 0;
+    if (fisheye_out) {   // image-plane radius 1 <-> 90 degrees off axis; hfov/vfov = full field of view of the fisheye image
+        o->fish = 1;
+        o->sxu = (float)(clampd(v.hfov_deg, 1e-3, 360.0) / 180.0 / (double)v.width);
+        o->syv = (float)(clampd(v.vfov_deg, 1e-3, 360.0) / 180.0 / (double)v.height);
+        o->level = 0;
+        o->blocked = 0;
+        o->tiles_y = (v.height + kTileH - 1) / kTileH;
     }
     const int half_w = (v.width + 1) / 2;
     o->tiles_x = (half_w + kTileW - 1) / kTileW;
@@ -424,7 +433,7 @@ int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, 
         return fail(GS360_ERR_ARG, "bad source size %dx%d (an equirect frame is at least 8 texels wide)", W, H);
     if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_CUBIC)
         return fail(GS360_ERR_UNSUPPORTED, "equirect path implements INTER_LINEAR (1) and INTER_CUBIC (2), got %d", interp);
-    if (flags != 0) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
+    if (flags & ~(uint32_t)GS360_EQ_FISHEYE_OUT) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
     if (src_stride == 0) src_stride = (size_t)W * C;
     if (src_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "src_stride smaller than a row");
     if (src_stride >= ((size_t)1 << 24) || (uint64_t)src_stride * (uint64_t)H >= ((uint64_t)1 << 32))
@@ -451,7 +460,7 @@ int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, 
             std::memset(&L, 0, sizeof(L));
             int base = 0;
             for (int k = 0; k < nv; ++k) {
-                make_eq_view(views[v0 + k], W, &L.view[k]);
+                make_eq_view(views[v0 + k], W, (flags & GS360_EQ_FISHEYE_OUT) != 0, &L.view[k]);
                 L.view[k].tile_base = base;
                 base += L.view[k].tiles_x * L.view[k].tiles_y;
             }

@@ -34,6 +34,7 @@ struct EqView {
     int32_t tiles_x, tiles_y;
     int32_t tile_base;   // first tile index of this view inside one frame
     int32_t level;       // pitch == 0 exactly (sp == 0, cp == 1): horizon-symmetric fast path
+    int32_t fish;        // equidistant-fisheye output (GS360_EQ_FISHEYE_OUT): sxu/syv = fov/180/size, general row path
     int32_t blocked;     // RGB bilinear only: 4-row x 16-column gather patches instead of 64-pixel rows (strong minification)
 };
 

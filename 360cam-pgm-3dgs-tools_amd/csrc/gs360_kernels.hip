@@ -335,6 +335,21 @@ __device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, 
         out[c] = blend(r0[ix * C + c], r0[ix1 * C + c], r1[ix * C + c], r1[ix1 * C + c], w00, w01, w10, w11);
 }
 
+// Equidistant-fisheye output: S(q) = sin(pi r/2)/r and C(q) = cos(pi r/2) as degree-8 polynomials in q = r^2 on [0, 4]
+// (same coefficients and Horner order as the oracle).
+__device__ __constant__ const float kEqFishS[9] = {1.5707963705062866f, -0.6459640860557556f, 0.07969262450933456f,
+                                                   -0.004681753925979137f, 0.0001604411081643775f, -3.598792090997449e-06f,
+                                                   5.689994608815141e-08f, -6.633614213491512e-10f, 5.326020006968246e-12f};
+__device__ __constant__ const float kEqFishC[9] = {1.0f, -1.2337005138397217f, 0.25366950035095215f, -0.020863480865955353f,
+                                                   0.0009192594443447888f, -2.5201432436006144e-05f, 4.708266487796209e-07f,
+                                                   -6.321354106830768e-09f, 5.675555858619674e-11f};
+__device__ __forceinline__ float eq_poly8(const float* k, float q) {
+    float p = k[8];
+#pragma unroll
+    for (int n = 7; n >= 0; --n) p = __builtin_fmaf(p, q, k[n]);
+    return p;
+}
+
 // quantised longitude coordinate (1/32 px, wrapped to [0, 32W))
 __device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, const EqView& V) {
     int sx = (int)__builtin_rintf(__builtin_fmaf(r0, L.kx32, V.x0f32)) + V.x0i32 + K * 4 * L.W;
@@ -669,12 +684,22 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         } else {
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s) {
-            const float yv = (float)(2 * ys[s] + 1 - V.out_h) * V.syv;
-            const float bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
-            const float cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
-            const float h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
+            float yv = (float)(2 * ys[s] + 1 - V.out_h) * V.syv;
+            float xr = x, bz, cy;
+            if (V.fish) {      // wave-uniform: equidistant-fisheye output (EQ-SPEC v1 projection F), ray = (u S, v S, C)
+                const float q = __builtin_fmaf(x, x, yv * yv);
+                const float S = eq_poly8(kEqFishS, q), Cz = eq_poly8(kEqFishC, q);
+                xr = x * S;
+                yv = yv * S;
+                bz = __builtin_fmaf(V.sp, yv, V.cp * Cz);
+                cy = __builtin_fmaf(-V.cp, yv, V.sp * Cz);
+            } else {
+                bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
+                cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
+            }
+            const float h = __builtin_sqrtf(__builtin_fmaf(xr, xr, bz * bz));
             int Kl, Kt;
-            const float rl = eq_atan2_red(x, bz, Kl);
+            const float rl = eq_atan2_red(xr, bz, Kl);
             const float rt = eq_atan2_red(cy, h, Kt);
             sxl[s] = eq_quant_lon(rl, Kl, L, V);
             sxm[s] = eq_quant_lon(-rl, -Kl, L, V);

@@ -17,6 +17,7 @@ INTERP_NEAREST = 0  # == cv2.INTER_NEAREST
 INTERP_LINEAR = 1   # == cv2.INTER_LINEAR
 INTERP_CUBIC = 2    # == cv2.INTER_CUBIC
 INTERP_LANCZOS4 = 4  # == cv2.INTER_LANCZOS4 (table remap / fused fisheye only)
+EQ_FISHEYE_OUT = 1   # flags: the views are equidistant-fisheye outputs (v360 output=fisheye), see include/gs360.h
 MAX_VIEWS = 16
 MAX_FRAMES = 16
 
@@ -256,7 +257,7 @@ class Context:
 
     # -- hot path, device-resident ----------------------------------------------------------
     def equirect_views_dev(self, frames, W, H, Cn, views, dsts, slot=0, src_stride=0, dst_stride=0,
-                           interp=INTERP_LINEAR, masks=None):
+                           interp=INTERP_LINEAR, masks=None, flags=0):
         """frames: list of DeviceBuffer (H x W x C); dsts: list (len frames*views) of DeviceBuffer;
         masks: optional list of DeviceBuffer (H x W u8 keep-masks, one per frame) fused into the output."""
         nf, nv = len(frames), len(views)
@@ -268,10 +269,10 @@ class Context:
                 raise ValueError("one mask per frame")
             mp = (C.c_void_p * max(nf, 1))(*[b.ptr for b in masks])
             _check(self.L.gs360_equirect_views_masked_u8(self.handle, fp, mp, nf, W, H, Cn, src_stride, 0, va, nv, dp,
-                                                         dst_stride, interp, 0, slot), self.L)
+                                                         dst_stride, interp, int(flags), slot), self.L)
             return
         _check(self.L.gs360_equirect_views_u8(self.handle, fp, nf, W, H, Cn, src_stride, va, nv, dp, dst_stride,
-                                              interp, 0, slot), self.L)
+                                              interp, int(flags), slot), self.L)
 
     def make_equirect_call(self, frames, W, H, Cn, views, dsts, slot=0, interp=INTERP_LINEAR, src_stride=0):
         """Pre-marshal one batched launch; returns a zero-argument callable (used by bench loops)."""
@@ -341,7 +342,7 @@ class Context:
                                            (dst or src).ptr, dst_stride, slot), self.L)
 
     # -- hot path, host buffers (synchronous) -----------------------------------------------
-    def equirect_views(self, src, views, slot=0, interp=INTERP_LINEAR):
+    def equirect_views(self, src, views, slot=0, interp=INTERP_LINEAR, flags=0):
         """src: H x W x C uint8 ndarray -> list of per-view ndarrays (height x width x C)."""
         src = np.ascontiguousarray(src, dtype=np.uint8)
         if src.ndim == 2:
@@ -354,7 +355,7 @@ class Context:
         dp = (C.c_void_p * len(views))(*[o.ctypes.data for o in outs])
         with self.slot_locks[slot]:
             _check(self.L.gs360_equirect_views_u8_host(self.handle, src.ctypes.data, W, H, Cn, src.strides[0], va,
-                                                       len(views), dp, 0, interp, 0, slot), self.L)
+                                                       len(views), dp, 0, interp, int(flags), slot), self.L)
         return outs
 
     def remap(self, src, map_x, map_y, interpolation=INTERP_LINEAR, border_value=0.0, valid=None, fill_value=0,

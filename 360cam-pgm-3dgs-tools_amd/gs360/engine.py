@@ -131,32 +131,42 @@ class Engine:
             interp = capi.INTERP_LINEAR if interp_env == "linear" else capi.INTERP_CUBIC
         return interp
 
-    def _view_for(self, job: JobSpec) -> capi.View:
-        if job.input_projection != "equirect" or job.output_projection != "rectilinear":
+    def _view_for(self, job: JobSpec):
+        """-> (View, flags).  rectilinear: v360's h_fov/v_fov; fisheye (the fisheyeXY preset, PC:351-414): v360 takes a
+        diagonal field of view d_fov and spreads it over the image diagonal (equidistant)."""
+        if job.input_projection != "equirect" or job.output_projection not in ("rectilinear", "fisheye"):
             raise capi.Gs360Error(-4, f"v360 {job.input_projection}->{job.output_projection} is not implemented by "
-                                      "the HIP engine (only equirect->rectilinear); use --engine ffmpeg")
+                                      "the HIP engine (equirect->rectilinear|fisheye only); use --engine ffmpeg")
         if abs(job.fnum("roll", 0.0)) > 1e-12:
             raise capi.Gs360Error(-4, "roll != 0 is not implemented by the HIP engine")
-        return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"), job.width, job.height)
+        if job.output_projection == "fisheye":
+            w, h = job.width, job.height
+            if "d_fov" in job.v360:
+                diag = float(np.hypot(w, h))
+                hfov, vfov = job.fnum("d_fov") * w / diag, job.fnum("d_fov") * h / diag
+            else:
+                hfov, vfov = job.fnum("h_fov"), job.fnum("v_fov")
+            return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), hfov, vfov, w, h), capi.EQ_FISHEYE_OUT
+        return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"), job.width, job.height), 0
 
-    def _render(self, st: _DeviceState, buf, H, W, C, view, interp):
+    def _render(self, st: _DeviceState, buf, H, W, C, view, interp, flags=0):
         with st.lock:
             slot = next(st.slot_cycle)
         out_bytes = view.height * view.width * C
         with st.ctx.slot_locks[slot]:
             dst = st.out_buffer(slot, out_bytes)
-            st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp)
+            st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp, flags=flags)
             return st.ctx.download(dst, (view.height, view.width, C), slot=slot)
 
     def run_job(self, job: JobSpec):
         """Execute one (frame, view) job; returns the output array after writing job.dst."""
-        view = self._view_for(job)
+        view, flags = self._view_for(job)
         interp = self._interp_for(job)
         st = self.states[self.device_for(job.src)]
         entry = self.resident_frame(st, job.src)
         try:
             buf, H, W, C = entry[:4]
-            out = self._render(st, buf, H, W, C, view, interp)
+            out = self._render(st, buf, H, W, C, view, interp, flags)
         finally:
             self.release_frame(st, entry)
         imageio.write_image(job.dst, out, jpeg_q=job.jpeg_q)
@@ -175,7 +185,7 @@ class Engine:
 
     def run_video_job(self, job: JobSpec, plan, stop_event=None, register_proc=None, expected_jobs=None) -> int:
         """All frames of one view of a video; returns the number of frames written."""
-        view = self._view_for(job)
+        view, flags = self._view_for(job)
         interp = self._interp_for(job)
         sess = self._video_session(plan, stop_event, register_proc)
         written = 0
@@ -185,7 +195,7 @@ class Engine:
                 if fr is None:
                     break
                 st, buf, H, W = fr
-                out = self._render(st, buf, H, W, 3, view, interp)
+                out = self._render(st, buf, H, W, 3, view, interp, flags)
                 imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)
                 written += 1
         finally:

@@ -50,6 +50,12 @@ typedef enum gs360_status {
 #define GS360_INTERP_CUBIC 2
 #define GS360_INTERP_LANCZOS4 4 /* table remap and fused fisheye only (8x8 taps) */
 
+/* flags of gs360_equirect_views_u8: the views are EQUIDISTANT-FISHEYE outputs instead of rectilinear ones -- the
+ * `fisheyeXY` preset's `v360=...:output=fisheye:d_fov=...` jobs (cli_tools/gs360_360PerspCut.py:351-414).  hfov_deg /
+ * vfov_deg of each view are then the full horizontal / vertical field of view of the fisheye image (image-plane radius
+ * <-> off-axis angle, 90 degrees at radius 1; for v360's d_fov: hfov = d_fov * w / hypot(w, h)). */
+#define GS360_EQ_FISHEYE_OUT 0x1u
+
 /* limits of one batched launch (larger requests are split internally) */
 #define GS360_MAX_VIEWS 16
 #define GS360_MAX_FRAMES 16
@@ -106,7 +112,7 @@ int gs360_event_elapsed_ms(gs360_ctx *ctx, int slot, int event_from, int event_t
  * Geometry: EQ-SPEC v1: pinhole ray -> pitch about X -> yaw about Y -> lon/lat ->
  * 1/32-px fixed-point bilinear; horizontal border wraps, vertical border clamps.
  * interp: GS360_INTERP_LINEAR or GS360_INTERP_CUBIC (4x4 taps, OpenCV's fixed-point Keys A=-0.75 table; the
- * reference's own default is v360 interp=cubic, PC:730).  flags: 0.
+ * reference's own default is v360 interp=cubic, PC:730).  flags: 0 or GS360_EQ_FISHEYE_OUT.
  */
 int gs360_equirect_views_u8(gs360_ctx *ctx, const void *const *src_frames, int n_frames,
                             int W, int H, int C, size_t src_stride,

@@ -441,14 +441,20 @@ typedef struct eq_consts {
     int32_t x0i32;      /* 32 * (floor(...) mod W) */
     int32_t y0i32;      /* 16*H - 16 */
     int32_t W, H, out_w, out_h;
+    int32_t fish;       /* 0: rectilinear (pinhole) output; 1: equidistant fisheye output (PC:351-414, v360 output=fisheye) */
 } eq_consts;
 
-static void eq_make_consts(const orc_view *v, int W, int H, eq_consts *c) {
+static void eq_make_consts_proj(const orc_view *v, int W, int H, int fish, eq_consts *c) {
     const double PI = 3.14159265358979323846;
     double hf = fmax(1e-3, fmin(179.9, v->hfov_deg)) * PI / 180.0; /* clamp as GUI:437-438 */
     double vf = fmax(1e-3, fmin(179.9, v->vfov_deg)) * PI / 180.0;
     c->sxu = (float)(tan(hf * 0.5) / (double)v->width);
     c->syv = (float)(tan(vf * 0.5) / (double)v->height);
+    c->fish = fish;
+    if (fish) { /* image-plane radius 1 <-> 90 degrees off axis; the view spans hfov x vfov degrees */
+        c->sxu = (float)(fmax(1e-3, fmin(360.0, v->hfov_deg)) / 180.0 / (double)v->width);
+        c->syv = (float)(fmax(1e-3, fmin(360.0, v->vfov_deg)) / 180.0 / (double)v->height);
+    }
     double pitch = v->pitch_deg * PI / 180.0;
     c->sp = (float)sin(pitch);
     c->cp = (float)cos(pitch);
@@ -463,6 +469,8 @@ static void eq_make_consts(const orc_view *v, int W, int H, eq_consts *c) {
     c->y0i32 = 16 * H - 16;
     c->W = W; c->H = H; c->out_w = v->width; c->out_h = v->height;
 }
+
+static void eq_make_consts(const orc_view *v, int W, int H, eq_consts *c) { eq_make_consts_proj(v, W, H, 0, c); }
 
 #define EQ_T8 0x1.a8279ap-2f /* tan(pi/8) rounded to float32 */
 static const float EQ_C1 = -0.33333316445350647f, EQ_C2 = 0.199985072016716f,
@@ -491,12 +499,37 @@ static inline float eq_atan2_red(float yy, float xx, int *Kout) {
     return r0;
 }
 
+/* Equidistant-fisheye output (EQ-SPEC v1, projection F): image-plane point (u, v), radius r = |(u, v)| <-> r*90 degrees
+ * off the optical axis, ray = (u S, v S, C) with S = sin(pi r/2)/r and C = cos(pi r/2), both even in r and evaluated
+ * as degree-8 polynomials in q = r^2 on [0, 4] (float32 Horner with fma; |error| < 4e-7, i.e. < 0.001 px at 8K). */
+static const float EQ_FS[9] = {1.5707963705062866f, -0.6459640860557556f, 0.07969262450933456f, -0.004681753925979137f,
+                               0.0001604411081643775f, -3.598792090997449e-06f, 5.689994608815141e-08f,
+                               -6.633614213491512e-10f, 5.326020006968246e-12f};
+static const float EQ_FC[9] = {1.0f, -1.2337005138397217f, 0.25366950035095215f, -0.020863480865955353f,
+                               0.0009192594443447888f, -2.5201432436006144e-05f, 4.708266487796209e-07f,
+                               -6.321354106830768e-09f, 5.675555858619674e-11f};
+static inline float eq_poly8(const float *k, float q) {
+    float p = k[8];
+    for (int n = 7; n >= 0; --n) p = fmaf(p, q, k[n]);
+    return p;
+}
+
 /* quantised source coordinate (1/32 px) for output pixel (i, j) */
 static inline void eq_coord(const eq_consts *c, int i, int j, int *sxo, int *syo) {
     float x = (float)(2 * i + 1 - c->out_w) * c->sxu;
     float yv = (float)(2 * j + 1 - c->out_h) * c->syv;
-    float b = fmaf(c->sp, yv, c->cp);   /* forward component after pitch */
-    float cc = fmaf(-c->cp, yv, c->sp); /* up component after pitch */
+    float b, cc;
+    if (c->fish) {
+        float q = fmaf(x, x, yv * yv);
+        float S = eq_poly8(EQ_FS, q), Cz = eq_poly8(EQ_FC, q);
+        x = x * S;
+        yv = yv * S;
+        b = fmaf(c->sp, yv, c->cp * Cz);
+        cc = fmaf(-c->cp, yv, c->sp * Cz);
+    } else {
+        b = fmaf(c->sp, yv, c->cp);   /* forward component after pitch */
+        cc = fmaf(-c->cp, yv, c->sp); /* up component after pitch */
+    }
     float h = sqrtf(fmaf(x, x, b * b));
     int Kl, Kt;
     float rl = eq_atan2_red(x, b, &Kl);
@@ -514,6 +547,20 @@ ORC_API int orc_equirect_map(const orc_view *v, int W, int H, int32_t *sx_out, i
     if (!v || W < 2 || H < 2 || v->width < 1 || v->height < 1) return -1;
     eq_consts c;
     eq_make_consts(v, W, H, &c);
+    for (int j = 0; j < c.out_h; ++j)
+        for (int i = 0; i < c.out_w; ++i) {
+            int sx, sy;
+            eq_coord(&c, i, j, &sx, &sy);
+            sx_out[(size_t)j * c.out_w + i] = sx;
+            sy_out[(size_t)j * c.out_w + i] = sy;
+        }
+    return 0;
+}
+
+ORC_API int orc_equirect_map_proj(const orc_view *v, int W, int H, int fish, int32_t *sx_out, int32_t *sy_out) {
+    if (!v || W < 2 || H < 2 || v->width < 1 || v->height < 1) return -1;
+    eq_consts c;
+    eq_make_consts_proj(v, W, H, fish, &c);
     for (int j = 0; j < c.out_h; ++j)
         for (int i = 0; i < c.out_w; ++i) {
             int sx, sy;
@@ -587,9 +634,27 @@ ORC_API int orc_equirect_views_u8_interp(const uint8_t *src, int W, int H, int C
 /* mask != NULL: keep-mask fused into the output (BASELINE config 5, build-defined; mask convention of the reference's
  * SegmentationMaskTool, SEG:765-774: 0 = masked, 255 = keep): nearest texel of the same quantised coordinate,
  * out = 0 where mask < 128. */
+static int eq_views_impl(const uint8_t *src, const uint8_t *mask, int W, int H, int C, long src_stride,
+                         long mask_stride, const orc_view *views, int n_views,
+                         uint8_t *const *dst, long dst_stride, int interp, int n_threads, int fish);
+
 ORC_API int orc_equirect_views_masked_u8(const uint8_t *src, const uint8_t *mask, int W, int H, int C, long src_stride,
                                          long mask_stride, const orc_view *views, int n_views,
                                          uint8_t *const *dst, long dst_stride, int interp, int n_threads) {
+    return eq_views_impl(src, mask, W, H, C, src_stride, mask_stride, views, n_views, dst, dst_stride, interp, n_threads, 0);
+}
+
+/* equirect -> equidistant-fisheye views (the `fisheyeXY` preset's v360 output=fisheye jobs, PC:351-414):
+ * views[k].hfov_deg / vfov_deg = full horizontal / vertical field of view of the fisheye image */
+ORC_API int orc_equirect_fisheye_views_u8(const uint8_t *src, int W, int H, int C, long src_stride,
+                                          const orc_view *views, int n_views,
+                                          uint8_t *const *dst, long dst_stride, int interp, int n_threads) {
+    return eq_views_impl(src, NULL, W, H, C, src_stride, 0, views, n_views, dst, dst_stride, interp, n_threads, 1);
+}
+
+static int eq_views_impl(const uint8_t *src, const uint8_t *mask, int W, int H, int C, long src_stride,
+                         long mask_stride, const orc_view *views, int n_views,
+                         uint8_t *const *dst, long dst_stride, int interp, int n_threads, int fish) {
     if (interp != 1 && interp != 2) return -3;
     if (mask && mask_stride == 0) mask_stride = W;
     if (interp == 2) cubic_init();
@@ -603,7 +668,7 @@ ORC_API int orc_equirect_views_masked_u8(const uint8_t *src, const uint8_t *mask
     if (!cs || !row0) { free(cs); free(row0); return -4; }
     row0[0] = 0;
     for (int k = 0; k < n_views; ++k) {
-        eq_make_consts(&views[k], W, H, &cs[k]);
+        eq_make_consts_proj(&views[k], W, H, fish, &cs[k]);
         row0[k + 1] = row0[k] + cs[k].out_h;
     }
     long total_rows = row0[n_views];

@@ -52,6 +52,9 @@ def lib():
         L.orc_equirect_views_u8_interp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(OrcView),
                                                    C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
         L.orc_cubic_table.argtypes = [C.c_void_p]
+        L.orc_equirect_map_proj.argtypes = [C.POINTER(OrcView), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_equirect_fisheye_views_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(OrcView),
+                                                    C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
         L.orc_lanczos4_table.argtypes = [C.c_void_p]
         L.orc_equirect_views_masked_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
                                                    C.POINTER(OrcView), C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
@@ -140,6 +143,27 @@ def equirect_map(view, W, H):
     rc = lib().orc_equirect_map(C.byref(view), W, H, _ptr(sx), _ptr(sy))
     assert rc == 0
     return sx, sy
+
+
+def equirect_fisheye_map(view, W, H):
+    """quantised (1/32 px) source coordinates of an equidistant-fisheye output view (hfov/vfov = its full field of view)"""
+    sx = np.empty((view.height, view.width), np.int32)
+    sy = np.empty((view.height, view.width), np.int32)
+    rc = lib().orc_equirect_map_proj(C.byref(view), W, H, 1, _ptr(sx), _ptr(sy))
+    assert rc == 0
+    return sx, sy
+
+
+def equirect_fisheye_views_u8(src, views, threads=1, interp=1):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    H, W, Cn = src.shape
+    arr = (OrcView * len(views))(*views)
+    outs = [np.empty((v.height, v.width, Cn), np.uint8) for v in views]
+    ptrs = (C.c_void_p * len(views))(*[o.ctypes.data for o in outs])
+    rc = lib().orc_equirect_fisheye_views_u8(_ptr(src), W, H, Cn, src.strides[0], arr, len(views), ptrs, 0, int(interp), int(threads))
+    if rc != 0:
+        raise RuntimeError(f"orc_equirect_fisheye_views_u8 rc={rc}")
+    return outs
 
 
 def cubic_table():

@@ -50,6 +50,22 @@ def test_cli_renders_full360coverage_folder(tmp_path, orc):
         assert np.array_equal(got, want), v.output_name
 
 
+def test_cli_renders_fisheyexy_preset(tmp_path, orc):
+    """the fisheyeXY preset (equirect -> X/Y fisheye pair, v360 output=fisheye d_fov=180) runs on the GPU, no ffmpeg"""
+    src = make_panos(tmp_path / "in")
+    r = subprocess.run(EXE + ["-i", str(tmp_path / "in"), "--preset", "fisheyeXY", "--size", "120", "--ext", "png"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "success=4, failed=0, total=4" in r.stdout
+    out_dir = tmp_path / "in" / "_geometry"
+    assert sorted(p.name for p in out_dir.iterdir()) == ["pano_000_X.png", "pano_000_Y.png", "pano_001_X.png", "pano_001_Y.png"]
+    fov = 180.0 * 120 / float(np.hypot(120, 120))
+    for stem, img in src.items():
+        for tag, yaw in (("X", 0.0), ("Y", 180.0)):
+            want = orc.equirect_fisheye_views_u8(img, [orc.make_view(yaw, 0.0, fov, fov, 120, 120)], interp=2)[0]
+            assert np.array_equal(imageio.read_image(out_dir / f"{stem}_{tag}.png"), want), (stem, tag)
+
+
 def test_run_one_is_thread_safe_and_cancellable(tmp_path, orc):
     src = make_panos(tmp_path / "in", n=1)
     args = cut.create_arg_parser().parse_args(["-i", str(tmp_path / "in"), "--count", "6", "--size", "64", "--ext", "png"])

@@ -143,6 +143,20 @@ def test_equirect_batched_frames_device_api(ctx, orc, lanemap):
         ctx.free(b)
 
 
+@pytest.mark.parametrize("channels,interp", [(3, 1), (3, 2), (1, 1), (4, 2)])
+def test_equirect_fisheye_output(ctx, orc, channels, interp):
+    """GS360_EQ_FISHEYE_OUT: the fisheyeXY preset's equidistant-fisheye views (PC:351-414), incl. fov > 180 and odd sizes"""
+    src = rand_image(300, 600, c=channels, seed=29)
+    d180 = 180.0 / np.sqrt(2.0)
+    specs = [(0.0, 0.0, d180, d180, 150, 150), (180.0, 0.0, d180, d180, 150, 150), (37.0, -25.0, 200.0, 120.0, 131, 77),
+             (-100.0, 60.0, 254.0, 254.0, 64, 64), (5.0, 0.0, 90.0, 45.0, 1, 3)]
+    got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], interp=interp, flags=gs360.EQ_FISHEYE_OUT)
+    want = orc.equirect_fisheye_views_u8(src, [orc.make_view(*s) for s in specs], interp=interp)
+    _assert_same(got, want, f"fisheye output C={channels} interp={interp}")
+    with pytest.raises(gs360.Gs360Error):
+        ctx.equirect_views(src, [gs360.View.make(*specs[0])], flags=2)
+
+
 def test_equirect_many_views_split(ctx, orc):
     """more than GS360_MAX_VIEWS views -> split into several launches internally"""
     src = rand_image(200, 400, seed=5)

@@ -112,3 +112,57 @@ def test_algorithmic_bytes_constant_of_bench(orc):
     assert int(union.sum()) == 11_685_864
     assert bench.ALGO_BYTES_PER_FRAME == 6 * 800 * 800 * 3 + total * 3 == 54_495_972
     assert [tuple(v) for v in bench.view_table()] == [tuple(s) for s in ring_views(6, 800, HFOV_12MM)]
+
+
+# ---- equidistant-fisheye OUTPUT (the fisheyeXY preset's v360 output=fisheye jobs, PC:351-414) ---------------------
+def truth_fisheye_xy(spec, W, H):
+    """float64: image-plane radius r <-> 90 r degrees off axis (equidistant), pitch about X, yaw about Y, lon/lat"""
+    yaw, pitch, hfov, vfov, w, h = spec
+    u = ((2 * np.arange(w) + 1 - w) / w)[None, :] * (hfov / 180.0)
+    v = ((2 * np.arange(h) + 1 - h) / h)[:, None] * (vfov / 180.0)
+    r = np.hypot(u, v)
+    ang = np.pi / 2 * r
+    s = np.where(r > 0, np.sin(ang) / np.where(r > 0, r, 1), np.pi / 2)
+    x, yd, z = u * s, v * s, np.cos(ang) + 0 * u
+    p, yw = np.radians(pitch), np.radians(yaw)
+    fwd = np.sin(p) * yd + np.cos(p) * z
+    up = -np.cos(p) * yd + np.sin(p) * z
+    lon = np.arctan2(x, fwd) + yw
+    lat = np.arctan2(up, np.hypot(x, fwd))
+    return np.mod((lon / (2 * np.pi) + 0.5) * W - 0.5, W), (0.5 - lat / np.pi) * H - 0.5, lat
+
+
+@pytest.mark.parametrize("yaw,pitch,fov", [(0, 0, 127.27922061357856), (180, 0, 127.27922061357856), (33.0, -20.0, 100.0),
+                                           (-90.0, 45.0, 200.0), (10.0, 0.0, 254.0)])
+def test_fisheye_output_map_is_the_rounded_truth(orc, yaw, pitch, fov):
+    W, H = 7680, 3840
+    spec = (yaw, pitch, fov, fov, 360, 360)
+    sx, sy = orc.equirect_fisheye_map(orc.make_view(*spec), W, H)
+    X, Y, lat = truth_fisheye_xy(spec, W, H)
+    assert sx.min() >= 0 and sx.max() < 32 * W
+    dx = (sx / 32.0 - X + W / 2) % W - W / 2
+    dy = sy / 32.0 - Y
+    cosl = np.maximum(np.cos(lat), 1e-3)
+    assert np.abs(dy).max() <= 1 / 64 + 2e-3                  # polynomial sin/cos: < 0.001 px at 8K on top of the rounding
+    assert (np.abs(dx) * cosl).max() <= 1 / 64 + 2e-3
+
+
+def test_fisheye_output_centre_and_rim(orc):
+    """view centre looks along (yaw, pitch); at d_fov = 180 the corners of a square image are 90 degrees off axis"""
+    W, H = 4096, 2048
+    n = 201
+    fov = 180.0 / np.sqrt(2.0)
+    sx, sy = orc.equirect_fisheye_map(orc.make_view(90.0, 0.0, fov, fov, n, n), W, H)
+    c = n // 2
+    assert abs(sx[c, c] / 32.0 - ((90 / 360 + 0.5) * W - 0.5)) <= 1 / 64 + 1e-3 and abs(sy[c, c] / 32.0 - (H / 2 - 0.5)) <= 1 / 64 + 1e-3
+    # pixel centres nearest the corner: r = (n-1)/n * sqrt(2) * fov/180 = (n-1)/n -> 90 (n-1)/n degrees off axis, on the diagonal
+    off = np.radians(90.0 * (n - 1) / n)
+    d = np.array([np.sin(off) / np.sqrt(2), np.sin(off) / np.sqrt(2), np.cos(off)])        # (right, up, forward) of the top-right corner
+    lon = np.arctan2(d[0], d[2]) + np.pi / 2
+    lat = np.arcsin(d[1])
+    assert abs(sx[0, n - 1] / 32.0 - np.mod((lon / (2 * np.pi) + 0.5) * W - 0.5, W)) < 0.05
+    assert abs(sy[0, n - 1] / 32.0 - ((0.5 - lat / np.pi) * H - 0.5)) < 0.05
+    src = rand_image(128, 256)
+    a = orc.equirect_fisheye_views_u8(src, [orc.make_view(0, 0, fov, fov, 33, 21)])[0]
+    b = orc.equirect_fisheye_views_u8(np.roll(src, 64, axis=1), [orc.make_view(90.0, 0, fov, fov, 33, 21)])[0]
+    assert np.array_equal(a, b)                          # yaw by 90 degrees == rolling the panorama by W/4
