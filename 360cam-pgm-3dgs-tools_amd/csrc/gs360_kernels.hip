@@ -455,6 +455,39 @@ __device__ __forceinline__ uint32_t eq_mask_at(const EqLaunch& L, const uint8_t*
     return mask[(uint32_t)yn * (uint32_t)L.mask_stride + (uint32_t)xn];
 }
 
+// Hand the wavefront's pixels to memory: blocked patches (store_patch_rgb) or one row per slot (store_row).
+template <int C>
+__device__ __forceinline__ void eq_store(uint8_t* dst, int64_t dstride, const uint32_t (&px)[kRowsPerWave][4],
+                                         const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
+                                         int col0, int n_px, bool reversed, bool aligned4, bool skip_first,
+                                         bool use_blk, const BlkStore blk) {
+    if constexpr (C == 3 && kRowsPerWave == 4 && kWaves == 4) {   // == kBlocked of the kernel
+      if (use_blk) {                                      // wave-uniform: this view uses the blocked lane map
+        if (blk.mode == 1) {
+            store_patch_rgb<4>(dst, dstride, blk.lds, px, 0, blk.y0, 1, blk.nrows, col0, n_px, aligned4, reversed, skip_first);
+            return;
+        }
+        {
+            // this wavefront owns tile columns [sub, sub + n_w); in the mirrored pass they sit at the other end of the segment
+            const int n_w = min(max(n_px - blk.sub, 0), 32);
+            const int c0 = reversed ? col0 + n_px - blk.sub - n_w : col0 + blk.sub;
+            const bool al = aligned4 && (((c0 * 3) & 3) == 0);
+            const bool skip = skip_first && n_w > 0 && blk.sub + n_w == n_px;   // the centre column is this half's last one
+            store_patch_rgb<2>(dst, dstride, blk.lds, px, 0, blk.y0, 1, blk.nrows, c0, n_w, al, reversed, skip);
+            store_patch_rgb<2>(dst, dstride, blk.lds, px, 2, blk.yb, -1, blk.nrows_b, c0, n_w, al, reversed, skip);
+            return;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s)
+#if GS360_EXPERIMENT == 1   // load-path probe: only one lane-row in a million is written
+        if (row_ok[s] && px[s][0] == 0x12345u) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+#else
+        if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+#endif
+}
+
 template <int C, bool CUBIC>
 __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __restrict__ src, const uint8_t* __restrict__ mask,
                                         uint8_t* dst, int64_t dstride,
@@ -486,9 +519,7 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
             for (int s = 0; s < kRowsPerWave; ++s)
                 if (eq_mask_at(L, mask, sxs[s], sys[s]) < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
         }
-#pragma unroll
-        for (int s = 0; s < kRowsPerWave; ++s)
-            if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+        eq_store<C>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, use_blk, blk);
         return;
     }
     EqTaps<C> taps[kRowsPerWave];
@@ -518,31 +549,7 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
         for (int s = 0; s < kRowsPerWave; ++s)
             if (keep[s] < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
     }
-    if constexpr (C == 3 && !CUBIC && kRowsPerWave == 4 && kWaves == 4) {   // == kBlocked of the kernel
-      if (use_blk) {                                      // wave-uniform: this view uses the blocked lane map
-        if (blk.mode == 1) {
-            store_patch_rgb<4>(dst, dstride, blk.lds, px, 0, blk.y0, 1, blk.nrows, col0, n_px, aligned4, reversed, skip_first);
-            return;
-        }
-        {
-            // this wavefront owns tile columns [sub, sub + n_w); in the mirrored pass they sit at the other end of the segment
-            const int n_w = min(max(n_px - blk.sub, 0), 32);
-            const int c0 = reversed ? col0 + n_px - blk.sub - n_w : col0 + blk.sub;
-            const bool al = aligned4 && (((c0 * 3) & 3) == 0);
-            const bool skip = skip_first && n_w > 0 && blk.sub + n_w == n_px;   // the centre column is this half's last one
-            store_patch_rgb<2>(dst, dstride, blk.lds, px, 0, blk.y0, 1, blk.nrows, c0, n_w, al, reversed, skip);
-            store_patch_rgb<2>(dst, dstride, blk.lds, px, 2, blk.yb, -1, blk.nrows_b, c0, n_w, al, reversed, skip);
-            return;
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s)
-#if GS360_EXPERIMENT == 1   // load-path probe: only one lane-row in a million is written
-        if (row_ok[s] && px[s][0] == 0x12345u) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
-#else
-        if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
-#endif
+    eq_store<C>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, use_blk, blk);
 }
 
 // equirect -> rectilinear views.  The pinhole grid is mirror-symmetric about the view's vertical axis:
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
         __syncthreads();
     }
-    constexpr bool kBlocked = (C == 3) && !CUBIC && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map, see below
+    constexpr bool kBlocked = (C == 3) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map, see below
     __shared__ uint32_t s_blk[kBlocked ? kWaves * 256 + 4 : 4];
     int f = t / L.tiles_per_frame;
     int r = t - f * L.tiles_per_frame;

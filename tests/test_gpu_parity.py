@@ -179,7 +179,7 @@ def test_equirect_empty_and_errors(ctx):
 
 
 @pytest.mark.parametrize("channels", [1, 3, 4])
-def test_equirect_cubic(ctx, orc, channels):
+def test_equirect_cubic(ctx, orc, channels, lanemap):
     """cubic sampler (the reference's default interp, PC:730): wrap columns / clamp rows, OpenCV fixed-point table"""
     src = rand_image(193, 386, c=channels, seed=71)
     specs = [(0, 0, 110, 110, 130, 70), (180, 0, 100, 100, 65, 65), (-75.5, 33, 90, 120, 67, 129), (0, 90, 120, 120, 64, 64),
