@@ -369,10 +369,11 @@ struct EqCubicTaps {
     bool fix;
 };
 
-__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy) {
-    const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
+// window anchored at texel (ix, iy) with phase (fx, fy); `fix` = the window's columns could not be read in place
+__device__ __forceinline__ EqCubicTaps cubic_fetch_rgb(const int16_t* wtab, const uint8_t* __restrict__ src, uint32_t stride, int W, int H,
+                                                       int ix, int iy, int fx, int fy) {
     EqCubicTaps t;
-    const int x0 = min(max(ix - 1, 0), L.W - 6);            // 16-byte aligned read of 12 tap bytes stays in-row
+    const int x0 = min(max(ix - 1, 0), W - 6);              // 16-byte aligned read of 12 tap bytes stays in-row
     t.fix = (x0 != ix - 1);
     const uint4* wq = reinterpret_cast<const uint4*>(wtab + (fy * 32 + fx) * 16);
     t.wa = wq[0];
@@ -380,7 +381,7 @@ __device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const i
     const uint32_t col = (uint32_t)x0 * 3u;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), L.H - 1), (uint32_t)L.src_stride) + col;
+        const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
         const uint8_t* p = src + off;
         const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
         const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
@@ -390,6 +391,10 @@ __device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const i
         t.row[ky][2] = __builtin_amdgcn_alignbyte(d3, d2, o);
     }
     return t;
+}
+
+__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy) {
+    return cubic_fetch_rgb(wtab, src, (uint32_t)L.src_stride, L.W, L.H, sx >> 5, sy >> 5, sx & 31, sy & 31);
 }
 
 // 48 multiply-adds per pixel as 24 v_dot2_i32_i16 (see eq_blend): constant selectors -- the 12 tap bytes of a row are
@@ -937,6 +942,49 @@ __device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out
     eq_blend<C>(e, t.fx, t.fy, out);     // same 1/32-px weights: only the fractional bits of sx, sy are used
 }
 
+// cv2 bicubic for the wavefront's four row slots of an RGB image.  Windows that lie inside the image take the
+// equirect kernel's path (four dword-aligned 16-byte row reads + the 32-byte weight entry issued together, dot-product
+// blend); the others are redone by the straight-line border sampler.  Needs W >= 8 and 32-bit tap offsets (`pipelined`).
+__device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
+                                                   const float (&mxs)[kRowsPerWave], const float (&mys)[kRowsPerWave],
+                                                   const uint8_t (&cval)[4], const int16_t* __restrict__ tab,
+                                                   uint32_t (&px)[kRowsPerWave][4]) {
+    static_assert(kRowsPerWave == 4, "four row slots");
+    bool fast[4];
+#pragma unroll
+    for (int s0 = 0; s0 < 4; s0 += 2) {                   // two slots at a time: 8 row reads in flight, 24 tap dwords live
+        EqCubicTaps t[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int sx = cv_round(mxs[s0 + u] * 32.0f), sy = cv_round(mys[s0 + u] * 32.0f);
+            const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+            fast[s0 + u] = ix >= 1 && iy >= 1 && ix <= W - 5 && iy <= H - 3;
+            t[u] = cubic_fetch_rgb(tab, src, (uint32_t)stride, W, H, ix, iy, sx & 31, sy & 31);
+        }
+        eq_cubic_blend(t[0], px[s0]);
+        eq_cubic_blend(t[1], px[s0 + 1]);
+    }
+    if (__any(!(fast[0] && fast[1] && fast[2] && fast[3]))) {
+        // border windows: ONE copy of the straight-line sampler in a rolled loop (slot picked with uniform selects), so
+        // that its 48 byte loads do not set the register budget of the path above
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const float mx = rr == 0 ? mxs[0] : rr == 1 ? mxs[1] : rr == 2 ? mxs[2] : mxs[3];
+            const float my = rr == 0 ? mys[0] : rr == 1 ? mys[1] : rr == 2 ? mys[2] : mys[3];
+            const bool f = rr == 0 ? fast[0] : rr == 1 ? fast[1] : rr == 2 ? fast[2] : fast[3];
+            if (!f) {
+                uint32_t o[4];
+                cv_sample_cubic<3>(src, stride, W, H, mx, my, cval, tab, o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (rr == k) px[k][c] = o[c];
+            }
+        }
+    }
+}
+
 // One instantiation per interpolation: the 8x8 Lanczos window would otherwise set the register budget (and with it the
 // occupancy) of the bilinear path.
 template <int C, int INTERP>
@@ -955,8 +1003,9 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
     const int n_px = min(kTileW, L.w - x0);
     const int xc = min(x0 + lane, L.w - 1);
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
-    if (INTERP == GS360_INTERP_LINEAR && L.pipelined) {
-        // maps of the wavefront's 4 rows -> all 8 gathers in flight -> blend -> border/valid fix-ups -> packed stores
+    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
+    if ((INTERP == GS360_INTERP_LINEAR || kFastCubic) && L.pipelined) {
+        // maps of the wavefront's 4 rows -> all gathers in flight -> blend -> border/valid fix-ups -> packed stores
         const int ybase = tile_y * kTileH + wave * kRowsPerWave;
         float mxs[kRowsPerWave], mys[kRowsPerWave];
         bool inval[kRowsPerWave];
@@ -967,20 +1016,24 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
             mys[rr] = L.map_y[o];
             inval[rr] = L.valid && !L.valid[o];
         }
-        CvTaps<C> taps[kRowsPerWave];
-        bool any_slow = false;
-#pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) {
-            taps[rr] = cv_fetch_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr]);
-            any_slow |= !taps[rr].fast;
-        }
         uint32_t px[kRowsPerWave][4];
+        if constexpr (kFastCubic) {
+            cv_cubic_slots_rgb(L.src, L.src_stride, L.W, L.H, mxs, mys, L.cval, L.cubic_tab, px);
+        } else {
+            CvTaps<C> taps[kRowsPerWave];
+            bool any_slow = false;
 #pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
-        if (__any(any_slow)) {
+            for (int rr = 0; rr < kRowsPerWave; ++rr) {
+                taps[rr] = cv_fetch_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr]);
+                any_slow |= !taps[rr].fast;
+            }
 #pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr)
-                if (!taps[rr].fast) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
+            for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
+            if (__any(any_slow)) {
+#pragma unroll
+                for (int rr = 0; rr < kRowsPerWave; ++rr)
+                    if (!taps[rr].fast) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
+            }
         }
 #pragma unroll
         for (int rr = 0; rr < kRowsPerWave; ++rr) {
@@ -1069,7 +1122,9 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
         oks[rr] = (Z >= V.cos_tmax * N) && (mx >= 0.0f) && (mx <= V.wmax) && (my >= 0.0f) && (my <= V.hmax);
     }
     uint32_t px[kRowsPerWave][4];
-    if (pipelined) {
+    if ((INTERP == GS360_INTERP_CUBIC) && (C == 3) && L.pipelined) {
+        if constexpr (C == 3) cv_cubic_slots_rgb(V.src, L.src_stride, V.W, V.H, mxs, mys, L.cval, L.cubic_tab, px);
+    } else if (pipelined) {
         CvTaps<C> taps[kRowsPerWave];
         bool any_slow = false;
 #pragma unroll
@@ -1085,11 +1140,23 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
                 if (!taps[rr].fast) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
         }
     } else {
-        for (int rr = 0; rr < kRowsPerWave; ++rr) {
-            if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
-            else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
-            else if constexpr (INTERP == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, L.cubic_tab, px[rr]);
-            else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
+        // one copy of the straight-line sampler in a rolled loop; the slot is picked with wave-uniform selects so that the
+        // coordinate / pixel arrays stay in registers
+        static_assert(kRowsPerWave == 4, "four row slots");
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const float mx = rr == 0 ? mxs[0] : rr == 1 ? mxs[1] : rr == 2 ? mxs[2] : mxs[3];
+            const float my = rr == 0 ? mys[0] : rr == 1 ? mys[1] : rr == 2 ? mys[2] : mys[3];
+            uint32_t o[4];
+            if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, o);
+            else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, L.cubic_tab, o);
+            else if constexpr (INTERP == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, L.cubic_tab, o);
+            else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (rr == k) px[k][c] = o[c];
         }
     }
 #pragma unroll
