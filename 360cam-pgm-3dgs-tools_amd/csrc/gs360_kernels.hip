@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
     const int xc = min(x0 + lane, L.w - 1);
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
     constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    if ((INTERP == GS360_INTERP_LINEAR || kFastCubic) && L.pipelined) {
+    if ((INTERP == GS360_INTERP_LINEAR || INTERP == GS360_INTERP_NEAREST || kFastCubic) && L.pipelined) {
         // maps of the wavefront's 4 rows -> all gathers in flight -> blend -> border/valid fix-ups -> packed stores
         const int ybase = tile_y * kTileH + wave * kRowsPerWave;
         float mxs[kRowsPerWave], mys[kRowsPerWave];
@@ -1019,6 +1019,9 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
         uint32_t px[kRowsPerWave][4];
         if constexpr (kFastCubic) {
             cv_cubic_slots_rgb(L.src, L.src_stride, L.W, L.H, mxs, mys, L.cval, L.cubic_tab, px);
+        } else if constexpr (INTERP == GS360_INTERP_NEAREST) {   // mask cutting (DF:2031-2043): the 4 slots' reads in flight together
+#pragma unroll
+            for (int rr = 0; rr < kRowsPerWave; ++rr) cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
         } else {
             CvTaps<C> taps[kRowsPerWave];
             bool any_slow = false;
