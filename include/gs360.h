@@ -137,6 +137,7 @@ int gs360_equirect_views_masked_u8(gs360_ctx *ctx, const void *const *src_frames
  * cv2.remap with float32 maps, BORDER_CONSTANT; then, if valid != NULL, dst[~valid] = fill_value
  * on all channels.  src: H x W x C; map_x/map_y/valid: h x w (tight); dst: h x w x C.
  * border_value: 4 doubles (cv::Scalar; Python's borderValue=float(v) is {v,0,0,0}).
+ * interp: GS360_INTERP_NEAREST / LINEAR / CUBIC / LANCZOS4 (cv2's fixed-point tables for 8-bit images).
  * All pointers are device pointers.  H, W < 32767 (cv2.remap's own limit).
  */
 int gs360_remap_table_u8(gs360_ctx *ctx, const void *src, int H, int W, int C, size_t src_stride,

@@ -27,6 +27,33 @@ def test_library_exports_every_declared_symbol():
     assert lib.gs360_abi_version() == int(re.search(r"#define GS360_ABI_VERSION (\d+)", HEADER).group(1))
 
 
+def test_binding_struct_layouts_match_the_header():
+    """ctypes mirrors of the POD structs: sizes and field offsets as a C compiler lays out include/gs360.h (LP64)"""
+    import subprocess
+    import tempfile
+    from gs360 import capi
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "gs360.h"
+int main(void) {
+    printf("%zu %zu %zu\n", sizeof(gs360_view), sizeof(gs360_calib), sizeof(gs360_remap_job));
+    printf("%zu %zu %zu %zu %zu\n", offsetof(gs360_remap_job, src_stride), offsetof(gs360_remap_job, valid),
+           offsetof(gs360_remap_job, fill_value), offsetof(gs360_remap_job, dst), offsetof(gs360_remap_job, dst_stride));
+    return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        src = pathlib.Path(td) / "t.c"
+        src.write_text(prog)
+        exe = pathlib.Path(td) / "t"
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", str(exe), str(src)], check=True)
+        out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    sizes, offs = [int(v) for v in out[:3]], [int(v) for v in out[3:]]
+    assert sizes == [ctypes.sizeof(capi.View), ctypes.sizeof(capi.Calib), ctypes.sizeof(capi.RemapJob)] == [40, 96, 80]
+    J = capi.RemapJob
+    assert offs == [J.src_stride.offset, J.valid.offset, J.fill_value.offset, J.dst.offset, J.dst_stride.offset]
+
+
 def test_no_torch_or_oracle_in_product_signatures_or_imports():
     pkg = ROOT / "360cam-pgm-3dgs-tools_amd"
     for path in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
