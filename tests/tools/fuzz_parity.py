@@ -45,6 +45,9 @@ def fuzz_equirect(ctx, rng, case):
     spad = int(rng.choice([0, 0, 1, 3, 4, 64]))
     dpad = int(rng.choice([0, 0, 1, 2, 4]))
     use_mask = rng.random() < 0.3
+    fish = (not use_mask) and rng.random() < 0.3          # equidistant-fisheye outputs (GS360_EQ_FISHEYE_OUT)
+    if fish:
+        specs = [(s[0], s[1], float(rng.uniform(20, 300)), float(rng.uniform(20, 300)), s[4], s[5]) for s in specs]
     sbuf, sstride = padded(rng, src, spad)
     d_src = ctx.to_device(sbuf)
     views = [gs360.View.make(*s) for s in specs]
@@ -58,8 +61,11 @@ def fuzz_equirect(ctx, rng, case):
         mask = (rng.integers(0, 2, (H, W), dtype=np.uint8) * 255)
         d_mask = ctx.to_device(mask)
     ctx.equirect_views_dev([d_src], W, H, c, views, d_out, src_stride=sstride if spad else 0, dst_stride=dstride, interp=interp,
-                           masks=[d_mask] if use_mask else None)
-    want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], interp=interp, mask=mask, threads=0)
+                           masks=[d_mask] if use_mask else None, flags=gs360.EQ_FISHEYE_OUT if fish else 0)
+    if fish:
+        want = orc.equirect_fisheye_views_u8(src, [orc.make_view(*s) for s in specs], interp=interp, threads=0)
+    else:
+        want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], interp=interp, mask=mask, threads=0)
     ok = True
     for k, s in enumerate(specs):
         row = dstride or s[4] * c
@@ -68,7 +74,7 @@ def fuzz_equirect(ctx, rng, case):
         if not np.array_equal(got, want[k]):
             ok = False
             bad = np.argwhere(got != want[k])
-            print(f"[equirect] case {case}: view {k} {s} C={c} src {W}x{H} interp={interp} spad={spad} dpad={dpad} mask={use_mask}: "
+            print(f"[equirect] case {case}: view {k} {s} C={c} src {W}x{H} interp={interp} spad={spad} dpad={dpad} mask={use_mask} fish={fish}: "
                   f"{len(bad)} bytes differ, first at {bad[0].tolist()}")
         if dstride and not np.all(raw[:, s[4] * c:] == 0xAB):
             ok = False
@@ -158,6 +164,33 @@ def fuzz_fisheye(ctx, rng, case):
     return True
 
 
+def fuzz_color(ctx, rng, case):
+    from gs360 import color
+    from oracle import color_np
+    n = int(rng.integers(2, 34))
+    table = (rng.random((n, n, n, 3), dtype=np.float32) * np.float32(1.3) - np.float32(0.15)).astype(np.float32)
+    if rng.random() < 0.5:     # smooth LUT (realistic), else noise
+        g = np.linspace(0, 1, n, dtype=np.float32)
+        bb, gg, rr = np.meshgrid(g, g, g, indexing="ij")
+        table = np.stack([rr ** np.float32(rng.uniform(0.4, 2.0)), gg * np.float32(0.8) + bb * np.float32(0.2),
+                          bb ** np.float32(rng.uniform(0.4, 2.0))], -1).astype(np.float32)
+    dmin = np.float32(rng.uniform(0, 0.2, 3)) if rng.random() < 0.4 else np.zeros(3, np.float32)
+    dmax = np.float32(rng.uniform(0.7, 1.0, 3)) if rng.random() < 0.4 else np.ones(3, np.float32)
+    space = str(rng.choice(["srgb", "passthrough"]))
+    c = int(rng.choice([3, 3, 4]))
+    img = rng.integers(0, 256, (int(rng.integers(1, 90)), int(rng.integers(1, 300)), c), dtype=np.uint8)
+    red = int(rng.choice([0, 2]))
+    stage = color.ColorStage(color.CubeLUT(n, table, dmin, dmax), space)
+    got = stage.apply(ctx, img, red_index=red)
+    stage.close()
+    want = color_np.color_pipeline(img, table, dmin, dmax, space, red_index=red)
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        print(f"[color] case {case}: lut {n}^3 {space} img {img.shape} red={red}: {len(bad)} bytes differ, first at {bad[0].tolist()}")
+        return False
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -165,11 +198,11 @@ def main():
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=2)
     t0 = time.time()
-    counts = {"equirect": 0, "table": 0, "fisheye": 0}
-    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye}
+    counts = {"equirect": 0, "table": 0, "fisheye": 0, "color": 0}
+    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye, "color": fuzz_color}
     case, failures = 0, 0
     while time.time() - t0 < args.seconds and failures < 5:
-        name = ("equirect", "table", "fisheye")[case % 3]
+        name = ("equirect", "table", "fisheye", "color")[case % 4]
         rng = np.random.default_rng([args.seed, case])
         if not fns[name](ctx, rng, f"{args.seed}:{case}"):
             failures += 1
