@@ -14,6 +14,13 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (lib/ is git-ignored): build it once with hipcc if it is there
+    lib = PKG / "lib" / "libgs360hip.so"
+    if not lib.exists():
+        import shutil
+        import subprocess
+        if shutil.which("hipcc") or pathlib.Path("/opt/rocm/bin/hipcc").exists():
+            subprocess.run(["make", "-C", str(PKG / "csrc")], check=False)
 
 
 @pytest.fixture(scope="session")
