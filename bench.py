@@ -10,7 +10,7 @@ already resident in HBM (default 8 frames = 708 MB of source, 2.8x the 256 MiB I
 steps are served from HBM; measured: 1 frame/step (cache-hot) and 4 frames/step are ~8 % and ~18 % faster per
 frame and are NOT what is reported).  `value` = output pixels written by all ranks / wall time.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 400 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -99,8 +99,8 @@ def cpu_baseline(np, frame, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--frames", type=int, default=8, help="distinct HBM-resident frames per step (one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
