@@ -632,6 +632,9 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
     // ---- coordinates (EQ-SPEC v1) ------------------------------------------------------------------
     int sxl[kRowsPerWave], sxm[kRowsPerWave], sys[kRowsPerWave];
     const bool blocked = kBlocked && V.blocked != 0;      // wave-uniform, chosen per view on the host
+    // A wavefront of a level view's blocked tile owns 32 columns; in the last tile of a row of tiles (400 = 6 x 64 + 16
+    // for an 800-pixel view) the upper half has nothing to do.  No workgroup-level barrier follows, so it can leave.
+    if (level && blocked && (wave & 1) * 32 >= n_px) return;
     if (level && blocked) {
         // level view, blocked lane map: the wavefront owns 4 top rows x 32 columns (slots 0,1 = its two 16-column
         // groups) and their horizon mirrors (slots 2,3).  Longitude is per column, latitude per (column, row) and
