@@ -179,14 +179,16 @@ class Context:
         self.device = int(device)
         self.n_slots = int(n_slots)
         self.slot_locks = [threading.Lock() for _ in range(n_slots)]
-        self._buffers = []
+        self._buffers = set()                 # live DeviceBuffers; touched by reader and render threads alike
+        self._buffers_lock = threading.Lock()
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if self.handle:
-            for b in self._buffers:
+            with self._buffers_lock:
+                live, self._buffers = self._buffers, set()
+            for b in live:
                 b.free()
-            self._buffers = []
             self.L.gs360_ctx_destroy(self.handle)
             self.handle = None
 
@@ -206,13 +208,14 @@ class Context:
     # -- memory -----------------------------------------------------------------------------
     def alloc(self, nbytes):
         b = DeviceBuffer(self, nbytes)
-        self._buffers.append(b)
+        with self._buffers_lock:
+            self._buffers.add(b)
         return b
 
     def free(self, buf):
         buf.free()
-        if buf in self._buffers:
-            self._buffers.remove(buf)
+        with self._buffers_lock:
+            self._buffers.discard(buf)
 
     def pinned(self, nbytes):
         return PinnedBuffer(self, nbytes)

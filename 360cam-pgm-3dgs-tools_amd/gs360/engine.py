@@ -23,7 +23,11 @@ _SLOTS_PER_DEVICE = 4
 
 class _DeviceState:
     def __init__(self, device):
-        self.ctx = capi.Context(device=device, n_slots=_SLOTS_PER_DEVICE)
+        # render slots 0.._SLOTS_PER_DEVICE-1 plus ONE upload stream that _render never uses: a frame upload's sync then
+        # waits for that copy only, not for kernels and downloads queued by view jobs (and the reverse)
+        self.ctx = capi.Context(device=device, n_slots=_SLOTS_PER_DEVICE + 1)
+        self.upload_slot = _SLOTS_PER_DEVICE
+        self.upload_lock = threading.Lock()
         self.frames = collections.OrderedDict()   # key -> [DeviceBuffer, H, W, C, users]
         self.frame_bytes = 0
         self.lock = threading.Lock()              # guards the LRU bookkeeping
@@ -94,7 +98,8 @@ class Engine:
             if C not in (1, 3, 4):
                 raise capi.Gs360Error(-1, f"{path}: unsupported channel count {C}")
             buf = st.ctx.alloc(img.nbytes)
-            st.ctx.upload(buf, img, slot=0, sync=True)
+            with st.upload_lock:
+                st.ctx.upload(buf, img, slot=st.upload_slot, sync=True)
             entry = [buf, H, W, C, 1]             # last field: users currently holding the frame
             with st.lock:
                 st.frames[key] = entry

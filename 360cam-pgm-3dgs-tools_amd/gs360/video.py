@@ -18,6 +18,7 @@ bit-comparable with the reference's -- parity at this seam is unpinned (no ffmpe
 import os
 import re
 import subprocess
+import tempfile
 import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -80,6 +81,13 @@ def build_decode_plan(job: JobSpec) -> Optional[DecodePlan]:
         numbers = None                     # select without frame_pts: plain sequential numbering
     if numbers is None and "-frame_pts" in job.options:
         return None                        # pts-driven numbering without a select list cannot be reproduced
+    if numbers is not None and any(k in job.options for k in ("-ss", "-to", "-t")):
+        # The GUI keeps -ss/-to on the OUTPUT side next to -copyts (gs360_GUI.py:19094-19148): ffmpeg then drops every
+        # selected frame whose timestamp lies outside [S, T], and -frame_pts still names the survivors by their own
+        # index.  The PPM pipe carries no timestamps, so which selected indices survive cannot be known here without
+        # probing the stream; pairing the k-th decoded frame with the k-th selected index would misnumber every output.
+        # Such jobs stay on the reference's per-view subprocess path.
+        return None
     argv = [job.program, "-hide_banner", "-loglevel", "error", "-nostdin"]
     argv += [f for f in job.flags if f == "-copyts"]
 
@@ -172,9 +180,13 @@ class VideoSession:
     # reader thread ---------------------------------------------------------------------------------------------
     def _reader(self):
         pinned = {}
+        errlog = None
         try:
+            # stderr goes to an unnamed temporary file, not a pipe: a damaged stream can make ffmpeg print more than a pipe
+            # buffer holds while this thread is blocked on stdout, which would stall decoder and view jobs alike
+            errlog = tempfile.TemporaryFile()
             try:
-                self.proc = subprocess.Popen(list(self.plan.argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, bufsize=1 << 20)
+                self.proc = subprocess.Popen(list(self.plan.argv), stdout=subprocess.PIPE, stderr=errlog, bufsize=1 << 20)
             except OSError as exc:
                 raise PpmError("{}: {}".format(self.plan.argv[0], exc)) from exc
             if self.register_proc:
@@ -202,7 +214,7 @@ class VideoSession:
                 host = np.frombuffer(stage.view, dtype=np.uint8, count=nbytes)      # the pinned block as an array
                 read_exact_into(out, memoryview(host))
                 buf = st.ctx.alloc(nbytes)
-                st.ctx.upload(buf, host, slot=0, sync=True)
+                st.ctx.upload(buf, host, slot=st.upload_slot, sync=True)
                 with self.cond:
                     self.frames.append((st, buf, h, w))
                     self.bytes += nbytes
@@ -210,7 +222,8 @@ class VideoSession:
                 k += 1
             rc = self.proc.wait()
             if rc != 0:
-                text = (self.proc.stderr.read() or b"").decode(errors="ignore").strip()
+                errlog.seek(max(0, errlog.seek(0, os.SEEK_END) - 2000))
+                text = errlog.read().decode(errors="ignore").strip()
                 raise PpmError("decoder exited with code {}: {}".format(rc, text[-400:]))
         except Exception as exc:  # noqa: BLE001  (reported to every waiting view job)
             with self.cond:
@@ -223,6 +236,8 @@ class VideoSession:
         finally:
             for stage in pinned.values():
                 stage.free()
+            if errlog is not None:
+                errlog.close()
             if self.proc is not None and self.register_proc:
                 self.register_proc(self.proc, False)
             with self.cond:

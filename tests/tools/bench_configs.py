@@ -170,6 +170,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--only", default="", help="comma list of: equirect, fisheye, color (default all)")
+    ap.add_argument("--eq", default="", help="comma list of equirect rows: cfg1,cfg2,cfg2cubic,cfg3,cfg5,cfg5mask (default all)")
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=1)
     rows = []
@@ -183,16 +184,22 @@ def main():
             print(json.dumps(r))
         ctx.close()
         return
-    rows.append(equirect_cfg(ctx, "cfg1 5760x2880 -> default preset 8x1600^2", 5760, 2880, ring_views(8, 1600, HFOV_12MM), 8, args.steps))
-    rows.append(equirect_cfg(ctx, "cfg2 7680x3840 -> 6x800^2 (headline, bench.py)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps))
-    rows.append(equirect_cfg(ctx, "cfg2 with INTER_CUBIC (reference default interp)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps,
-                             interp=gs360.INTERP_CUBIC))
-    rows.append(equirect_cfg(ctx, "cfg3 7680x3840 -> full360coverage 12x1600^2", 7680, 3840,
-                             [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps))
-    rows.append(equirect_cfg(ctx, "cfg5 7680x3840 -> fisheyelike 10x2048^2 (u8, no fp16/mask fusion)", 7680, 3840,
-                             [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps))
-    rows.append(equirect_cfg(ctx, "cfg5 + fused keep-mask multiply (u8 mask, nearest, threshold 128)", 7680, 3840,
-                             [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps, with_mask=True))
+    eq = {
+        "cfg1": lambda: equirect_cfg(ctx, "cfg1 5760x2880 -> default preset 8x1600^2", 5760, 2880, ring_views(8, 1600, HFOV_12MM), 8, args.steps),
+        "cfg2": lambda: equirect_cfg(ctx, "cfg2 7680x3840 -> 6x800^2 (headline, bench.py)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps),
+        "cfg2cubic": lambda: equirect_cfg(ctx, "cfg2 with INTER_CUBIC (reference default interp)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8,
+                                          args.steps, interp=gs360.INTERP_CUBIC),
+        "cfg3": lambda: equirect_cfg(ctx, "cfg3 7680x3840 -> full360coverage 12x1600^2", 7680, 3840,
+                                     [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps),
+        "cfg5": lambda: equirect_cfg(ctx, "cfg5 7680x3840 -> fisheyelike 10x2048^2 (u8, no fp16/mask fusion)", 7680, 3840,
+                                     [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps),
+        "cfg5mask": lambda: equirect_cfg(ctx, "cfg5 + fused keep-mask multiply (u8 mask, nearest, threshold 128)", 7680, 3840,
+                                         [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps,
+                                         with_mask=True),
+    }
+    for name, fn in eq.items():
+        if not args.eq or name in args.eq.split(","):
+            rows.append(fn())
     if not only or "fisheye" in only:
         rows += fisheye_cfg(ctx, args.steps)
     if not only or "color" in only:
