@@ -26,8 +26,12 @@ class _Slot:
 
 
 class FramePipeline:
-    def __init__(self, ctx: capi.Context, W: int, H: int, Cn: int, views: Sequence[capi.View], n_slots: int = None):
+    def __init__(self, ctx: capi.Context, W: int, H: int, Cn: int, views: Sequence[capi.View], n_slots: int = None,
+                 copy_out: bool = True):
+        """copy_out=False hands results out as arrays that ALIAS the slot's pinned output buffers (valid until that slot
+        is handed out again by acquire()): a consumer that encodes or writes them right away needs no extra host copy."""
         self.ctx, self.W, self.H, self.C = ctx, W, H, Cn
+        self.copy_out = copy_out
         self.views = list(views)
         n_slots = n_slots or ctx.n_slots
         if n_slots > ctx.n_slots:
@@ -70,7 +74,9 @@ class FramePipeline:
 
     def _collect(self, s):
         self.ctx.sync(s.idx)
-        outs = [np.frombuffer(hb.view, dtype=np.uint8).reshape(shape).copy() for hb, shape in zip(s.h_out, self.view_shapes)]
+        outs = [np.frombuffer(hb.view, dtype=np.uint8).reshape(shape) for hb, shape in zip(s.h_out, self.view_shapes)]
+        if self.copy_out:
+            outs = [o.copy() for o in outs]
         s.busy = False
         return s.tag, outs
 

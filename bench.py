@@ -13,10 +13,17 @@ frame and are NOT what is reported).  `value` = output pixels written by all ran
     python bench.py --gpus 1 --steps 400 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            # no launcher in the environment: starts that torch.distributed.run itself
 
 Frames x views shard with no exchange step, so every rank runs the same per-GPU workload (weak scaling)
 and no collective touches the data path; torch.distributed is used only for the barrier and the
 max-over-ranks of the elapsed time.
+
+`--mode stream` is the host-fed STRONG-scaling companion (BASELINE.json configs[2], reference seam
+gs360_360PerspCut.py:1049-1078): 600 8K frames are dealt round-robin to the ranks (gs360/sharding.py), every frame
+goes pinned host -> H2D -> one 12-view `full360coverage` launch -> D2H through gs360/stream.py; the rate is bounded by
+PCIe (88.5 MB in + 92.2 MB out per frame), which the line reports next to the measured value.  It is never the
+headline `value` of the default mode.
 """
 import argparse
 import json
@@ -75,12 +82,14 @@ def cpu_baseline(np, frame, budget_s=10.0):
     ncpu = os.cpu_count() or 1
     cand = sorted({c for c in (ncpu, ncpu // 2, 64, 32, 16) if 1 <= c <= ncpu}, reverse=True)
     best, best_t = cand[0], None
+    sweep = {}
     for c in cand:
         orc.equirect_views_u8(frame, views, threads=c)              # warm this team size
         t0 = time.perf_counter()
         for _ in range(3):
             orc.equirect_views_u8(frame, views, threads=c)
         dt = (time.perf_counter() - t0) / 3
+        sweep[c] = dt
         if best_t is None or dt < best_t:
             best, best_t = c, dt
     n, t0 = 0, time.perf_counter()
@@ -91,9 +100,101 @@ def cpu_baseline(np, frame, budget_s=10.0):
         if dt >= budget_s or n >= 2000:
             break
     mpix = n * N_VIEWS * SIZE * SIZE / 1e6
+    # SURVEY 8(d) asks for both ends: the same port on ONE thread (2 passes, ~1 s) next to the best team size
+    t1 = time.perf_counter()
+    for _ in range(2):
+        orc.equirect_views_u8(frame, views, threads=1)
+    dt1 = (time.perf_counter() - t1) / 2
     return {"value": round(mpix / dt, 2), "unit": "MPix/s", "cores": best, "kind": "port",
             "sample": f"{n} passes of 1 frame x {N_VIEWS} views (same 8K->6x800^2 workload) in {dt:.1f} s; "
-                      f"OpenMP over (view,row), {best} of {ncpu} host threads (best of {cand})"}, outs
+                      f"OpenMP over (view,row), {best} of {ncpu} host threads (best of {cand})",
+            "single_thread": {"value": round(N_VIEWS * SIZE * SIZE / 1e6 / dt1, 2), "unit": "MPix/s", "cores": 1,
+                              "sample": "2 passes of the same frame on one thread"},
+            "all_threads": {"cores": ncpu, "value": round(N_VIEWS * SIZE * SIZE / 1e6 / sweep[ncpu], 2) if ncpu in sweep else None,
+                            "unit": "MPix/s", "sample": "3 passes at every host thread"}}, outs
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` typed by hand (no WORLD_SIZE in the environment): start the N ranks with the same
+    launcher the driver uses.  Runs before anything touches the GPU; the launcher is a CHILD process (never an exec)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(pathlib.Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
+    """BASELINE.json configs[2] fed from the host: 600 frames dealt to the ranks, pinned -> H2D -> 12 views -> D2H."""
+    from gs360.sharding import frames_for_rank
+    from gs360.stream import FramePipeline
+    hf = 104.2500326978036                       # fov_from_focal_mm(14, 36): the full360coverage preset (PC:614-626)
+    layout = [(0, 0), (45, 30), (45, -30), (90, 0), (135, 30), (135, -30), (180, 0), (-135, 30), (-135, -30), (-90, 0), (-45, 30), (-45, -30)]
+    size = args.stream_size
+    specs = [(float(y), float(p), hf, hf, size, size) for y, p in layout]
+    views = [gs360.View.make(*v) for v in specs]
+    mine = frames_for_rank(args.stream_frames, world, rank)
+    n_slots = 3
+    pipe = FramePipeline(ctx, W, H, C, views, n_slots=n_slots, copy_out=False)   # results alias pinned memory
+    # every slot's pinned input holds its own synthetic frame; a decoder would write the next frame in place
+    # (FramePipeline.acquire()/commit(), what gs360/video.py's reader does), so no host-side copy sits in the timed loop
+    for k in range(n_slots):
+        _done, buf = pipe.acquire()
+        buf[:] = synth_frame(np, k + 7 * rank).reshape(-1)
+        pipe.commit(tag=("warm", k))
+    last = None
+    for tag, outs in pipe.drain():
+        last = (tag, outs)
+    barrier()
+    t0 = time.perf_counter()
+    for fidx in mine:
+        _done, _buf = pipe.acquire()
+        pipe.commit(tag=fidx)
+    for tag, outs in pipe.drain():
+        last = (tag, [outs[k].copy() for k in (0, 1, 8)])
+    ctx.sync(-1)
+    local = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline and last is not None:
+        from oracle import orc
+        orc.build()
+        slot_frame = synth_frame(np, ((len(mine) - 1) % n_slots if mine else 0) + 7 * rank)   # what the last slot's buffer holds
+        pick = [0, 1, 8]
+        want = orc.equirect_views_u8(slot_frame, [orc.make_view(*specs[k]) for k in pick], threads=0)
+        parity = all(np.array_equal(g, w) for g, w in zip(last[1], want))
+    pipe.close()
+    if rank == 0:
+        px = args.stream_frames * len(views) * size * size
+        in_b, out_b = W * H * C, len(views) * size * size * C
+        line = {
+            "metric": "MPix/s remapped, 8K equirect->preset views", "value": round(px / elapsed / 1e6, 1), "unit": "MPix/s",
+            "n_gpus": world, "steps": args.stream_frames, "warmup": n_slots, "ms_per_step": round(elapsed * 1e3 / max(1, args.stream_frames), 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"HOST-FED stream (not the headline): {args.stream_frames} 7680x3840x3 frames dealt round-robin to {world} rank(s) -> "
+                                   f"full360coverage 12x{size}x{size}, pinned host -> H2D -> one 12-view launch -> D2H per frame "
+                                   "(BASELINE.json configs[2]; PC:1049-1078)",
+                       "frames_total": args.stream_frames, "frames_rank0": len(mine), "views": len(views), "device": info["name"],
+                       "parallelism": f"frames sharded x{world}, no collective", "parity_vs_oracle": parity,
+                       "frames_per_s": round(args.stream_frames / elapsed, 1), "rank0_seconds": round(local, 4),
+                       "pcie_bytes_per_frame": {"h2d": in_b, "d2h": out_b},
+                       "pcie_bound_frames_per_s_per_gpu": round(63e9 / max(in_b, out_b), 1)},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line))
 
 
 def main():
@@ -107,14 +208,30 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (gloo: control-flow tests on a box "
                          "with fewer GPUs than ranks; ranks then share devices round-robin)")
+    ap.add_argument("--mode", default="resident", choices=["resident", "stream"],
+                    help="resident (default, the headline): HBM-resident cfg2 launches, weak scaling; stream: host-fed cfg3 frames "
+                         "dealt to the ranks, strong scaling, PCIe-bound")
+    ap.add_argument("--stream-frames", type=int, default=600, help="--mode stream: total frames of the job (all ranks)")
+    ap.add_argument("--stream-size", type=int, default=1600, help="--mode stream: view size (full360coverage: 1600)")
     ap.add_argument("--stride-pad", type=int, default=0, help="experiments only: extra bytes per source row")
     ap.add_argument("--src-width", type=int, default=7680, help="experiments only: equirect width (height = width/2); "
                     "any value other than 7680 is NOT the BASELINE workload and is labelled as such")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
     if args.src_width != W:
         globals()["W"], globals()["H"] = args.src_width, args.src_width // 2
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(_self_launch(args.gpus))          # nothing has touched the GPU yet; the ranks are child processes
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; run\n"
+              f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+              f"--master-port P bench.py --gpus {args.gpus} ...\n(or plain `python bench.py --gpus {args.gpus}`, which starts it)",
+              file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.with_torch
@@ -129,6 +246,10 @@ def main():
         n_dev = max(1, torch.cuda.device_count())
         if args.backend == "gloo":
             local_rank %= n_dev
+        elif local_rank >= n_dev:
+            print(f"bench.py: rank {rank} needs GPU {local_rank} but only {n_dev} are visible (one rank per GPU over RCCL); "
+                  "--backend gloo lets ranks share devices for control-flow tests", file=sys.stderr)
+            sys.exit(3)
         torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on stdout when the first communicator comes up; stdout must carry exactly one
         # JSON line, so fd 1 points at stderr while the group is created and warmed up.
@@ -151,8 +272,22 @@ def main():
     import numpy as np
     import gs360
 
-    ctx = gs360.Context(device=local_rank if use_dist else 0, n_slots=2)
+    ctx = gs360.Context(device=local_rank if use_dist else 0, n_slots=3 if args.mode == "stream" else 2)
     info = ctx.info()
+
+    def barrier():
+        ctx.sync(-1)
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.mode == "stream":
+        stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist if use_dist else None, torch)
+        ctx.close()
+        if use_dist:
+            dist.destroy_process_group()
+        return
     views = [gs360.View.make(*v) for v in view_table()]
     nf = max(1, min(args.frames, gs360.capi.MAX_FRAMES))
     frames_host = [synth_frame(np, k + 7 * rank) for k in range(nf)]
@@ -168,13 +303,6 @@ def main():
         d_frames = [ctx.to_device(f) for f in frames_host]
     d_out = [ctx.alloc(SIZE * SIZE * C) for _ in range(nf * N_VIEWS)]
     step = ctx.make_equirect_call(d_frames, W, H, C, views, d_out, slot=0, src_stride=stride if args.stride_pad else 0)
-
-    def barrier():
-        ctx.sync(-1)
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -211,11 +339,12 @@ def main():
         px_per_step = nf * N_VIEWS * SIZE * SIZE
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = world * px_per_step * args.steps / elapsed / 1e6
+        baseline_shape = (W == 7680 and args.stride_pad == 0)   # ALGO_BYTES_PER_FRAME was counted for the 7680-wide source only
         algo_bytes = ALGO_BYTES_PER_FRAME * nf
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"        # written from rocprofv3 --pmc passes (see profiles/README.md)
-        if tf.exists():
+        if tf.exists() and baseline_shape:
             try:
                 rec = json.loads(tf.read_text())
                 if rec.get("frames_per_launch") == nf:
@@ -233,7 +362,7 @@ def main():
                        "frames_per_step": nf, "views": N_VIEWS, "out_px_per_step": px_per_step,
                        "device": info["name"], "parallelism": f"frames sharded x{world}, no collective",
                        "parity_vs_oracle": parity},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": None if not baseline_shape else {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          # same launch time against the bytes the PMC counters saw move (whole 128-B lines), for context
                          "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),

@@ -84,3 +84,13 @@ def test_two_rank_gloo_sharding():
     views = [orc.make_view(y, 0, 90, 90, 16, 16) for y in (0, 120, -120)]
     truth = [int(sum(int(o.astype(np.int64).sum()) for o in orc.equirect_views_u8(f, views))) for f in frames]
     assert truth == sums0
+
+
+def test_bench_world_size_mismatch_is_refused():
+    """ADVICE r1 (bench.py:103): --gpus N with a launcher that started another world size exits non-zero before any GPU call"""
+    import pathlib
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 2 and "WORLD_SIZE=2" in p.stderr
