@@ -235,7 +235,7 @@ def run_one(cmd: List[str]) -> Tuple[int, str]:
     try:
         from gs360 import engine as _engine
         if plan is None:
-            _engine.get_engine().run_job(job)
+            _engine.get_engine().run_job(job, stop_event=stop_event)
         else:
             _engine.get_engine().run_video_job(job, plan, stop_event=stop_event, register_proc=_track_proc,
                                                expected_jobs=_planned_video_jobs.get(str(job.src)))
@@ -266,6 +266,23 @@ def build_view_jobs(args, files: List[pathlib.Path], out_dir: pathlib.Path) -> B
                 counts[key] = counts.get(key, 0) + 1
         _planned_video_jobs.update(counts)
     return result
+
+
+def _announce_jobs(jobs_list, workers: int) -> None:
+    """Tell the engine how many view jobs of each source can arrive together so that it batches them into one launch
+    without waiting out its linger window (gs360/engine.py).  Purely a hint: run_one works without it (the GUI path)."""
+    try:
+        from gs360 import engine as _engine
+        specs = []
+        for cmd, _src, _dst in jobs_list:
+            try:
+                specs.append(parse_job_argv(list(cmd)))
+            except JobParseError:
+                pass
+        if specs:
+            _engine.get_engine().announce(specs, workers=workers)
+    except Exception:  # noqa: BLE001  (no GPU / no library: run_one reports that per job, exactly as before)
+        pass
 
 
 # ---- main (PC:983-1087) --------------------------------------------------------------------------------
@@ -326,6 +343,8 @@ def main():
             if line:
                 print(line)
 
+    if _selected_engine() != "ffmpeg":
+        _announce_jobs(jobs_list, jobs)
     ok = fail = done = 0
     last_pct = -1
     with ThreadPoolExecutor(max_workers=jobs) as pool:

@@ -3,13 +3,21 @@
 Unit of work = (frame, view), exactly the reference's job granularity (PC:830-836).  Sharding is by FRAME:
 all views of one source image run on the same device, so the decoded frame is uploaded once and stays
 resident in HBM (an LRU of device frames per GPU); there is no exchange step and therefore no collective.
-Concurrency comes from the caller's thread pool (PC:1049 / gs360_GUI.py:19297): each call takes one of the
-device's stream slots.
+Concurrency comes from the caller's thread pool (PC:1049 / gs360_GUI.py:19297).
+
+Launch shape.  The callers hand over ONE (frame, view) at a time, but a single 800^2 view is ~350 workgroups -- a
+quarter of the chip's resident slots -- so a launch per view is all tail.  The jobs of one frame arrive together (the
+planner emits them frame-major and the pool starts them concurrently), so they are COALESCED: the first job of a
+frame becomes the batch leader, gets the frame resident, waits a short linger (GS360_BATCH_LINGER_MS, default 3 ms;
+it leaves early once the announced number of views has arrived), then renders every view that joined in ONE batched
+launch, queues all device->pinned-host copies on the same stream and synchronises once.  Every job then encodes its
+own view in its own thread (the encoders are the end-to-end bound, scripts/bench_cli_e2e.py).
 """
 import collections
 import itertools
 import os
 import threading
+import time
 import zlib
 
 import numpy as np
@@ -19,6 +27,19 @@ from .jobspec import JobSpec
 
 _FRAME_CACHE_BYTES = int(os.environ.get("GS360_FRAME_CACHE_MB", "4096")) << 20
 _SLOTS_PER_DEVICE = 4
+_LINGER_S = float(os.environ.get("GS360_BATCH_LINGER_MS", "3")) * 1e-3
+
+
+class _Batch:
+    """Views of ONE frame (same interpolation / projection flags) that go out as one launch."""
+    __slots__ = ("views", "state", "done", "results", "error")
+
+    def __init__(self):
+        self.views = []                 # capi.View, in arrival order
+        self.state = "open"             # open -> running -> done
+        self.done = threading.Event()
+        self.results = None             # list of (ndarray aliasing a pinned buffer, PinnedBuffer)
+        self.error = None
 
 
 class _DeviceState:
@@ -34,6 +55,23 @@ class _DeviceState:
         self.key_locks = {}                       # key -> lock: one decode+upload per frame
         self.slot_cycle = itertools.cycle(range(_SLOTS_PER_DEVICE))
         self.out_bufs = [None] * _SLOTS_PER_DEVICE   # grow-only per-slot output buffers (no hipMalloc/hipFree per job)
+        self.batch_cond = threading.Condition()   # guards open_batches
+        self.open_batches = {}                    # (frame key, interp, flags) -> _Batch still collecting views
+        self.pool_lock = threading.Lock()
+        self.dev_pool = collections.defaultdict(list)    # nbytes -> free DeviceBuffers (view outputs)
+        self.pin_pool = collections.defaultdict(list)    # nbytes -> free PinnedBuffers
+        self.stats = collections.Counter()        # launches, views, gpu_s (launch + copies, wall on the stream), ...
+
+    def take(self, pool, nbytes, make):
+        with self.pool_lock:
+            free = pool[nbytes]
+            if free:
+                return free.pop()
+        return make(nbytes)
+
+    def give(self, pool, buf):
+        with self.pool_lock:
+            pool[buf.nbytes].append(buf)
 
     def out_buffer(self, slot, nbytes):
         buf = self.out_bufs[slot]
@@ -58,6 +96,8 @@ class Engine:
         self._warned_cubic = False
         self.videos = {}                          # DecodePlan.key -> video.VideoSession
         self.videos_lock = threading.Lock()
+        self._expected = {}                       # str(source path) -> view jobs that can arrive together (announce())
+        self._announce_lock = threading.Lock()
 
     def close(self):
         with self.videos_lock:
@@ -65,6 +105,12 @@ class Engine:
         for sess in sessions:
             sess.close()
         for st in self.states:
+            with st.pool_lock:
+                pinned = [hb for free in st.pin_pool.values() for hb in free]
+                st.pin_pool.clear()
+                st.dev_pool.clear()               # device buffers are owned (and freed) by the context
+            for hb in pinned:
+                hb.free()
             st.ctx.close()
         self.states = []
 
@@ -154,28 +200,121 @@ class Engine:
             return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), hfov, vfov, w, h), capi.EQ_FISHEYE_OUT
         return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"), job.width, job.height), 0
 
-    def _render(self, st: _DeviceState, buf, H, W, C, view, interp, flags=0):
+    def _launch_batch(self, st: _DeviceState, buf, H, W, C, views, interp, flags):
+        """One batched launch for `views` of one resident frame; returns [(array aliasing pinned memory, PinnedBuffer)]."""
         with st.lock:
             slot = next(st.slot_cycle)
-        out_bytes = view.height * view.width * C
-        with st.ctx.slot_locks[slot]:
-            dst = st.out_buffer(slot, out_bytes)
-            st.ctx.equirect_views_dev([buf], W, H, C, [view], [dst], slot=slot, interp=interp, flags=flags)
-            return st.ctx.download(dst, (view.height, view.width, C), slot=slot)
+        ctx, L = st.ctx, st.ctx.L
+        sizes = [v.height * v.width * C for v in views]
+        d_out = [st.take(st.dev_pool, n, ctx.alloc) for n in sizes]
+        h_out = [st.take(st.pin_pool, n, ctx.pinned) for n in sizes]
+        t0 = time.perf_counter()
+        try:
+            with ctx.slot_locks[slot]:
+                ctx.equirect_views_dev([buf], W, H, C, views, d_out, slot=slot, interp=interp, flags=flags)
+                for d, hb, n in zip(d_out, h_out, sizes):
+                    capi._check(L.gs360_download(ctx.handle, hb.ptr, d.ptr, n, slot), L)
+                ctx.sync(slot)
+        finally:
+            for d in d_out:
+                st.give(st.dev_pool, d)
+        with st.pool_lock:
+            st.stats["launches"] += 1
+            st.stats["views"] += len(views)
+            st.stats["gpu_s"] += time.perf_counter() - t0
+        return [(np.frombuffer(hb.view, dtype=np.uint8, count=n).reshape(v.height, v.width, C), hb)
+                for hb, n, v in zip(h_out, sizes, views)]
 
-    def run_job(self, job: JobSpec):
+    def _render(self, st: _DeviceState, fkey, get_frame, view, interp, flags=0, expected=1, stop_event=None):
+        """Render `view` of the frame identified by `fkey`, coalesced with the other views of that frame that arrive
+        within the linger window.  get_frame() -> (DeviceBuffer, H, W, C) is called by the batch leader only.
+        Returns (array, release): the array aliases pinned host memory until release() is called."""
+        key = (fkey, interp, flags)
+        with st.batch_cond:
+            b = st.open_batches.get(key)
+            leader = b is None
+            if leader:
+                b = st.open_batches[key] = _Batch()
+            idx = len(b.views)
+            b.views.append(view)
+            st.batch_cond.notify_all()
+        if leader:
+            try:
+                buf, H, W, C = get_frame()            # decode + upload happen here; followers keep arriving meanwhile
+                deadline = time.monotonic() + (_LINGER_S if expected > 1 else 0.0)
+                with st.batch_cond:
+                    while len(b.views) < min(expected, capi.MAX_VIEWS):
+                        left = deadline - time.monotonic()
+                        if left <= 0 or (stop_event is not None and stop_event.is_set()):
+                            break
+                        st.batch_cond.wait(left)
+                    b.state = "running"
+                    del st.open_batches[key]
+                    views = list(b.views)
+                b.results = self._launch_batch(st, buf, H, W, C, views, interp, flags)
+            except BaseException as exc:  # noqa: BLE001  (handed to every member of the batch)
+                with st.batch_cond:
+                    if st.open_batches.get(key) is b:
+                        del st.open_batches[key]
+                b.error = exc
+            finally:
+                b.state = "done"
+                b.done.set()
+        else:
+            while not b.done.wait(0.25):
+                if stop_event is not None and stop_event.is_set():
+                    break
+        if b.error is not None:
+            if leader:
+                raise b.error
+            raise capi.Gs360Error(-2, f"batched launch failed: {b.error}")
+        if b.results is None:
+            raise capi.Gs360Error(-2, "cancelled")
+        arr, hb = b.results[idx]
+        return arr, (lambda: st.give(st.pin_pool, hb))
+
+    def announce(self, jobs, workers=None):
+        """Optional hint from a caller that knows its whole job list (the drop-in CLI's main()): how many view jobs each
+        source has, and how many of them can be in flight at once.  Lets a batch leader stop lingering as soon as every
+        view that can arrive has arrived.  Without it every batch simply lingers for the full window."""
+        counts = collections.Counter(str(j.src) for j in jobs)
+        with self._announce_lock:
+            for k, n in counts.items():
+                self._expected[k] = min(n, workers) if workers else n
+
+    def _expected_for(self, src) -> int:
+        with self._announce_lock:
+            return self._expected.get(str(src), capi.MAX_VIEWS)
+
+    def run_job(self, job: JobSpec, stop_event=None):
         """Execute one (frame, view) job; returns the output array after writing job.dst."""
         view, flags = self._view_for(job)
         interp = self._interp_for(job)
         st = self.states[self.device_for(job.src)]
-        entry = self.resident_frame(st, job.src)
+        held = []
+
+        def get_frame():
+            entry = self.resident_frame(st, job.src)
+            held.append(entry)
+            return entry[:4]
         try:
-            buf, H, W, C = entry[:4]
-            out = self._render(st, buf, H, W, C, view, interp, flags)
+            arr, release = self._render(st, self._frame_key(job.src), get_frame, view, interp, flags,
+                                        expected=self._expected_for(job.src), stop_event=stop_event)
         finally:
-            self.release_frame(st, entry)
-        imageio.write_image(job.dst, out, jpeg_q=job.jpeg_q)
-        return out
+            for entry in held:
+                self.release_frame(st, entry)
+        try:
+            imageio.write_image(job.dst, arr, jpeg_q=job.jpeg_q)
+            return np.array(arr)
+        finally:
+            release()
+
+    def stats(self):
+        """Counters since start: batched launches, views, seconds the launch+copy sections held a stream."""
+        total = collections.Counter()
+        for st in self.states:
+            total.update(st.stats)
+        return dict(total)
 
     # -- video: one decode, frames resident in HBM, every view job walks them (gs360/video.py) -------------------
     def _video_session(self, plan, stop_event, register_proc):
@@ -200,8 +339,13 @@ class Engine:
                 if fr is None:
                     break
                 st, buf, H, W = fr
-                out = self._render(st, buf, H, W, 3, view, interp, flags)
-                imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)
+                # the view jobs of a video walk its frames together: frame k of every active view goes out as one launch
+                out, release = self._render(st, ("video", plan.key, written), lambda: (buf, H, W, 3), view, interp, flags,
+                                            expected=min(sess.active_jobs, expected_jobs or sess.active_jobs), stop_event=stop_event)
+                try:
+                    imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)
+                finally:
+                    release()
                 written += 1
         finally:
             with self.videos_lock:
