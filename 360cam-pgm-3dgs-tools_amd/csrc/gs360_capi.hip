@@ -56,6 +56,7 @@ struct gs360_ctx {
     hipDeviceProp_t prop;
     int16_t* d_cubic = nullptr;   // 32*32*16 int16 cubic weight table, uploaded at context creation
     int16_t* d_lanczos = nullptr; // 32*32*64 int16 Lanczos4 weight table
+    float* d_coef1d = nullptr;    // 448 float32 1-D phase coefficients for the 16-bit (float-weight) samplers
 };
 
 namespace {
@@ -183,8 +184,8 @@ void build_tab2d(const float* c1, int ks, int16_t* out) {
 }
 }  // namespace
 
-void gs360::build_cubic_table(int16_t* out) {   // Keys kernel, A = -0.75
-    float c1[32 * 4];
+namespace {
+void cubic_coef1d(float* c1) {   // Keys kernel, A = -0.75: 32 phases x 4 taps
     const float A = -0.75f;
     for (int i = 0; i < 32; ++i) {
         const float x = (float)i * (1.0f / 32.0f);
@@ -194,13 +195,11 @@ void gs360::build_cubic_table(int16_t* out) {   // Keys kernel, A = -0.75
         c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
         c[3] = 1.f - c[0] - c[1] - c[2];
     }
-    build_tab2d(c1, 4, out);
 }
 
-void gs360::build_lanczos4_table(int16_t* out) {   // OpenCV interpolateLanczos4: taps -3..+4, one sin/cos pair per phase
+void lanczos4_coef1d(float* c1) {   // OpenCV interpolateLanczos4: taps -3..+4, one sin/cos pair per phase; 32 phases x 8 taps
     static const double r = 0.70710678118654752440084436210485;
     static const double rot[8][2] = {{1, 0}, {-r, -r}, {0, 1}, {r, -r}, {-1, 0}, {r, r}, {0, -1}, {-r, r}};
-    float c1[32 * 8];
     for (int i = 0; i < 32; ++i) {
         const float x = (float)i * (1.0f / 32.0f);
         float* c = c1 + i * 8;
@@ -218,7 +217,30 @@ void gs360::build_lanczos4_table(int16_t* out) {   // OpenCV interpolateLanczos4
         sum = 1.f / sum;
         for (int t = 0; t < 8; ++t) c[t] *= sum;
     }
+}
+}  // namespace
+
+void gs360::build_cubic_table(int16_t* out) {
+    float c1[32 * 4];
+    cubic_coef1d(c1);
+    build_tab2d(c1, 4, out);
+}
+
+void gs360::build_lanczos4_table(int16_t* out) {
+    float c1[32 * 8];
+    lanczos4_coef1d(c1);
     build_tab2d(c1, 8, out);
+}
+
+// float32 1-D phase tables of the CV_16U samplers: [0,64) linear (1-x, x), [64,192) cubic, [192,448) lanczos4
+void gs360::build_coef1d(float* out) {
+    for (int i = 0; i < 32; ++i) {
+        const float x = (float)i * (1.0f / 32.0f);
+        out[i * 2] = 1.f - x;
+        out[i * 2 + 1] = x;
+    }
+    cubic_coef1d(out + 64);
+    lanczos4_coef1d(out + 192);
 }
 
 namespace {
@@ -293,6 +315,12 @@ int gs360_ctx_create(int device, int n_slots, gs360_ctx** out) {
             e = hipMalloc((void**)&c->d_lanczos, tab.size() * sizeof(int16_t));
             if (e == hipSuccess) e = hipMemcpy(c->d_lanczos, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice);
         }
+        if (e == hipSuccess) {
+            float coef[448];
+            build_coef1d(coef);
+            e = hipMalloc((void**)&c->d_coef1d, sizeof(coef));
+            if (e == hipSuccess) e = hipMemcpy(c->d_coef1d, coef, sizeof(coef), hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             int rc = fail(GS360_ERR_HIP, "interpolation table upload failed: %s", hipGetErrorString(e));
             gs360_ctx_destroy(c);
@@ -317,6 +345,7 @@ int gs360_ctx_destroy(gs360_ctx* c) {
     }
     if (c->d_cubic) (void)hipFree(c->d_cubic);
     if (c->d_lanczos) (void)hipFree(c->d_lanczos);
+    if (c->d_coef1d) (void)hipFree(c->d_coef1d);
     delete c;
     return GS360_OK;
 }
@@ -407,16 +436,37 @@ int gs360_event_elapsed_ms(gs360_ctx* c, int slot, int from, int to, float* ms) 
 }
 
 // ---- equirect -> views -------------------------------------------------------------------------
+namespace {
+int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void* const* mask_frames, int n_frames,
+                        int W, int H, int C, size_t src_stride, size_t mask_stride, const gs360_view* views,
+                        int n_views, void* const* dst, size_t dst_stride, int interp, uint32_t flags, int slot, int esize);
+}
+
 int gs360_equirect_views_u8(gs360_ctx* c, const void* const* src_frames, int n_frames, int W, int H, int C,
                             size_t src_stride, const gs360_view* views, int n_views, void* const* dst,
                             size_t dst_stride, int interp, uint32_t flags, int slot) {
-    return gs360_equirect_views_masked_u8(c, src_frames, nullptr, n_frames, W, H, C, src_stride, 0, views, n_views, dst,
-                                          dst_stride, interp, flags, slot);
+    return equirect_views_impl(c, src_frames, nullptr, n_frames, W, H, C, src_stride, 0, views, n_views, dst,
+                               dst_stride, interp, flags, slot, 1);
+}
+
+int gs360_equirect_views_u16(gs360_ctx* c, const void* const* src_frames, int n_frames, int W, int H, int C,
+                             size_t src_stride, const gs360_view* views, int n_views, void* const* dst,
+                             size_t dst_stride, int interp, uint32_t flags, int slot) {
+    return equirect_views_impl(c, src_frames, nullptr, n_frames, W, H, C, src_stride, 0, views, n_views, dst,
+                               dst_stride, interp, flags, slot, 2);
 }
 
 int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, const void* const* mask_frames, int n_frames,
                                    int W, int H, int C, size_t src_stride, size_t mask_stride, const gs360_view* views,
                                    int n_views, void* const* dst, size_t dst_stride, int interp, uint32_t flags, int slot) {
+    return equirect_views_impl(c, src_frames, mask_frames, n_frames, W, H, C, src_stride, mask_stride, views, n_views, dst,
+                               dst_stride, interp, flags, slot, 1);
+}
+
+namespace {
+int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void* const* mask_frames, int n_frames,
+                        int W, int H, int C, size_t src_stride, size_t mask_stride, const gs360_view* views,
+                        int n_views, void* const* dst, size_t dst_stride, int interp, uint32_t flags, int slot, int esize) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
     if (!src_frames || !views || !dst) return fail(GS360_ERR_ARG, "NULL argument");
     if (mask_frames) {
@@ -434,14 +484,15 @@ int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, 
     if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_CUBIC)
         return fail(GS360_ERR_UNSUPPORTED, "equirect path implements INTER_LINEAR (1) and INTER_CUBIC (2), got %d", interp);
     if (flags & ~(uint32_t)GS360_EQ_FISHEYE_OUT) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
-    if (src_stride == 0) src_stride = (size_t)W * C;
-    if (src_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "src_stride smaller than a row");
+    if (src_stride == 0) src_stride = (size_t)W * C * esize;
+    if (src_stride < (size_t)W * C * esize) return fail(GS360_ERR_ARG, "src_stride smaller than a row");
+    if (esize == 2 && ((src_stride | dst_stride) & 1)) return fail(GS360_ERR_ARG, "16-bit images need even strides");
     if (src_stride >= ((size_t)1 << 24) || (uint64_t)src_stride * (uint64_t)H >= ((uint64_t)1 << 32))
         return fail(GS360_ERR_UNSUPPORTED, "frame too large for 32-bit tap offsets (stride %zu x %d rows)", src_stride, H);
     for (int k = 0; k < n_views; ++k) {
         if (views[k].width < 1 || views[k].height < 1 || views[k].width > 32768 || views[k].height > 32768)
             return fail(GS360_ERR_ARG, "view %d has bad size %dx%d", k, views[k].width, views[k].height);
-        if (dst_stride && dst_stride < (size_t)views[k].width * C) return fail(GS360_ERR_ARG, "dst_stride smaller than a row");
+        if (dst_stride && dst_stride < (size_t)views[k].width * C * esize) return fail(GS360_ERR_ARG, "dst_stride smaller than a row");
         if (!std::isfinite(views[k].yaw_deg) || !std::isfinite(views[k].pitch_deg) || !std::isfinite(views[k].hfov_deg) ||
             !std::isfinite(views[k].vfov_deg))
             return fail(GS360_ERR_ARG, "view %d has a non-finite angle", k);
@@ -461,6 +512,12 @@ int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, 
             int base = 0;
             for (int k = 0; k < nv; ++k) {
                 make_eq_view(views[v0 + k], W, (flags & GS360_EQ_FISHEYE_OUT) != 0, &L.view[k]);
+                if (esize == 2) {        // the 16-bit kernel walks whole rows of the full view: plain 64 x 16 tiling
+                    L.view[k].level = 0;
+                    L.view[k].blocked = 0;
+                    L.view[k].tiles_x = (views[v0 + k].width + kTileW - 1) / kTileW;
+                    L.view[k].tiles_y = (views[v0 + k].height + kTileH - 1) / kTileH;
+                }
                 L.view[k].tile_base = base;
                 base += L.view[k].tiles_x * L.view[k].tiles_y;
             }
@@ -481,7 +538,9 @@ int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, 
             L.mask_stride = (int64_t)mask_stride;
             L.dst_stride = (int64_t)dst_stride;
             L.cubic_tab = c->d_cubic;
-            if (interp == GS360_INTERP_CUBIC) {   // same tiling and symmetry reuse, 4x4 taps
+            if (esize == 2) {
+                HIP_TRY(launch_equirect_u16(L, C, interp == GS360_INTERP_CUBIC, c->stream[slot]));
+            } else if (interp == GS360_INTERP_CUBIC) {   // same tiling and symmetry reuse, 4x4 taps
                 HIP_TRY(launch_equirect_cubic(L, C, c->stream[slot]));
             } else {
                 HIP_TRY(launch_equirect(L, C, c->stream[slot]));
@@ -490,6 +549,7 @@ int gs360_equirect_views_masked_u8(gs360_ctx* c, const void* const* src_frames, 
     }
     return GS360_OK;
 }
+}  // namespace
 
 // ---- table remap -------------------------------------------------------------------------------
 namespace {
@@ -544,6 +604,39 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     J.src = src; J.H = H; J.W = W; J.src_stride = src_stride; J.map_x = map_x; J.map_y = map_y; J.valid = valid;
     J.h = h; J.w = w; J.fill_value = fill_value; J.dst = dst; J.dst_stride = dst_stride;
     return gs360_remap_tables_u8(c, &J, 1, C, interp, border_value, slot);
+}
+
+int gs360_remap_table_u16(gs360_ctx* c, const void* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                          const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                          const double* border_value, int fill_value, void* dst, size_t dst_stride, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!src || !map_x || !map_y || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
+    if (H < 1 || W < 1 || H >= 32767 || W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", W, H);
+    if (h < 0 || w < 0 || h >= 32767 || w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", w, h);
+    if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC &&
+        interp != GS360_INTERP_LANCZOS4)
+        return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2, lanczos4=4)", interp);
+    if (h == 0 || w == 0) return GS360_OK;
+    if (src_stride == 0) src_stride = (size_t)W * C * 2;
+    if (dst_stride == 0) dst_stride = (size_t)w * C * 2;
+    if (src_stride < (size_t)W * C * 2 || dst_stride < (size_t)w * C * 2) return fail(GS360_ERR_ARG, "stride smaller than a row");
+    if ((src_stride | dst_stride) & 1) return fail(GS360_ERR_ARG, "16-bit images need even strides");
+    HIP_TRY(hipSetDevice(c->device));
+    TableLaunch L;
+    std::memset(&L, 0, sizeof(L));
+    L.src = (const uint8_t*)src; L.map_x = map_x; L.map_y = map_y; L.valid = valid; L.dst = (uint8_t*)dst;
+    L.H = H; L.W = W; L.h = h; L.w = w;
+    L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
+    L.interp = interp;
+    L.fill = fill_value < 0 ? 0 : (fill_value > 65535 ? 65535 : fill_value);
+    uint16_t cval[4];
+    for (int k = 0; k < 4; ++k) {      // cv::saturate_cast<ushort>(double)
+        long r = std::lrint(border_value ? border_value[k] : 0.0);
+        cval[k] = (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+    }
+    HIP_TRY(launch_table_u16(L, C, c->d_coef1d, cval, c->stream[slot]));
+    return GS360_OK;
 }
 
 // ---- fused fisheye -> views --------------------------------------------------------------------
@@ -688,15 +781,16 @@ int gs360_color_apply_u8(gs360_ctx* c, const gs360_color_plan* p, const void* sr
 }
 
 // ---- host-buffer conveniences ------------------------------------------------------------------
-int gs360_equirect_views_u8_host(gs360_ctx* c, const uint8_t* src, int W, int H, int C, size_t src_stride,
-                                 const gs360_view* views, int n_views, uint8_t* const* dst, size_t dst_stride,
-                                 int interp, uint32_t flags, int slot) {
+namespace {
+int equirect_views_host_impl(gs360_ctx* c, const void* src, int W, int H, int C, size_t src_stride,
+                             const gs360_view* views, int n_views, void* const* dst, size_t dst_stride,
+                             int interp, uint32_t flags, int slot, int esize) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
     if (!src || !views || !dst) return fail(GS360_ERR_ARG, "NULL argument");
     if (n_views <= 0) return n_views == 0 ? GS360_OK : fail(GS360_ERR_ARG, "negative count");
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
     if (W < 2 || H < 2) return fail(GS360_ERR_ARG, "bad source size");
-    if (src_stride == 0) src_stride = (size_t)W * C;
+    if (src_stride == 0) src_stride = (size_t)W * C * esize;
     HIP_TRY(hipSetDevice(c->device));
     Staging& S = c->stage[slot];
     size_t src_bytes = src_stride * (size_t)H;
@@ -704,7 +798,7 @@ int gs360_equirect_views_u8_host(gs360_ctx* c, const uint8_t* src, int W, int H,
     size_t total = 0;
     for (int k = 0; k < n_views; ++k) {
         if (views[k].width < 1 || views[k].height < 1) return fail(GS360_ERR_ARG, "view %d has bad size", k);
-        size_t ds = dst_stride ? dst_stride : (size_t)views[k].width * C;
+        size_t ds = dst_stride ? dst_stride : (size_t)views[k].width * C * esize;
         off[k] = total;
         total += (ds * (size_t)views[k].height + 255) & ~(size_t)255;
     }
@@ -715,28 +809,41 @@ int gs360_equirect_views_u8_host(gs360_ctx* c, const uint8_t* src, int W, int H,
     std::vector<void*> dptr(n_views);
     for (int k = 0; k < n_views; ++k) dptr[k] = (uint8_t*)S.d_dst + off[k];
     const void* frames[1] = {S.d_src};
-    if (int rc = gs360_equirect_views_u8(c, frames, 1, W, H, C, src_stride, views, n_views, dptr.data(), dst_stride, interp,
-                                         flags, slot))
+    if (int rc = equirect_views_impl(c, frames, nullptr, 1, W, H, C, src_stride, 0, views, n_views, dptr.data(), dst_stride, interp,
+                                     flags, slot, esize))
         return rc;
     for (int k = 0; k < n_views; ++k) {
         if (!dst[k]) return fail(GS360_ERR_ARG, "dst[%d] is NULL", k);
-        size_t ds = dst_stride ? dst_stride : (size_t)views[k].width * C;
+        size_t ds = dst_stride ? dst_stride : (size_t)views[k].width * C * esize;
         HIP_TRY(hipMemcpyAsync(dst[k], dptr[k], ds * (size_t)views[k].height, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     return GS360_OK;
 }
+}  // namespace
 
-int gs360_remap_table_u8_host(gs360_ctx* c, const uint8_t* src, int H, int W, int C, size_t src_stride, const float* map_x,
-                              const float* map_y, const uint8_t* valid, int h, int w, int interp,
-                              const double* border_value, int fill_value, uint8_t* dst, size_t dst_stride, int slot) {
+int gs360_equirect_views_u8_host(gs360_ctx* c, const uint8_t* src, int W, int H, int C, size_t src_stride,
+                                 const gs360_view* views, int n_views, uint8_t* const* dst, size_t dst_stride,
+                                 int interp, uint32_t flags, int slot) {
+    return equirect_views_host_impl(c, src, W, H, C, src_stride, views, n_views, (void* const*)dst, dst_stride, interp, flags, slot, 1);
+}
+int gs360_equirect_views_u16_host(gs360_ctx* c, const uint16_t* src, int W, int H, int C, size_t src_stride,
+                                  const gs360_view* views, int n_views, uint16_t* const* dst, size_t dst_stride,
+                                  int interp, uint32_t flags, int slot) {
+    return equirect_views_host_impl(c, src, W, H, C, src_stride, views, n_views, (void* const*)dst, dst_stride, interp, flags, slot, 2);
+}
+
+namespace {
+int remap_table_host_impl(gs360_ctx* c, const void* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                          const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                          const double* border_value, int fill_value, void* dst, size_t dst_stride, int slot, int esize) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
     if (!src || !map_x || !map_y || !dst) return fail(GS360_ERR_ARG, "NULL argument");
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
     if (H < 1 || W < 1 || h < 0 || w < 0) return fail(GS360_ERR_ARG, "bad size");
     if (h == 0 || w == 0) return GS360_OK;
-    if (src_stride == 0) src_stride = (size_t)W * C;
-    if (dst_stride == 0) dst_stride = (size_t)w * C;
+    if (src_stride == 0) src_stride = (size_t)W * C * esize;
+    if (dst_stride == 0) dst_stride = (size_t)w * C * esize;
     HIP_TRY(hipSetDevice(c->device));
     Staging& S = c->stage[slot];
     size_t src_bytes = src_stride * (size_t)H, dst_bytes = dst_stride * (size_t)h;
@@ -753,12 +860,24 @@ int gs360_remap_table_u8_host(gs360_ctx* c, const uint8_t* src, int H, int W, in
     HIP_TRY(hipMemcpyAsync(dmx, map_x, map_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dmy, map_y, map_bytes, hipMemcpyHostToDevice, st));
     if (valid) HIP_TRY(hipMemcpyAsync(dva, valid, npx, hipMemcpyHostToDevice, st));
-    if (int rc = gs360_remap_table_u8(c, S.d_src, H, W, C, src_stride, dmx, dmy, valid ? dva : nullptr, h, w, interp,
-                                      border_value, fill_value, S.d_dst, dst_stride, slot))
+    if (int rc = (esize == 2 ? gs360_remap_table_u16 : gs360_remap_table_u8)(c, S.d_src, H, W, C, src_stride, dmx, dmy, valid ? dva : nullptr,
+                                                                             h, w, interp, border_value, fill_value, S.d_dst, dst_stride, slot))
         return rc;
     HIP_TRY(hipMemcpyAsync(dst, S.d_dst, dst_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GS360_OK;
+}
+}  // namespace
+
+int gs360_remap_table_u8_host(gs360_ctx* c, const uint8_t* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                              const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                              const double* border_value, int fill_value, uint8_t* dst, size_t dst_stride, int slot) {
+    return remap_table_host_impl(c, src, H, W, C, src_stride, map_x, map_y, valid, h, w, interp, border_value, fill_value, dst, dst_stride, slot, 1);
+}
+int gs360_remap_table_u16_host(gs360_ctx* c, const uint16_t* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                               const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                               const double* border_value, int fill_value, uint16_t* dst, size_t dst_stride, int slot) {
+    return remap_table_host_impl(c, src, H, W, C, src_stride, map_x, map_y, valid, h, w, interp, border_value, fill_value, dst, dst_stride, slot, 2);
 }
 
 }  // extern "C"

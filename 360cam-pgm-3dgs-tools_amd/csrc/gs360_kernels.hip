@@ -24,6 +24,7 @@
 // Compile with -ffp-contract=off: the float32 specs are defined operation by operation and must match the
 // CPU oracle bit for bit; only explicit __builtin_fmaf may fuse.
 #include "gs360_kernels.h"
+#include "gs360_eqspec.h"
 
 #ifndef GS360_EXPERIMENT
 #define GS360_EXPERIMENT 0   // 1 / 2: scratch probes used while profiling (never built into lib/)
@@ -205,39 +206,6 @@ struct BlkStore {
     int sub;             // mode 2: first tile column of this wavefront's 32-column half
 };
 
-// ------------------------------------------------------------------------------------------------
-// EQ-SPEC v1
-// ------------------------------------------------------------------------------------------------
-#define EQ_T8 0x1.a8279ap-2f
-#define EQ_C1 (-0.33333316445350647f)
-#define EQ_C2 (0.199985072016716f)
-#define EQ_C3 (-0.14244139194488525f)
-#define EQ_C4 (0.10597943514585495f)
-#define EQ_C5 (-0.06087981536984444f)
-
-// atan2(yy, xx) = r0 + K * pi/4 with |r0| <= pi/8 (sign folded into r0), K in [-4, 4]
-__device__ __forceinline__ float eq_atan2_red(float yy, float xx, int& K) {
-    float ax = __builtin_fabsf(xx), ay = __builtin_fabsf(yy);
-    bool steep = ay > ax;
-    float mx = steep ? ay : ax, mn = steep ? ax : ay;
-    bool big = mn > EQ_T8 * mx;
-    float num = big ? mn - mx : mn;
-    float den = big ? mn + mx : mx;
-    float t = num / (den > 0.0f ? den : 1.0f);   // den == 0 only when num == 0: same value as the spec's guard, no branch
-    float z = t * t;
-    float p = __builtin_fmaf(EQ_C5, z, EQ_C4);
-    p = __builtin_fmaf(p, z, EQ_C3);
-    p = __builtin_fmaf(p, z, EQ_C2);
-    p = __builtin_fmaf(p, z, EQ_C1);
-    float r0 = __builtin_fmaf(p * z, t, t);
-    int k = big ? 1 : 0;
-    if (steep) { r0 = -r0; k = 2 - k; }
-    if (xx < 0.0f) { r0 = -r0; k = 4 - k; }
-    if (yy < 0.0f) { r0 = -r0; k = -k; }
-    K = k;
-    return r0;
-}
-
 // Tap fetch for the equirect sampler, split in two so that all gathers of a wavefront can be in flight at once:
 //   eq_fetch   issues the two row reads of one pixel with NO control flow (the column is clamped so that the
 //              2*C-byte read never leaves the row); lanes whose right tap wraps around the 360-degree seam, or
@@ -333,30 +301,6 @@ __device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, 
 #pragma unroll
     for (int c = 0; c < C; ++c)
         out[c] = blend(r0[ix * C + c], r0[ix1 * C + c], r1[ix * C + c], r1[ix1 * C + c], w00, w01, w10, w11);
-}
-
-// Equidistant-fisheye output: S(q) = sin(pi r/2)/r and C(q) = cos(pi r/2) as degree-8 polynomials in q = r^2 on [0, 4]
-// (same coefficients and Horner order as the oracle).
-__device__ __constant__ const float kEqFishS[9] = {1.5707963705062866f, -0.6459640860557556f, 0.07969262450933456f,
-                                                   -0.004681753925979137f, 0.0001604411081643775f, -3.598792090997449e-06f,
-                                                   5.689994608815141e-08f, -6.633614213491512e-10f, 5.326020006968246e-12f};
-__device__ __constant__ const float kEqFishC[9] = {1.0f, -1.2337005138397217f, 0.25366950035095215f, -0.020863480865955353f,
-                                                   0.0009192594443447888f, -2.5201432436006144e-05f, 4.708266487796209e-07f,
-                                                   -6.321354106830768e-09f, 5.675555858619674e-11f};
-__device__ __forceinline__ float eq_poly8(const float* k, float q) {
-    float p = k[8];
-#pragma unroll
-    for (int n = 7; n >= 0; --n) p = __builtin_fmaf(p, q, k[n]);
-    return p;
-}
-
-// quantised longitude coordinate (1/32 px, wrapped to [0, 32W))
-__device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, const EqView& V) {
-    int sx = (int)__builtin_rintf(__builtin_fmaf(r0, L.kx32, V.x0f32)) + V.x0i32 + K * 4 * L.W;
-    const int W32 = 32 * L.W;
-    if (sx < 0) sx += W32;
-    if (sx >= W32) sx -= W32;
-    return sx;
 }
 
 // ---- cubic variant of the equirect sampler (4x4 Keys taps, OpenCV fixed-point table) -------------------------------

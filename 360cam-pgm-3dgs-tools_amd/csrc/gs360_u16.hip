@@ -1,0 +1,218 @@
+// gs360_u16.hip -- 16-bit (uint16) variants of the two samplers.
+//
+//   eq_views_u16_kernel      EQ-SPEC v1 on 16-bit equirect sources: 16-bit stills keep their depth through the reference's
+//                            ffmpeg path (PC:327-347 sets no -pix_fmt for PNG/TIFF stills) and > 8-bit videos leave as
+//                            rgb48le (PC:343-347).  Same quantised coordinates as the 8-bit kernel, evaluated per pixel
+//                            (eq_coord_px); bilinear (sum S a b + 512) >> 10, bicubic with the fixed-point Keys table in
+//                            64-bit, columns wrap, rows clamp.
+//   table_remap_u16_kernel   cv2.remap on CV_16U sources (DF:735 keeps 16-bit inputs at native depth; DF:2001-2014):
+//                            OpenCV routes ushort to its FLOAT-weight samplers -- 2-D weight = cy[k1] * cx[k2] in float32
+//                            from the 1-D phase tables, float32 accumulation in OpenCV's expression order, cvRound +
+//                            saturate to [0, 65535].  Order (compiled with -ffp-contract=off): window inside the image --
+//                            bilinear ((S00 w0 + S01 w1) + S10 w2) + S11 w3; bicubic / lanczos4 sum each window row left to
+//                            right and add the row sums row by row; window on the border (BORDER_CONSTANT) -- bilinear replaces
+//                            outside taps by the border value, bicubic / lanczos4 start from the border value cv and add
+//                            (S - cv) w for every in-image tap in row-major order.
+//
+// First-cut kernels: one output pixel per lane per row slot, straight-line samplers, 2-byte-element gathers.  They are
+// HBM-bound byte gathers like their 8-bit siblings but carry none of the tuned fetch paths yet.
+#include "gs360_eqspec.h"
+
+namespace gs360 {
+
+namespace {
+
+__device__ __forceinline__ int cv_round_u16(float v) {
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (int)0x80000000;
+    return (int)__builtin_rintf(v);
+}
+__device__ __forceinline__ int sat_s16_u16(int v) { return min(max(v, -32768), 32767); }
+__device__ __forceinline__ uint16_t sat_u16(float v) { return (uint16_t)min(max(cv_round_u16(v), 0), 65535); }
+
+template <int C, bool CUBIC>
+__global__ __launch_bounds__(64 * kWaves) void eq_views_u16_kernel(const EqLaunch L) {
+    int b = blockIdx.x;
+    int t = (b & 7) * L.chunk + (b >> 3);
+    if (t >= L.total_tiles) return;
+    int f = t / L.tiles_per_frame;
+    int r = t - f * L.tiles_per_frame;
+    int k = 0;
+    while (k + 1 < L.n_views && r >= L.view[k + 1].tile_base) ++k;
+    const EqView& V = L.view[k];
+    r -= V.tile_base;
+    const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = tile_x * kTileW + lane;
+    if (i >= V.out_w) return;
+    const uint16_t* __restrict__ src = reinterpret_cast<const uint16_t*>(L.src[f]);
+    const size_t ss = (size_t)L.src_stride >> 1;                       // elements per source row
+    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C * 2;
+    uint8_t* dst = L.dst[f * L.n_views + k];
+    const int W = L.W, H = L.H;
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) {
+        const int j = tile_y * kTileH + wave * kRowsPerWave + s;
+        if (j >= V.out_h) break;
+        int sx, sy;
+        eq_coord_px(L, V, i, j, sx, sy);
+        const int fx = sx & 31, ix = sx >> 5, fy = sy & 31, iy = sy >> 5;
+        uint16_t* out = reinterpret_cast<uint16_t*>(dst + (int64_t)j * dstride) + (size_t)i * C;
+        if constexpr (!CUBIC) {
+            const int ix1 = (ix + 1 == W) ? 0 : ix + 1;
+            const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
+            const uint16_t* r0 = src + (size_t)y0 * ss;
+            const uint16_t* r1 = src + (size_t)y1 * ss;
+            const uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const uint32_t acc = ((uint32_t)r0[ix * C + c] * a0 + (uint32_t)r0[ix1 * C + c] * a1) * b0 +
+                                     ((uint32_t)r1[ix * C + c] * a0 + (uint32_t)r1[ix1 * C + c] * a1) * b1;
+                out[c] = (uint16_t)((acc + 512u) >> 10);
+            }
+        } else {
+            const int16_t* wt = L.cubic_tab + (fy * 32 + fx) * 16;
+            int cols[4];
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int xx = ix - 1 + kx;
+                cols[kx] = xx < 0 ? xx + W : (xx >= W ? xx - W : xx);
+            }
+            int64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const uint16_t* row = src + (size_t)min(max(iy - 1 + ky, 0), H - 1) * ss;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int w = wt[ky * 4 + kx];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += (int64_t)((int)row[(size_t)cols[kx] * C + c] * w);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int64_t v = (acc[c] + (1 << 14)) >> 15;
+                out[c] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+            }
+        }
+    }
+}
+
+// cv2.remap(CV_16U) -- see the file header.  coef: 32 phases x (2 + 4 + 8) float32 1-D coefficients (linear, cubic, lanczos4).
+template <int C>
+__global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const TableLaunch T, const float* __restrict__ coef, const uint16_t c0,
+                                                                      const uint16_t c1, const uint16_t c2, const uint16_t c3) {
+    const int tiles_x = (T.w + kTileW - 1) / kTileW;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = tile_x * kTileW + lane;
+    if (x >= T.w) return;
+    const uint16_t cval[4] = {c0, c1, c2, c3};
+    const uint16_t* __restrict__ src = reinterpret_cast<const uint16_t*>(T.src);
+    const size_t ss = (size_t)T.src_stride >> 1;
+    const int W = T.W, H = T.H, interp = T.interp;
+    const int ks = interp == GS360_INTERP_LINEAR ? 2 : (interp == GS360_INTERP_CUBIC ? 4 : 8);
+    const float* tab = coef + (interp == GS360_INTERP_LINEAR ? 0 : (interp == GS360_INTERP_CUBIC ? 64 : 192));
+#pragma unroll 1
+    for (int s = 0; s < kRowsPerWave; ++s) {
+        const int y = tile_y * kTileH + wave * kRowsPerWave + s;
+        if (y >= T.h) break;
+        const size_t p = (size_t)y * T.w + x;
+        uint16_t* out = reinterpret_cast<uint16_t*>(T.dst + (int64_t)y * T.dst_stride) + (size_t)x * C;
+        if (T.valid && !T.valid[p]) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) out[c] = (uint16_t)T.fill;
+            continue;
+        }
+        const float mx = T.map_x[p], my = T.map_y[p];
+        if (interp == GS360_INTERP_NEAREST) {
+            const int ix = sat_s16_u16(cv_round_u16(mx)), iy = sat_s16_u16(cv_round_u16(my));
+            const bool in = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
+#pragma unroll
+            for (int c = 0; c < C; ++c) out[c] = in ? src[(size_t)iy * ss + (size_t)ix * C + c] : cval[c];
+            continue;
+        }
+        const int sx = cv_round_u16(mx * 32.0f), sy = cv_round_u16(my * 32.0f);
+        const int fx = sx & 31, fy = sy & 31;
+        const int ix = sat_s16_u16(sx >> 5), iy = sat_s16_u16(sy >> 5);
+        const int x0 = ix - (ks / 2 - 1), y0 = iy - (ks / 2 - 1);
+        if (x0 >= W || x0 + ks <= 0 || y0 >= H || y0 + ks <= 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) out[c] = cval[c];
+            continue;
+        }
+        const float* cy = tab + fy * ks;
+        const float* cx = tab + fx * ks;
+        const bool inside = x0 >= 0 && x0 + ks <= W && y0 >= 0 && y0 + ks <= H;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float sum;
+            if (interp == GS360_INTERP_LINEAR) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+                    v[q] = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? (float)src[(size_t)yy * ss + (size_t)xx * C + c] : (float)cval[c];
+                }
+                sum = v[0] * (cy[0] * cx[0]) + v[1] * (cy[0] * cx[1]) + v[2] * (cy[1] * cx[0]) + v[3] * (cy[1] * cx[1]);
+            } else if (inside) {
+                sum = 0.f;
+                for (int ky = 0; ky < ks; ++ky) {
+                    const uint16_t* row = src + (size_t)(y0 + ky) * ss + (size_t)x0 * C + c;
+                    float rs = (float)row[0] * (cy[ky] * cx[0]);
+                    for (int kx = 1; kx < ks; ++kx) rs += (float)row[(size_t)kx * C] * (cy[ky] * cx[kx]);
+                    sum = (ky == 0 && interp == GS360_INTERP_CUBIC) ? rs : sum + rs;
+                }
+            } else {
+                const float cv = (float)cval[c];
+                sum = cv;
+                for (int ky = 0; ky < ks; ++ky) {
+                    const int yy = y0 + ky;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int kx = 0; kx < ks; ++kx) {
+                        const int xx = x0 + kx;
+                        if (xx < 0 || xx >= W) continue;
+                        sum += ((float)src[(size_t)yy * ss + (size_t)xx * C + c] - cv) * (cy[ky] * cx[kx]);
+                    }
+                }
+            }
+            out[c] = sat_u16(sum);
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_equirect_u16(const EqLaunch& L, int C, bool cubic, hipStream_t s) {
+    dim3 grid((unsigned)(L.chunk * 8)), block(64 * kWaves);
+    if (cubic) {
+        switch (C) {
+            case 1: hipLaunchKernelGGL((eq_views_u16_kernel<1, true>), grid, block, 0, s, L); break;
+            case 3: hipLaunchKernelGGL((eq_views_u16_kernel<3, true>), grid, block, 0, s, L); break;
+            case 4: hipLaunchKernelGGL((eq_views_u16_kernel<4, true>), grid, block, 0, s, L); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (C) {
+            case 1: hipLaunchKernelGGL((eq_views_u16_kernel<1, false>), grid, block, 0, s, L); break;
+            case 3: hipLaunchKernelGGL((eq_views_u16_kernel<3, false>), grid, block, 0, s, L); break;
+            case 4: hipLaunchKernelGGL((eq_views_u16_kernel<4, false>), grid, block, 0, s, L); break;
+            default: return hipErrorInvalidValue;
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_table_u16(const TableLaunch& T, int C, const float* coef, const uint16_t cval[4], hipStream_t s) {
+    const int tiles = ((T.w + kTileW - 1) / kTileW) * ((T.h + kTileH - 1) / kTileH);
+    if (tiles == 0) return hipSuccess;
+    dim3 grid((unsigned)tiles), block(64 * kWaves);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((table_remap_u16_kernel<1>), grid, block, 0, s, T, coef, cval[0], cval[1], cval[2], cval[3]); break;
+        case 3: hipLaunchKernelGGL((table_remap_u16_kernel<3>), grid, block, 0, s, T, coef, cval[0], cval[1], cval[2], cval[3]); break;
+        case 4: hipLaunchKernelGGL((table_remap_u16_kernel<4>), grid, block, 0, s, T, coef, cval[0], cval[1], cval[2], cval[3]); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gs360

@@ -29,6 +29,7 @@ EXPORTS = (
     "gs360_fisheye_views_u8", "gs360_remap_tables_u8",
     "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
+    "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
 )
 
 
@@ -111,6 +112,10 @@ def load_library(path=None):
         L.gs360_equirect_views_u8_host.argtypes = [vp, vp, i, i, i, sz, C.POINTER(View), i, pvp, sz, i, u32, i]
         L.gs360_remap_table_u8_host.argtypes = [vp, vp, i, i, i, sz, vp, vp, vp, i, i, i, C.POINTER(C.c_double), i, vp,
                                                 sz, i]
+        L.gs360_equirect_views_u16.argtypes = L.gs360_equirect_views_u8.argtypes
+        L.gs360_remap_table_u16.argtypes = L.gs360_remap_table_u8.argtypes
+        L.gs360_equirect_views_u16_host.argtypes = L.gs360_equirect_views_u8_host.argtypes
+        L.gs360_remap_table_u16_host.argtypes = L.gs360_remap_table_u8_host.argtypes
         for name in EXPORTS:
             getattr(L, name).restype = C.c_int
         if path is None:
@@ -260,9 +265,10 @@ class Context:
 
     # -- hot path, device-resident ----------------------------------------------------------
     def equirect_views_dev(self, frames, W, H, Cn, views, dsts, slot=0, src_stride=0, dst_stride=0,
-                           interp=INTERP_LINEAR, masks=None, flags=0):
+                           interp=INTERP_LINEAR, masks=None, flags=0, dtype=np.uint8):
         """frames: list of DeviceBuffer (H x W x C); dsts: list (len frames*views) of DeviceBuffer;
-        masks: optional list of DeviceBuffer (H x W u8 keep-masks, one per frame) fused into the output."""
+        masks: optional list of DeviceBuffer (H x W u8 keep-masks, one per frame) fused into the output.
+        dtype: np.uint8 or np.uint16 samples (strides in bytes)."""
         nf, nv = len(frames), len(views)
         fp = (C.c_void_p * max(nf, 1))(*[b.ptr for b in frames])
         dp = (C.c_void_p * max(nf * nv, 1))(*[b.ptr for b in dsts])
@@ -270,12 +276,14 @@ class Context:
         if masks is not None:
             if len(masks) != nf:
                 raise ValueError("one mask per frame")
+            if np.dtype(dtype) != np.uint8:
+                raise Gs360Error(-4, "the fused keep-mask exists for 8-bit images only")
             mp = (C.c_void_p * max(nf, 1))(*[b.ptr for b in masks])
             _check(self.L.gs360_equirect_views_masked_u8(self.handle, fp, mp, nf, W, H, Cn, src_stride, 0, va, nv, dp,
                                                          dst_stride, interp, int(flags), slot), self.L)
             return
-        _check(self.L.gs360_equirect_views_u8(self.handle, fp, nf, W, H, Cn, src_stride, va, nv, dp, dst_stride,
-                                              interp, int(flags), slot), self.L)
+        fn = self.L.gs360_equirect_views_u16 if np.dtype(dtype) == np.uint16 else self.L.gs360_equirect_views_u8
+        _check(fn(self.handle, fp, nf, W, H, Cn, src_stride, va, nv, dp, dst_stride, interp, int(flags), slot), self.L)
 
     def make_equirect_call(self, frames, W, H, Cn, views, dsts, slot=0, interp=INTERP_LINEAR, src_stride=0):
         """Pre-marshal one batched launch; returns a zero-argument callable (used by bench loops)."""
@@ -293,11 +301,11 @@ class Context:
         return call
 
     def remap_table_dev(self, src, H, W, Cn, map_x, map_y, valid, h, w, dst, interp=INTERP_LINEAR,
-                        border_value=(0, 0, 0, 0), fill_value=0, slot=0):
+                        border_value=(0, 0, 0, 0), fill_value=0, slot=0, dtype=np.uint8):
         bv = (C.c_double * 4)(*[float(x) for x in border_value])
-        _check(self.L.gs360_remap_table_u8(self.handle, src.ptr, H, W, Cn, 0, map_x.ptr, map_y.ptr,
-                                           valid.ptr if valid is not None else None, h, w, interp, bv,
-                                           int(fill_value), dst.ptr, 0, slot), self.L)
+        fn = self.L.gs360_remap_table_u16 if np.dtype(dtype) == np.uint16 else self.L.gs360_remap_table_u8
+        _check(fn(self.handle, src.ptr, H, W, Cn, 0, map_x.ptr, map_y.ptr, valid.ptr if valid is not None else None, h, w, interp, bv,
+                  int(fill_value), dst.ptr, 0, slot), self.L)
 
     def remap_tables_dev(self, jobs, Cn, interp=INTERP_LINEAR, border_value=(0, 0, 0, 0), slot=0):
         """Several remaps in one launch.  jobs: iterable of (src, H, W, map_x, map_y, valid_or_None, h, w, fill_value, dst)
@@ -346,26 +354,29 @@ class Context:
 
     # -- hot path, host buffers (synchronous) -----------------------------------------------
     def equirect_views(self, src, views, slot=0, interp=INTERP_LINEAR, flags=0):
-        """src: H x W x C uint8 ndarray -> list of per-view ndarrays (height x width x C)."""
-        src = np.ascontiguousarray(src, dtype=np.uint8)
+        """src: H x W x C uint8 (or uint16) ndarray -> list of per-view ndarrays (height x width x C) of the same dtype."""
+        dt = np.uint16 if np.asarray(src).dtype == np.uint16 else np.uint8
+        src = np.ascontiguousarray(src, dtype=dt)
         if src.ndim == 2:
             src = src[:, :, None]
         H, W, Cn = src.shape
-        outs = [np.empty((v.height, v.width, Cn), np.uint8) for v in views]
+        outs = [np.empty((v.height, v.width, Cn), dt) for v in views]
         if not views:
             return outs
         va = (View * len(views))(*views)
         dp = (C.c_void_p * len(views))(*[o.ctypes.data for o in outs])
         with self.slot_locks[slot]:
-            _check(self.L.gs360_equirect_views_u8_host(self.handle, src.ctypes.data, W, H, Cn, src.strides[0], va,
-                                                       len(views), dp, 0, interp, int(flags), slot), self.L)
+            fn = self.L.gs360_equirect_views_u16_host if dt == np.uint16 else self.L.gs360_equirect_views_u8_host
+            _check(fn(self.handle, src.ctypes.data, W, H, Cn, src.strides[0], va, len(views), dp, 0, interp, int(flags), slot), self.L)
         return outs
 
     def remap(self, src, map_x, map_y, interpolation=INTERP_LINEAR, border_value=0.0, valid=None, fill_value=0,
               slot=0):
         """cv2.remap(src, map_x, map_y, interpolation, borderMode=BORDER_CONSTANT, borderValue=...) drop-in
-        (DF:2001-2008); `valid`/`fill_value` fuse the reference's `out[~valid] = mask_value` (DF:2009-2014)."""
-        src = np.ascontiguousarray(src, dtype=np.uint8)
+        (DF:2001-2008); `valid`/`fill_value` fuse the reference's `out[~valid] = mask_value` (DF:2009-2014).
+        uint16 sources take cv2's CV_16U (float-weight) samplers and return uint16."""
+        dt = np.uint16 if np.asarray(src).dtype == np.uint16 else np.uint8
+        src = np.ascontiguousarray(src, dtype=dt)
         s3 = src if src.ndim == 3 else src[:, :, None]
         H, W, Cn = s3.shape
         mx = np.ascontiguousarray(map_x, dtype=np.float32)
@@ -381,11 +392,10 @@ class Context:
             va = np.ascontiguousarray(valid, dtype=np.uint8)
             if va.shape != (h, w):
                 raise ValueError("valid mask shape mismatch")
-        dst = np.empty((h, w, Cn), np.uint8)
+        dst = np.empty((h, w, Cn), dt)
         with self.slot_locks[slot]:
-            _check(self.L.gs360_remap_table_u8_host(self.handle, s3.ctypes.data, H, W, Cn, s3.strides[0],
-                                                    mx.ctypes.data, my.ctypes.data,
-                                                    va.ctypes.data if va is not None else None, h, w,
-                                                    int(interpolation), bv, int(fill_value), dst.ctypes.data, 0, slot),
+            fn = self.L.gs360_remap_table_u16_host if dt == np.uint16 else self.L.gs360_remap_table_u8_host
+            _check(fn(self.handle, s3.ctypes.data, H, W, Cn, s3.strides[0], mx.ctypes.data, my.ctypes.data,
+                      va.ctypes.data if va is not None else None, h, w, int(interpolation), bv, int(fill_value), dst.ctypes.data, 0, slot),
                    self.L)
         return dst if src.ndim == 3 else dst[:, :, 0]

@@ -206,6 +206,26 @@ int gs360_color_plan_destroy(gs360_ctx *ctx, gs360_color_plan *plan);
 int gs360_color_apply_u8(gs360_ctx *ctx, const gs360_color_plan *plan, const void *src, int H, int W, int C,
                          size_t src_stride, int red_index, void *dst, size_t dst_stride, int slot);
 
+/* ---- 16-bit images ---------------------------------------------------------------
+ * Same calls on uint16 samples (interleaved H x W x C, strides in BYTES and even).  The reference keeps 16-bit inputs at
+ * native depth: cv2.imread(IMREAD_UNCHANGED) in the dual-fisheye tool (DF:735) and 16-bit PNG/TIFF stills / > 8-bit
+ * videos (rgb48le) in 360PerspCut (gs360_360PerspCut.py:327-347).
+ *   gs360_equirect_views_u16  EQ-SPEC v1 coordinates; bilinear (sum S a b + 512) >> 10, bicubic with the fixed-point
+ *                             Keys table accumulated in 64 bits, clamped to [0, 65535].  No fused keep-mask.
+ *   gs360_remap_table_u16     cv2.remap on CV_16U: OpenCV's float-weight samplers (weights cy[k1]*cx[k2] in float32,
+ *                             float32 accumulation in OpenCV's expression order, cvRound + saturate), all four
+ *                             interpolations; border_value saturates to [0, 65535]; fill_value is written as uint16.
+ */
+int gs360_equirect_views_u16(gs360_ctx *ctx, const void *const *src_frames, int n_frames,
+                             int W, int H, int C, size_t src_stride,
+                             const gs360_view *views, int n_views,
+                             void *const *dst, size_t dst_stride,
+                             int interp, uint32_t flags, int slot);
+int gs360_remap_table_u16(gs360_ctx *ctx, const void *src, int H, int W, int C, size_t src_stride,
+                          const float *map_x, const float *map_y, const uint8_t *valid, int h, int w,
+                          int interp, const double *border_value, int fill_value,
+                          void *dst, size_t dst_stride, int slot);
+
 /* ---- host-buffer conveniences (synchronous: H2D -> kernel -> D2H on `slot`) ----------------- */
 int gs360_equirect_views_u8_host(gs360_ctx *ctx, const uint8_t *src, int W, int H, int C, size_t src_stride,
                                  const gs360_view *views, int n_views,
@@ -214,6 +234,14 @@ int gs360_remap_table_u8_host(gs360_ctx *ctx, const uint8_t *src, int H, int W, 
                               const float *map_x, const float *map_y, const uint8_t *valid, int h, int w,
                               int interp, const double *border_value, int fill_value,
                               uint8_t *dst, size_t dst_stride, int slot);
+
+int gs360_equirect_views_u16_host(gs360_ctx *ctx, const uint16_t *src, int W, int H, int C, size_t src_stride,
+                                  const gs360_view *views, int n_views,
+                                  uint16_t *const *dst, size_t dst_stride, int interp, uint32_t flags, int slot);
+int gs360_remap_table_u16_host(gs360_ctx *ctx, const uint16_t *src, int H, int W, int C, size_t src_stride,
+                               const float *map_x, const float *map_y, const uint8_t *valid, int h, int w,
+                               int interp, const double *border_value, int fill_value,
+                               uint16_t *dst, size_t dst_stride, int slot);
 
 #ifdef __cplusplus
 }

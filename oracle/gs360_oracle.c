@@ -16,6 +16,8 @@
  *                         restated here.  PARITY UNPINNED at that boundary: the reference has
  *                         no tests or golden images for it; pinned instead by hand-derivable
  *                         integer known-answer tests (tests/test_oracle_remap.py).
+ *   orc_remap_u16         the same call on 16-bit sources (DF:735 keeps them at native depth): OpenCV's float-weight
+ *                         samplers for ushort, restated next to the function; parity unpinned as well.
  *   orc_valid_fill        DF:1207-1212, DF:2009-2014 (rendered[~valid] = mask_value).
  *   orc_fisheye_map       DF:1759-1823 build_direct_perspective_map_for_lens, with
  *                         DF:975-1005 (_apply_brown_distortion) and DF:1310-1339
@@ -283,6 +285,127 @@ ORC_API int orc_remap_u8(const uint8_t *src, int H, int W, int C, long src_strid
                 d[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
             }
         }
+    }
+    return 0;
+}
+
+/*
+ * cv2.remap on CV_16U sources (DF:735: cv2.imread(IMREAD_UNCHANGED) keeps 16-bit PNG/TIFF inputs at native depth).
+ * OpenCV's dispatch tables send ushort to the FLOAT-weight samplers -- remapBilinear<Cast<float,ushort>, RemapNoVec, float>,
+ * remapBicubic<Cast<float,ushort>, float, 1>, remapLanczos4<Cast<float,ushort>, float, 1> -- with the same 1/32-px
+ * quantised coordinates as the 8-bit path: 2-D weights = cy[k1] * cx[k2] in float32 from the 1-D phase tables (no
+ * fixed-point scaling, no sum fix-up), float32 accumulation in the source's expression order, then
+ * saturate_cast<ushort>(float) = cvRound (half to even) clamped to [0, 65535].  Accumulation order as restated:
+ *   inside the image   bilinear: ((S00*w0 + S01*w1) + S10*w2) + S11*w3;   bicubic / lanczos4: the ks products of a window
+ *                      row are summed left to right, and the row sums are added to the running sum row by row
+ *                      (`sum = row0; sum += row1; ...` / `sum = 0; sum += row_r` for Lanczos4);
+ *   window on the border (BORDER_CONSTANT)   bilinear: taps outside are replaced by the border value, same expression;
+ *                      bicubic / lanczos4: sum = cv, then sum += (S - cv) * w for every in-image tap in row-major order
+ *                      (rows above/below the image are skipped).
+ * RESTATED FROM MEMORY OF THE OPENCV 4.x SOURCE (imgwarp.cpp), parity unpinned like the 8-bit samplers; the
+ * opportunistic cv2 cross-check (tests/test_crosscheck_external.py) covers u16 as well.
+ * Strides are in BYTES.
+ */
+static inline uint16_t sat_u16_f(float v) {
+    int iv = cv_round_f(v);
+    return (uint16_t)(iv < 0 ? 0 : (iv > 65535 ? 65535 : iv));
+}
+static inline uint16_t sat_u16_d(double v) {
+    long r = lrint(v);
+    return (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+}
+
+ORC_API int orc_remap_u16(const uint16_t *src, int H, int W, int C, long src_stride,
+                          const float *map_x, const float *map_y, int h, int w,
+                          int interp, const double *border_val,
+                          uint16_t *dst, long dst_stride, int n_threads) {
+    if (!src || !map_x || !map_y || !dst || C < 1 || C > 4 || H < 1 || W < 1) return -1;
+    if (H >= 32767 || W >= 32767) return -2;
+    if (interp != 0 && interp != 1 && interp != 2 && interp != 4) return -3;
+    float lin1[32][2], cub1[32][4], lan1[32][8];
+    for (int i = 0; i < 32; ++i) {
+        float x = (float)i * (1.0f / 32.0f);
+        lin1[i][0] = 1.f - x; lin1[i][1] = x;
+        cubic_coeffs(x, cub1[i]);
+        lanczos4_coeffs(x, lan1[i]);
+    }
+    uint16_t cval[4];
+    for (int c = 0; c < 4; ++c) cval[c] = sat_u16_d(border_val ? border_val[c] : 0.0);
+    const size_t ss = (size_t)src_stride / 2;
+    int nt = pick_threads(n_threads);
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int y = 0; y < h; ++y) {
+        const float *mx = map_x + (size_t)y * w, *my = map_y + (size_t)y * w;
+        uint16_t *d = (uint16_t *)((uint8_t *)dst + (size_t)y * dst_stride);
+        for (int x = 0; x < w; ++x, d += C) {
+            if (interp == 0) {
+                int ix = sat_s16(cv_round_f(mx[x])), iy = sat_s16(cv_round_f(my[x]));
+                if ((unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
+                    const uint16_t *s = src + (size_t)iy * ss + (size_t)ix * C;
+                    for (int c = 0; c < C; ++c) d[c] = s[c];
+                } else {
+                    for (int c = 0; c < C; ++c) d[c] = cval[c];
+                }
+                continue;
+            }
+            int sx = cv_round_f(mx[x] * 32.0f), sy = cv_round_f(my[x] * 32.0f);
+            int fx = sx & 31, fy = sy & 31;
+            int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+            const int ks = interp == 1 ? 2 : (interp == 2 ? 4 : 8);
+            const float *cy = interp == 1 ? lin1[fy] : (interp == 2 ? cub1[fy] : lan1[fy]);
+            const float *cx = interp == 1 ? lin1[fx] : (interp == 2 ? cub1[fx] : lan1[fx]);
+            int x0 = ix - (ks / 2 - 1), y0 = iy - (ks / 2 - 1);
+            if (x0 >= W || x0 + ks <= 0 || y0 >= H || y0 + ks <= 0) {
+                for (int c = 0; c < C; ++c) d[c] = cval[c];
+                continue;
+            }
+            const int inside = x0 >= 0 && x0 + ks <= W && y0 >= 0 && y0 + ks <= H;
+            for (int c = 0; c < C; ++c) {
+                float sum;
+                if (interp == 1) {
+                    float v[4];
+                    for (int ky = 0; ky < 2; ++ky)
+                        for (int kx = 0; kx < 2; ++kx) {
+                            int xx = x0 + kx, yy = y0 + ky;
+                            v[ky * 2 + kx] = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? (float)src[(size_t)yy * ss + (size_t)xx * C + c]
+                                                                                      : (float)cval[c];
+                        }
+                    sum = v[0] * (cy[0] * cx[0]) + v[1] * (cy[0] * cx[1]) + v[2] * (cy[1] * cx[0]) + v[3] * (cy[1] * cx[1]);
+                } else if (inside) {
+                    sum = 0.f;
+                    for (int ky = 0; ky < ks; ++ky) {
+                        const uint16_t *row = src + (size_t)(y0 + ky) * ss + (size_t)x0 * C + c;
+                        float r = (float)row[0] * (cy[ky] * cx[0]);
+                        for (int kx = 1; kx < ks; ++kx) r += (float)row[(size_t)kx * C] * (cy[ky] * cx[kx]);
+                        sum = (ky == 0 && interp == 2) ? r : sum + r;
+                    }
+                } else {
+                    const float cv = (float)cval[c];
+                    sum = cv;      /* cv * ONE with ONE = 1 for the float samplers */
+                    for (int ky = 0; ky < ks; ++ky) {
+                        int yy = y0 + ky;
+                        if (yy < 0 || yy >= H) continue;
+                        for (int kx = 0; kx < ks; ++kx) {
+                            int xx = x0 + kx;
+                            if (xx < 0 || xx >= W) continue;
+                            sum += ((float)src[(size_t)yy * ss + (size_t)xx * C + c] - cv) * (cy[ky] * cx[kx]);
+                        }
+                    }
+                }
+                d[c] = sat_u16_f(sum);
+            }
+        }
+    }
+    return 0;
+}
+
+ORC_API int orc_valid_fill_u16(uint16_t *dst, long dst_stride, int h, int w, int C, const uint8_t *valid, int fill) {
+    for (int y = 0; y < h; ++y) {
+        uint16_t *row = (uint16_t *)((uint8_t *)dst + (size_t)y * dst_stride);
+        for (int x = 0; x < w; ++x)
+            if (!valid[(size_t)y * w + x])
+                for (int c = 0; c < C; ++c) row[(size_t)x * C + c] = (uint16_t)fill;
     }
     return 0;
 }
@@ -695,6 +818,67 @@ static int eq_views_impl(const uint8_t *src, const uint8_t *mask, int W, int H, 
         }
     }
     free(cs); free(row0);
+    return 0;
+}
+
+/*
+ * EQ-SPEC v1 on 16-bit sources (16-bit stills keep their depth through the reference's ffmpeg path, PC:327-347 writes no
+ * -pix_fmt for PNG/TIFF stills; > 8-bit videos leave as rgb48le, PC:343-347).  Same quantised coordinates; the samplers
+ * are the 8-bit ones with 16-bit texels: bilinear (sum S a b + 512) >> 10, bicubic (sum S w + 2^14) >> 15 with the
+ * fixed-point Keys table in 64-bit, clamped to [0, 65535].  Build-defined like the rest of EQ-SPEC.  Strides in BYTES.
+ */
+ORC_API int orc_equirect_views_u16(const uint16_t *src, int W, int H, int C, long src_stride,
+                                   const orc_view *views, int n_views,
+                                   uint16_t *const *dst, long dst_stride, int interp, int fish, int n_threads) {
+    if (interp != 1 && interp != 2) return -3;
+    if (interp == 2) cubic_init();
+    if (!src || !views || !dst || C < 1 || C > 4 || W < 2 || H < 2 || n_views < 0) return -1;
+    if (src_stride == 0) src_stride = (long)W * C * 2;
+    const size_t ss = (size_t)src_stride / 2;
+    int nt = pick_threads(n_threads);
+    (void)nt;
+    for (int k = 0; k < n_views; ++k) {
+        eq_consts c;
+        eq_make_consts_proj(&views[k], W, H, fish, &c);
+        long ds = dst_stride ? dst_stride : (long)c.out_w * C * 2;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 8)
+        for (int j = 0; j < c.out_h; ++j) {
+            uint16_t *out = (uint16_t *)((uint8_t *)dst[k] + (size_t)j * ds);
+            for (int i = 0; i < c.out_w; ++i) {
+                int sx, sy;
+                eq_coord(&c, i, j, &sx, &sy);
+                int fx = sx & 31, ix = sx >> 5, fy = sy & 31, iy = sy >> 5;
+                if (interp == 1) {
+                    int ix1 = ix + 1 == W ? 0 : ix + 1;
+                    int y0 = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+                    int y1 = iy + 1 < 0 ? 0 : (iy + 1 > H - 1 ? H - 1 : iy + 1);
+                    const uint16_t *r0 = src + (size_t)y0 * ss, *r1 = src + (size_t)y1 * ss;
+                    uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
+                    for (int ch = 0; ch < C; ++ch) {
+                        uint32_t acc = (r0[ix * C + ch] * a0 + r0[ix1 * C + ch] * a1) * b0 +
+                                       (r1[ix * C + ch] * a0 + r1[ix1 * C + ch] * a1) * b1;
+                        out[(size_t)i * C + ch] = (uint16_t)((acc + 512) >> 10);
+                    }
+                } else {
+                    const int16_t *wt = g_cubic_tab + (fy * 32 + fx) * 16;
+                    for (int ch = 0; ch < C; ++ch) {
+                        int64_t acc = 0;
+                        for (int ky = 0; ky < 4; ++ky) {
+                            int yy = iy - 1 + ky;
+                            yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+                            for (int kx = 0; kx < 4; ++kx) {
+                                int xx = ix - 1 + kx;
+                                xx = xx < 0 ? xx + W : (xx >= W ? xx - W : xx);
+                                acc += (int64_t)src[(size_t)yy * ss + (size_t)xx * C + ch] * wt[ky * 4 + kx];
+                            }
+                        }
+                        int64_t r = (acc + (1 << 14)) >> 15;
+                        out[(size_t)i * C + ch] = (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+                    }
+                }
+            }
+        }
+    }
     return 0;
 }
 

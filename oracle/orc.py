@@ -58,6 +58,11 @@ def lib():
         L.orc_lanczos4_table.argtypes = [C.c_void_p]
         L.orc_equirect_views_masked_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
                                                    C.POINTER(OrcView), C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int]
+        L.orc_remap_u16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_long, C.c_int]
+        L.orc_valid_fill_u16.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_equirect_views_u16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(OrcView),
+                                             C.c_int, C.POINTER(C.c_void_p), C.c_long, C.c_int, C.c_int, C.c_int]
         L.orc_equirect_distinct_texels.argtypes = [C.POINTER(OrcView), C.c_int, C.c_int, C.c_void_p]
         L.orc_equirect_distinct_texels.restype = C.c_long
         L.orc_table_distinct_texels.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int]
@@ -103,8 +108,41 @@ def remap_u8(src, map_x, map_y, interp=1, border_value=(0, 0, 0, 0), threads=1):
 def valid_fill(img, valid, fill):
     a = img if img.ndim == 3 else img[:, :, None]
     v = np.ascontiguousarray(valid, dtype=np.uint8)
-    lib().orc_valid_fill(_ptr(a), a.strides[0], a.shape[0], a.shape[1], a.shape[2], _ptr(v), int(fill))
+    fn = lib().orc_valid_fill_u16 if img.dtype == np.uint16 else lib().orc_valid_fill
+    fn(_ptr(a), a.strides[0], a.shape[0], a.shape[1], a.shape[2], _ptr(v), int(fill))
     return img
+
+
+def remap_u16(src, map_x, map_y, interp=1, border_value=(0, 0, 0, 0), threads=1):
+    """cv2.remap on a CV_16U source (float-weight samplers), BORDER_CONSTANT."""
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    s3 = src if src.ndim == 3 else src[:, :, None]
+    H, W, Cn = s3.shape
+    mx = np.ascontiguousarray(map_x, dtype=np.float32)
+    my = np.ascontiguousarray(map_y, dtype=np.float32)
+    h, w = mx.shape
+    if np.isscalar(border_value):
+        border_value = (float(border_value), 0.0, 0.0, 0.0)
+    bv = (C.c_double * 4)(*[float(b) for b in (list(border_value) + [0, 0, 0, 0])[:4]])
+    dst = np.empty((h, w, Cn), dtype=np.uint16)
+    rc = lib().orc_remap_u16(_ptr(s3), H, W, Cn, s3.strides[0], _ptr(mx), _ptr(my), h, w, int(interp), bv,
+                             _ptr(dst), dst.strides[0], int(threads))
+    if rc != 0:
+        raise RuntimeError(f"orc_remap_u16 rc={rc}")
+    return dst if src.ndim == 3 else dst[:, :, 0]
+
+
+def equirect_views_u16(src, views, threads=1, interp=1, fisheye=False):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    H, W, Cn = src.shape
+    arr = (OrcView * len(views))(*views)
+    outs = [np.empty((v.height, v.width, Cn), np.uint16) for v in views]
+    ptrs = (C.c_void_p * len(views))(*[o.ctypes.data for o in outs])
+    rc = lib().orc_equirect_views_u16(_ptr(src), W, H, Cn, src.strides[0], arr, len(views), ptrs, 0, int(interp), int(bool(fisheye)),
+                                      int(threads))
+    if rc != 0:
+        raise RuntimeError(f"orc_equirect_views_u16 rc={rc}")
+    return outs
 
 
 def fisheye_map(calib, yaw, pitch, hfov, vfov, w, h, lens_fov, numpy2=True, threads=1):
