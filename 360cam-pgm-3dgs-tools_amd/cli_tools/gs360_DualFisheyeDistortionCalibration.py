@@ -188,7 +188,7 @@ def _write_image(path: pathlib.Path, image, jpeg_quality: Optional[int]):
     path.parent.mkdir(parents=True, exist_ok=True)
     if path.suffix.lower() in (".jpg", ".jpeg") and imageio.Image is not None:
         import numpy as np
-        a = np.ascontiguousarray(image)
+        a = imageio.to_uint8(np.ascontiguousarray(image))       # JPEG is an 8-bit container
         mode = {1: "L", 3: "RGB", 4: "RGBA"}[1 if a.ndim == 2 else a.shape[2]]
         im = imageio.Image.fromarray(a[:, :, 0] if (a.ndim == 3 and a.shape[2] == 1) else a, mode)
         if mode == "RGBA":

@@ -780,6 +780,41 @@ int gs360_color_apply_u8(gs360_ctx* c, const gs360_color_plan* p, const void* sr
     return GS360_OK;
 }
 
+// ---- image-codec helper (host only) ---------------------------------------------------------------
+// PNG scanline reconstruction (filter types 0-4) in place: `data` holds h rows of (1 + stride) bytes as inflated from the
+// IDAT stream; on return row y's pixels sit at data + y * (stride + 1) + 1.  Both directions of a PNG filter are
+// sequential (left neighbour and previous row), so the Python-side codec (gs360/imageio.py, used for 16-bit PNG, which
+// Pillow cannot deliver at full depth for RGB) calls this instead of looping over bytes.  No GPU involved.
+int gs360_png_unfilter(uint8_t* data, int h, int stride, int bpp) {
+    if (!data || h < 0 || stride < 1 || bpp < 1 || bpp > 8) return fail(GS360_ERR_ARG, "bad PNG geometry");
+    const size_t pitch = (size_t)stride + 1;
+    for (int y = 0; y < h; ++y) {
+        uint8_t* cur = data + (size_t)y * pitch + 1;
+        const uint8_t* up = y ? cur - pitch : nullptr;
+        const int ft = cur[-1];
+        switch (ft) {
+            case 0: break;
+            case 1: for (int i = bpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+            case 2: if (up) for (int i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]); break;
+            case 3:
+                for (int i = 0; i < stride; ++i) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                    cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
+                }
+                break;
+            case 4:
+                for (int i = 0; i < stride; ++i) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+                    const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
+                    cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+                }
+                break;
+            default: return fail(GS360_ERR_ARG, "PNG row %d has unknown filter type %d", y, ft);
+        }
+    }
+    return GS360_OK;
+}
+
 // ---- host-buffer conveniences ------------------------------------------------------------------
 namespace {
 int equirect_views_host_impl(gs360_ctx* c, const void* src, int W, int H, int C, size_t src_stride,

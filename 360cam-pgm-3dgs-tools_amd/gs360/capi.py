@@ -30,6 +30,7 @@ EXPORTS = (
     "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
     "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
+    "gs360_png_unfilter",
 )
 
 
@@ -116,6 +117,7 @@ def load_library(path=None):
         L.gs360_remap_table_u16.argtypes = L.gs360_remap_table_u8.argtypes
         L.gs360_equirect_views_u16_host.argtypes = L.gs360_equirect_views_u8_host.argtypes
         L.gs360_remap_table_u16_host.argtypes = L.gs360_remap_table_u8_host.argtypes
+        L.gs360_png_unfilter.argtypes = [vp, i, i, i]
         for name in EXPORTS:
             getattr(L, name).restype = C.c_int
         if path is None:

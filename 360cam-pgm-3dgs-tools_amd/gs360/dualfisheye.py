@@ -47,22 +47,24 @@ class PairRenderer:
                                        ctx.to_device(np.ascontiguousarray(u.valid_mask, np.uint8)))
 
     # ---------------------------------------------------------------------------------------------
-    def _remap(self, d_src, shape, maps, out_hw, interp, border, valid_fill):
+    def _remap(self, d_src, shape, maps, out_hw, interp, border, valid_fill, dtype=np.uint8):
         H, W, C = shape
         h, w = out_hw
-        need = h * w * C
+        need = h * w * C * np.dtype(dtype).itemsize
         if self._scratch is None or self._scratch.nbytes < need:
             if self._scratch is not None:
                 self.ctx.free(self._scratch)
             self._scratch = self.ctx.alloc(need)
         self.ctx.remap_table_dev(d_src, H, W, C, maps[0], maps[1], maps[2] if valid_fill is not None else None, h, w,
                                  self._scratch, interp=interp, border_value=border,
-                                 fill_value=valid_fill if valid_fill is not None else 0, slot=0)
-        return self.ctx.download(self._scratch, (h, w, C), slot=0)
+                                 fill_value=valid_fill if valid_fill is not None else 0, slot=0, dtype=dtype)
+        return self.ctx.download(self._scratch, (h, w, C), dtype=dtype, slot=0)
 
     def _remap_views(self, dev, imgs, dmask, interp, border, valid_fill):
         """All views of the pair in ONE batched launch (no per-view launch tails), then the downloads.  `dmask` set:
         the per-lens mask images are the sources (DF:2031-2043), else the lens images."""
+        if dmask is None and any(v.dtype == np.uint16 for v in imgs.values()):
+            return self._remap_views_u16(dev, imgs, interp, border, valid_fill)
         jobs, shapes, bufs = [], [], []
         for spec in self.specs:
             vid = str(spec["view_id"])
@@ -89,6 +91,18 @@ class PairRenderer:
         finally:
             for b in bufs:
                 self.ctx.free(b)
+
+    def _remap_views_u16(self, dev, imgs, interp, border, valid_fill):
+        """16-bit lens images: one CV_16U remap launch per view (the first-cut 16-bit kernel has no batched form)."""
+        if any(v.dtype != np.uint16 for v in imgs.values()):
+            raise RuntimeError("the two lens images differ in bit depth")
+        out = {}
+        for spec in self.specs:
+            vid = str(spec["view_id"])
+            key = self.tables[vid]["lens_key"]
+            out[vid] = self._remap(dev[key], imgs[key].shape, self.dev_tables[vid], (int(spec["height"]), int(spec["width"])),
+                                   interp, border, valid_fill, dtype=np.uint16)
+        return out
 
     def render_pair(self, image_x: np.ndarray, image_y: np.ndarray, sensor_id_x: str, sensor_id_y: str, *,
                     interpolation: int, mask_outside_model: bool, mask_value: int,
@@ -131,8 +145,10 @@ class PairRenderer:
                             raise RuntimeError("Resolution mismatch for {} lens: got {}x{}, expected {}x{}".format(
                                 key, imgs[key].shape[1], imgs[key].shape[0], c.width, c.height))
                         out["fisheye"][key] = self._remap(dev[key], imgs[key].shape, self.dev_undistort[sid],
-                                                          (c.height, c.width), interp, border, fill)
+                                                          (c.height, c.width), interp, border, fill, dtype=imgs[key].dtype)
                 if want_perspective:
+                    if self.fused and imgs["X"].dtype == np.uint16:
+                        raise RuntimeError("16-bit lens images need table mode (the fused-map kernel is 8-bit)")
                     if self.fused:
                         self._render_fused(out, imgs, dev, sensor_id_x, sensor_id_y, interp, mask_outside_model, mask_value)
                     else:
@@ -179,5 +195,6 @@ class PairRenderer:
 
 
 def _hwc(a: np.ndarray) -> np.ndarray:
-    a = np.ascontiguousarray(a, dtype=np.uint8)
+    """uint8 stays uint8; uint16 sources (cv2.imread(IMREAD_UNCHANGED), DF:735) stay uint16"""
+    a = np.ascontiguousarray(a, dtype=np.uint16 if np.asarray(a).dtype == np.uint16 else np.uint8)
     return a if a.ndim == 3 else a[:, :, None]

@@ -146,7 +146,7 @@ class Engine:
             buf = st.ctx.alloc(img.nbytes)
             with st.upload_lock:
                 st.ctx.upload(buf, img, slot=st.upload_slot, sync=True)
-            entry = [buf, H, W, C, 1]             # last field: users currently holding the frame
+            entry = [buf, H, W, C, 1, img.dtype]  # [4]: users currently holding the frame; [5]: uint8 / uint16
             with st.lock:
                 st.frames[key] = entry
                 st.frame_bytes += img.nbytes
@@ -157,7 +157,7 @@ class Engine:
                     if k == key or old[4] > 0:
                         continue
                     del st.frames[k]
-                    st.frame_bytes -= old[1] * old[2] * old[3]
+                    st.frame_bytes -= old[1] * old[2] * old[3] * np.dtype(old[5]).itemsize
                     st.ctx.free(old[0])
                 st.key_locks.pop(key, None)
             return entry
@@ -200,18 +200,19 @@ class Engine:
             return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), hfov, vfov, w, h), capi.EQ_FISHEYE_OUT
         return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"), job.width, job.height), 0
 
-    def _launch_batch(self, st: _DeviceState, buf, H, W, C, views, interp, flags):
+    def _launch_batch(self, st: _DeviceState, buf, H, W, C, views, interp, flags, dtype=np.uint8):
         """One batched launch for `views` of one resident frame; returns [(array aliasing pinned memory, PinnedBuffer)]."""
         with st.lock:
             slot = next(st.slot_cycle)
         ctx, L = st.ctx, st.ctx.L
-        sizes = [v.height * v.width * C for v in views]
+        esz = np.dtype(dtype).itemsize
+        sizes = [v.height * v.width * C * esz for v in views]
         d_out = [st.take(st.dev_pool, n, ctx.alloc) for n in sizes]
         h_out = [st.take(st.pin_pool, n, ctx.pinned) for n in sizes]
         t0 = time.perf_counter()
         try:
             with ctx.slot_locks[slot]:
-                ctx.equirect_views_dev([buf], W, H, C, views, d_out, slot=slot, interp=interp, flags=flags)
+                ctx.equirect_views_dev([buf], W, H, C, views, d_out, slot=slot, interp=interp, flags=flags, dtype=dtype)
                 for d, hb, n in zip(d_out, h_out, sizes):
                     capi._check(L.gs360_download(ctx.handle, hb.ptr, d.ptr, n, slot), L)
                 ctx.sync(slot)
@@ -222,12 +223,12 @@ class Engine:
             st.stats["launches"] += 1
             st.stats["views"] += len(views)
             st.stats["gpu_s"] += time.perf_counter() - t0
-        return [(np.frombuffer(hb.view, dtype=np.uint8, count=n).reshape(v.height, v.width, C), hb)
+        return [(np.frombuffer(hb.view, dtype=dtype, count=n // esz).reshape(v.height, v.width, C), hb)
                 for hb, n, v in zip(h_out, sizes, views)]
 
     def _render(self, st: _DeviceState, fkey, get_frame, view, interp, flags=0, expected=1, stop_event=None):
         """Render `view` of the frame identified by `fkey`, coalesced with the other views of that frame that arrive
-        within the linger window.  get_frame() -> (DeviceBuffer, H, W, C) is called by the batch leader only.
+        within the linger window.  get_frame() -> (DeviceBuffer, H, W, C, dtype) is called by the batch leader only.
         Returns (array, release): the array aliases pinned host memory until release() is called."""
         key = (fkey, interp, flags)
         with st.batch_cond:
@@ -240,7 +241,7 @@ class Engine:
             st.batch_cond.notify_all()
         if leader:
             try:
-                buf, H, W, C = get_frame()            # decode + upload happen here; followers keep arriving meanwhile
+                buf, H, W, C, dtype = get_frame()     # decode + upload happen here; followers keep arriving meanwhile
                 deadline = time.monotonic() + (_LINGER_S if expected > 1 else 0.0)
                 with st.batch_cond:
                     while len(b.views) < min(expected, capi.MAX_VIEWS):
@@ -251,7 +252,7 @@ class Engine:
                     b.state = "running"
                     del st.open_batches[key]
                     views = list(b.views)
-                b.results = self._launch_batch(st, buf, H, W, C, views, interp, flags)
+                b.results = self._launch_batch(st, buf, H, W, C, views, interp, flags, dtype)
             except BaseException as exc:  # noqa: BLE001  (handed to every member of the batch)
                 with st.batch_cond:
                     if st.open_batches.get(key) is b:
@@ -296,7 +297,7 @@ class Engine:
         def get_frame():
             entry = self.resident_frame(st, job.src)
             held.append(entry)
-            return entry[:4]
+            return entry[0], entry[1], entry[2], entry[3], entry[5]
         try:
             arr, release = self._render(st, self._frame_key(job.src), get_frame, view, interp, flags,
                                         expected=self._expected_for(job.src), stop_event=stop_event)
@@ -338,9 +339,9 @@ class Engine:
                 fr = sess.frame(written)
                 if fr is None:
                     break
-                st, buf, H, W = fr
+                st, buf, H, W, fdtype = fr
                 # the view jobs of a video walk its frames together: frame k of every active view goes out as one launch
-                out, release = self._render(st, ("video", plan.key, written), lambda: (buf, H, W, 3), view, interp, flags,
+                out, release = self._render(st, ("video", plan.key, written), lambda: (buf, H, W, 3, fdtype), view, interp, flags,
                                             expected=min(sess.active_jobs, expected_jobs or sess.active_jobs), stop_event=stop_event)
                 try:
                     imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)

@@ -63,8 +63,9 @@ def build_decode_plan(job: JobSpec) -> Optional[DecodePlan]:
     if "%" not in job.dst.name:
         return None
     pix = job.options.get("-pix_fmt", "")
-    if pix and pix not in ("rgb24", "yuvj444p"):
-        return None                        # rgb48le (bit depth > 8, PC:343-347): the engine is 8-bit
+    if pix and pix not in ("rgb24", "yuvj444p", "rgb48le"):
+        return None
+    deep = pix == "rgb48le"                # bit depth > 8 (PC:343-347): frames travel as 16-bit PPM, views are uint16
     known = _ENCODER_OPTIONS | _DECODER_OPTIONS
     for tok in job.input_options[0::2] + job.output_options[0::2]:
         if tok not in known:
@@ -98,7 +99,7 @@ def build_decode_plan(job: JobSpec) -> Optional[DecodePlan]:
                 out += [k, v]
         return out
     argv += keep(job.input_options) + ["-i", str(job.src)] + keep(job.output_options)
-    argv += ["-vf", ",".join(pre + ["format=rgb24"]), "-an", "-f", "image2pipe", "-c:v", "ppm", "pipe:1"]
+    argv += ["-vf", ",".join(pre + ["format=rgb48be" if deep else "format=rgb24"]), "-an", "-f", "image2pipe", "-c:v", "ppm", "pipe:1"]
     key = (str(job.src), tuple(argv[1:]))
     start = int(job.options.get("-start_number", "0")) if numbers is None else 0
     return DecodePlan(tuple(argv), key, numbers, start)
@@ -200,9 +201,10 @@ class VideoSession:
                 if head is None:
                     break
                 w, h, maxval = head
-                if maxval != 255:
-                    raise PpmError("decoder delivered {}-level samples; the engine is 8-bit".format(maxval + 1))
-                nbytes = w * h * 3
+                if maxval not in (255, 65535):
+                    raise PpmError("decoder delivered {}-level samples; the engine takes 8- or 16-bit frames".format(maxval + 1))
+                fdtype = np.uint16 if maxval == 65535 else np.uint8
+                nbytes = w * h * 3 * np.dtype(fdtype).itemsize
                 if self.bytes + nbytes > self.budget:
                     raise PpmError("decoded frames exceed the HBM budget of {:.0f} GB per GPU (GS360_VIDEO_CACHE_GB); lower "
                                    "--fps, cut the range with --start/--end, or use --engine ffmpeg".format(
@@ -213,10 +215,12 @@ class VideoSession:
                     stage = pinned[(id(st), nbytes)] = st.ctx.pinned(nbytes)
                 host = np.frombuffer(stage.view, dtype=np.uint8, count=nbytes)      # the pinned block as an array
                 read_exact_into(out, memoryview(host))
+                if fdtype == np.uint16:
+                    host.view(np.uint16).byteswap(inplace=True)       # PPM samples are big-endian
                 buf = st.ctx.alloc(nbytes)
                 st.ctx.upload(buf, host, slot=st.upload_slot, sync=True)
                 with self.cond:
-                    self.frames.append((st, buf, h, w))
+                    self.frames.append((st, buf, h, w, fdtype))
                     self.bytes += nbytes
                     self.cond.notify_all()
                 k += 1
@@ -246,7 +250,7 @@ class VideoSession:
 
     # view jobs -------------------------------------------------------------------------------------------------
     def frame(self, k: int):
-        """k-th decoded frame as (state, DeviceBuffer, H, W); None after the last one.  Raises on decoder failure."""
+        """k-th decoded frame as (state, DeviceBuffer, H, W, dtype); None after the last one.  Raises on decoder failure."""
         with self.cond:
             while k >= len(self.frames) and not self.finished:
                 self.cond.wait(timeout=0.25)
@@ -266,7 +270,7 @@ class VideoSession:
                 pass
         self.thread.join(timeout=5.0)
         with self.cond:
-            for st, buf, _h, _w in self.frames:
+            for st, buf, _h, _w, _dt in self.frames:
                 if st.ctx.handle:
                     st.ctx.free(buf)
             self.frames = []

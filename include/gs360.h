@@ -243,6 +243,11 @@ int gs360_remap_table_u16_host(gs360_ctx *ctx, const uint16_t *src, int H, int W
                                int interp, const double *border_value, int fill_value,
                                uint16_t *dst, size_t dst_stride, int slot);
 
+/* ---- image-codec helper (host only, no GPU) ------------------------------------------------------
+ * In-place PNG scanline reconstruction (filter types 0-4) of h rows of (1 + stride) inflated bytes; bpp = bytes per
+ * complete pixel.  Used by the package's own 16-bit PNG reader; image codecs are outside the measured path. */
+int gs360_png_unfilter(uint8_t *data, int h, int stride, int bpp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@
 Understands exactly the command line gs360/video.py composes for its shared decoder:
     <prog> -hide_banner -loglevel error -nostdin [-copyts] [-ss S] -i clip.npy [-ss S] [-to T] [-vsync vfr]
            -vf <chain>,format=rgb24 -an -f image2pipe -c:v ppm pipe:1
-`clip.npy` is a uint8 array [N, H, W, 3]; frame n has timestamp n seconds.  `fps=F` keeps frames whose timestamp is
+`clip.npy` is a uint8 (or uint16) array [N, H, W, 3]; frame n has timestamp n seconds.  `fps=F` keeps frames whose timestamp is
 a multiple of 1/F (F <= 1 in the tests), `select='eq(n\\,i)+...'` keeps the listed indices, -ss/-to bound the timestamps.
 Anything that looks like the reference's per-view invocation (a v360 filter, an image file pattern as output) is
 refused with exit code 3, so a test notices when a job was routed to the subprocess path by mistake.
@@ -33,7 +33,8 @@ def main(argv):
             opts[tok] = val
         i += 2
     chain = opts.get("-vf", "")
-    if "v360=" in chain or opts.get("-f") != "image2pipe" or opts.get("-c:v") != "ppm" or not chain.endswith("format=rgb24"):
+    deep = chain.endswith("format=rgb48be")
+    if "v360=" in chain or opts.get("-f") != "image2pipe" or opts.get("-c:v") != "ppm" or not (chain.endswith("format=rgb24") or deep):
         sys.stderr.write("fake_ffmpeg: unexpected decoder command line\n")
         return 3
     if src is None or src.endswith("broken.npy"):
@@ -55,6 +56,11 @@ def main(argv):
     out = sys.stdout.buffer
     for n in keep:
         fr = np.ascontiguousarray(clip[n])
+        if deep:          # 16-bit PPM: maxval 65535, big-endian samples (an 8-bit clip is widened like ffmpeg's format filter)
+            fr16 = fr.astype(np.uint16) * (257 if fr.dtype == np.uint8 else 1)
+            out.write(b"P6\n%d %d\n65535\n" % (fr.shape[1], fr.shape[0]))
+            out.write(fr16.astype(">u2").tobytes())
+            continue
         out.write(b"P6\n%d %d\n255\n" % (fr.shape[1], fr.shape[0]))
         out.write(fr.tobytes())
     out.flush()

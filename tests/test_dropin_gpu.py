@@ -126,3 +126,27 @@ def test_engine_sharding_is_deterministic_across_device_counts(tmp_path, orc):
             assert len(used) > 1          # the frames really were spread over several contexts
     for name, img in results["one"].items():
         assert np.array_equal(img, results["two"][name]) and np.array_equal(img, results["three"][name])
+
+
+def test_cli_16bit_stills_keep_their_depth(tmp_path, orc):
+    """a 16-bit TIFF panorama -> 16-bit views (the reference's image mode sets no -pix_fmt for PNG/TIFF, PC:327-347, so ffmpeg
+    keeps the depth); JPEG output is the 8-bit container"""
+    d = tmp_path / "in"
+    d.mkdir()
+    a = np.random.default_rng(3).integers(0, 65536, (256, 512, 3), dtype=np.uint16)
+    imageio.write_image(d / "pano.tif", a)
+    r = subprocess.run(EXE + ["-i", str(d), "--count", "4", "--size", "72", "--ext", "tif"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "success=4, failed=0, total=4" in r.stdout
+    args = cut.create_arg_parser().parse_args(["-i", str(d), "--count", "4", "--size", "72", "--ext", "tif"])
+    for x in ("size", "hfov", "focal_mm"):
+        setattr(args, x + "_explicit", getattr(args, x + "_explicit", False))
+    args.input_is_video, args.video_bit_depth = False, 8
+    plan = cut.build_view_jobs(args, [d / "pano.tif"], d / "_geometry")
+    for v in plan.view_specs:
+        want = orc.equirect_views_u16(a, [orc.make_view(v.yaw_deg, v.pitch_deg, v.hfov_deg, v.vfov_deg, v.width, v.height)], interp=2)[0]
+        got = imageio.read_image(d / "_geometry" / v.output_name)
+        assert got.dtype == np.uint16 and np.array_equal(got, want), v.output_name
+    r = subprocess.run(EXE + ["-i", str(d), "--count", "2", "--size", "40", "--ext", "jpg", "-o", str(tmp_path / "j")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and imageio.read_image(tmp_path / "j" / "pano_A.jpg").dtype == np.uint8

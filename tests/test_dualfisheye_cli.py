@@ -227,3 +227,34 @@ def test_pair_pipeline_with_input_lut_on_gpu(tmp_path, orc, space):
     und = fe.undistort_tables(sensors["0"], None, 190.0)
     got = imageio.read_image(d.resolve().with_name("shots_undistorted") / "frame_0000_X.png")
     assert np.array_equal(got, orc.valid_fill(orc.remap_u8(conv[(0, "X")], und.map_x, und.map_y, interp=1, border_value=0.0), und.valid_mask, 0))
+
+
+@pytest.mark.gpu
+def test_pair_pipeline_16bit_sources_keep_their_depth(tmp_path, orc):
+    """16-bit lens images (cv2.imread(IMREAD_UNCHANGED) keeps them uint16, DF:735) leave as 16-bit PNGs, sampled by the CV_16U
+    cv2.remap restatement -- cubic, the tool's default interpolation (DF:229-234)"""
+    d = tmp_path / "shots"
+    d.mkdir()
+    rng = np.random.default_rng(15)
+    imgs = {}
+    for lens in "XY":
+        a = rng.integers(0, 65536, (240, 240, 3), dtype=np.uint16)
+        imageio.write_image(d / f"frame_0000_{lens}.png", a)
+        imgs[lens] = a
+    xml = tmp_path / "c.xml"
+    xml.write_text(SMALL_XML)
+    r = run(["-i", str(d), "-x", str(xml), "--perspective-size", "80", "--perspective-ext", "png", "--mask-value", "9", "--save-fisheye-output"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    sensors, _ = fe.load_metashape_calibration(xml)
+    specs = fe.sfm10_specs(80, 14.0, "36 36", 40.0, 40.0)
+    tables = fe.choose_lens_tables(sensors, "0", "0", specs, 0.0, 180.0, 190.0)
+    root = d.resolve().with_name("shots_perspective_colmap")
+    for spec in specs:
+        t = tables[spec["view_id"]]
+        got = imageio.read_image(root / "Images" / f"frame_0000_{spec['view_id']}.png")
+        want = orc.valid_fill(orc.remap_u16(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=2, border_value=(0, 0, 9, 0)), t["valid"], 9)
+        assert got.dtype == np.uint16 and np.array_equal(got, want), spec["view_id"]
+    und = fe.undistort_tables(sensors["0"], None, 190.0)
+    got = imageio.read_image(d.resolve().with_name("shots_undistorted") / "frame_0000_Y.png")
+    want = orc.valid_fill(orc.remap_u16(imgs["Y"], und.map_x, und.map_y, interp=2, border_value=(0, 0, 9, 0)), und.valid_mask, 9)
+    assert got.dtype == np.uint16 and np.array_equal(got, want)

@@ -81,6 +81,16 @@ def test_decode_plan_jpeg_and_gui_selection(tmp_path):
     assert [pathlib.Path(video.output_path(job, q, k)).name for k in range(3)] == ["clip_0000007_A.jpg", "clip_0000019_A.jpg", "clip_0000040_A.jpg"]
 
 
+def test_decode_plan_gui_selection_with_seek_falls_back(tmp_path):
+    """ADVICE r1 (video.py:100): with -copyts and output-side -ss/-to ffmpeg drops selected frames outside [S, T]; the PPM
+    pipe carries no timestamps, so the k-th decoded frame cannot be paired with the k-th selected index -> no plan"""
+    cmd = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "2", "--start", "3", "--end", "9"]).jobs[0][0]
+    assert video.build_decode_plan(parse_job_argv(cmd)) is not None                  # the planner's own shape is fine
+    sel = gui_select_rewrite(cmd, [1, 4, 7, 20])
+    assert "-ss" in sel and sel.index("-ss") > sel.index("-i")                       # the GUI moved the seek behind the input
+    assert video.build_decode_plan(parse_job_argv(sel)) is None
+
+
 def test_decode_plan_refuses_what_it_does_not_understand(tmp_path):
     cmd = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "2"]).jobs[0][0]
     assert video.build_decode_plan(parse_job_argv(cmd)) is not None
@@ -89,7 +99,9 @@ def test_decode_plan_refuses_what_it_does_not_understand(tmp_path):
         c = list(cmd)
         fn(c)
         return video.build_decode_plan(parse_job_argv(c))
-    assert mutate(lambda c: c.__setitem__(c.index("-pix_fmt") + 1, "rgb48le")) is None          # 16-bit output
+    deep = mutate(lambda c: c.__setitem__(c.index("-pix_fmt") + 1, "rgb48le"))                  # > 8-bit video (PC:343-347)
+    assert deep is not None and deep.argv[deep.argv.index("-vf") + 1].endswith(",format=rgb48be")   # 16-bit PPM pipe
+    assert mutate(lambda c: c.__setitem__(c.index("-pix_fmt") + 1, "gbrp12le")) is None         # any other pixel format
     assert mutate(lambda c: c.__setitem__(c.index("-vf") + 1, c[c.index("-vf") + 1] + ",hflip")) is None   # filter after v360
     assert mutate(lambda c: c.__setitem__(slice(-1, -1), ["-metadata", "x=y"])) is None          # foreign option
     assert mutate(lambda c: c.__setitem__(slice(-1, -1), ["-frame_pts", "1"])) is None           # pts numbering without a select list
@@ -177,8 +189,16 @@ def test_video_gui_selection_numbering_and_decoder_failure(tmp_path, orc):
     bad = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "2"], ffmpeg=prog, name="broken.npy").jobs[0][0]
     rc, text = cut.run_one(bad)
     assert rc == 1 and "decoder exited with code 1" in text and "cannot open input" in text
-    # a 16-bit request is not the engine's: it goes to the per-view subprocess, which the double refuses (rc 3)
+    # a > 8-bit video (rgb48le, PC:343-347) stays in the engine: 16-bit PPM pipe -> uint16 frames -> 16-bit PNG views
     deep = list(res.jobs[0][0])
     deep[deep.index("-pix_fmt") + 1] = "rgb48le"
-    rc, text = cut.run_one(deep)
+    deep[-1] = str(tmp_path / "out" / "deep_%07d_A.png")
+    assert cut.run_one(deep) == (0, "")
+    got = imageio.read_image(tmp_path / "out" / "deep_0000003_A.png")
+    want = orc.equirect_views_u16(clip[3].astype(np.uint16) * 257, [orc.make_view(0.0, 0.0, HFOV_12MM, HFOV_12MM, 32, 32)], interp=2)[0]
+    assert got.dtype == np.uint16 and np.array_equal(got, want)
+    # a pixel format the engine does not know goes to the per-view subprocess, which the double refuses (rc 3)
+    odd = list(res.jobs[0][0])
+    odd[odd.index("-pix_fmt") + 1] = "gbrp12le"
+    rc, text = cut.run_one(odd)
     assert rc == 3 and "only the PPM pipe decoder role" in text
