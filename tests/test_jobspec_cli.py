@@ -34,17 +34,25 @@ def test_every_reference_argv_parses_back(name):
         assert job.is_still_image == (not G["cases"][name]["video"])
 
 
-def test_gui_rewritten_argv_still_parses():
-    """gs360_GUI.py:19081-19148 edits the argv: select filter with escaped commas, -frame_pts, -copyts, moved seeks"""
-    argv = ["ffmpeg", "-hide_banner", "-loglevel", "error", "-y", "-copyts", "-i", "/v/clip.mp4", "-ss", "1.5", "-to", "9.0",
-            "-vf", "select='eq(n\\,3)+eq(n\\,17)+eq(n\\,40)',colorspace=iall=bt709:all=smpte170m:trc=iec61966-2-1:format=yuv444p,"
-                   "v360=input=equirect:output=rectilinear:w=1600:h=1600:yaw=45.0:pitch=30.0:roll=0:h_fov=104.25:v_fov=104.25:interp=cubic",
-            "-threads", "1", "-vsync", "vfr", "-frame_pts", "1", "-pix_fmt", "rgb24", "/o/clip_%07d_B_U.png"]
-    job = parse_job_argv(argv)
-    assert job.filters[0] == "select='eq(n\\,3)+eq(n\\,17)+eq(n\\,40)'"
-    assert job.filter_named("colorspace").startswith("colorspace=iall=bt709")
-    assert job.options["-ss"] == "1.5" and job.options["-to"] == "9.0" and "-copyts" in job.flags
-    assert not job.is_still_image and job.fnum("pitch") == 30.0
+GUI = json.loads((GOLDEN / "gui_select_goldens.json").read_text())["cases"]
+
+
+@pytest.mark.parametrize("case", sorted(GUI))
+def test_gui_rewritten_argv_still_parses(case):
+    """argv lists produced by the reference GUI's own _apply_frame_selection_to_jobs (gs360_GUI.py:19081-19148, captured by
+    tests/golden/make_gui_select_goldens.py): select filter with escaped commas, -frame_pts, -copyts, seeks moved behind -i"""
+    g = GUI[case]
+    for planned, argv in zip(g["planned"], g["rewritten"]):
+        job, ref = parse_job_argv(argv), parse_job_argv(planned)
+        want = "select='" + "+".join("eq(n\\,{})".format(i) for i in g["indices"]) + "'"
+        assert job.filters[0] == want and not any(f.startswith("fps=") for f in job.filters)
+        assert job.filter_named("colorspace") == ref.filter_named("colorspace")
+        assert "-copyts" in job.flags and job.options.get("-frame_pts") == "1" and "-start_number" not in job.options
+        assert job.v360 == ref.v360 and job.dst == ref.dst and job.src == ref.src and not job.is_still_image
+        for flag in ("-ss", "-to"):                       # seeks survive, but now on the output side
+            assert job.options.get(flag) == ref.options.get(flag)
+            if flag in job.options:
+                assert flag in job.output_options and flag not in job.input_options
 
 
 def test_filter_chain_splitter():

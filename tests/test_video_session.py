@@ -52,6 +52,31 @@ def gui_select_rewrite(cmd, indices):
     return cmd
 
 
+def test_gui_rewrite_helper_and_decode_plans_against_the_reference_gui_goldens():
+    """tests/golden/gui_select_goldens.json holds argv lists rewritten by the reference GUI's own function
+    (gs360_GUI.py:19081-19148): the helper above must reproduce them exactly, selections without a seek window get a shared
+    decode plan numbered by the selected indices, selections WITH -ss/-to fall back (video.py:100)."""
+    import json
+    from conftest import GOLDEN
+    cases = json.loads((GOLDEN / "gui_select_goldens.json").read_text())["cases"]
+    assert len(cases) >= 5
+    for name, g in cases.items():
+        keys = set()
+        for planned, rewritten in zip(g["planned"], g["rewritten"]):
+            assert gui_select_rewrite(planned, g["indices"]) == rewritten, name
+            job = parse_job_argv(rewritten)
+            plan = video.build_decode_plan(job)
+            if "-ss" in job.options or "-to" in job.options:
+                assert plan is None, name
+                continue
+            assert plan is not None and plan.numbers == tuple(sorted(set(g["indices"]))), name
+            assert "-copyts" in plan.argv and plan.argv[-1] == "pipe:1"
+            assert [pathlib.Path(video.output_path(job, plan, k)).name for k in range(len(plan.numbers))] == \
+                [job.dst.name % n for n in plan.numbers]
+            keys.add(plan.key)
+        assert len(keys) <= 1, name                       # every view job of the video shares ONE decode
+
+
 def test_decode_plan_from_planner_argv(tmp_path):
     res = plan_jobs(tmp_path, ["-f", "2", "--ext", "png", "--start", "3", "--end", "12.5", "--count", "4"])
     plans = [video.build_decode_plan(parse_job_argv(cmd)) for cmd, _s, _d in res.jobs]
