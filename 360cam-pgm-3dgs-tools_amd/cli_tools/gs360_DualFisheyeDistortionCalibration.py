@@ -9,8 +9,10 @@ and the same output layout (<dir>_perspective_colmap/Images|Masks, <dir>_undisto
 
 What changed underneath: the per-pair `cv2.remap` calls (reference :2001-2014, :2031-2043, :1198-1212) run on the
 GPU through libgs360hip.so.  Default `--map-mode table` samples the reference-identical NumPy tables
-(gs360/fisheye.py) with cv2's 8-bit fixed-point arithmetic -> bit-identical to the reference for nearest/linear;
-`--map-mode fused` evaluates the map in-kernel.  `--input-lut` (.cube 3D LUT + optional Rec.709 -> sRGB re-encode,
+(gs360/fisheye.py) with a restatement of cv2's arithmetic (8-bit fixed point; float weights for 16-bit images, which
+keep their depth) -> bit-identical to the CPU checker's restatement of cv2.remap for all four interpolations (against a
+real cv2 the parity is unpinned: none exists in the build or test images, tests/test_crosscheck_external.py runs where
+one does); `--map-mode fused` evaluates the map in-kernel (8-bit images).  `--input-lut` (.cube 3D LUT + optional Rec.709 -> sRGB re-encode,
 reference :494-725) also runs on the GPU, on the uploaded lens images before any resampling (8-bit images).
 Not built here (outside the pixel path): the COLMAP / Metashape metadata export -- the flags are
 accepted, and asking for that stage is reported as an error instead of being silently skipped.

@@ -89,7 +89,11 @@ int gs360_ctx_create(int device, int n_slots, gs360_ctx **out);
 int gs360_ctx_destroy(gs360_ctx *ctx);
 int gs360_device_info(gs360_ctx *ctx, char *name, size_t name_len, int32_t *cu_count, uint64_t *hbm_bytes);
 
-/* ---- memory (device buffers carry 64 B of readable slack after the requested size) --------- */
+/* ---- memory (device buffers carry 64 B of readable slack after the requested size) ---------
+ * Images handed to the hot-path entry points must come with that slack (the aligned 12- / 16-byte tap reads of the last
+ * pixels of the last row run past the image) and, for 3-channel images, a 4-byte aligned base pointer; equirect sources
+ * are at least 8 texels wide, H * stride < 2^32 and stride < 2^24 (32-bit tap offsets).  gs360_dev_alloc satisfies
+ * the first two; the size limits are checked and reported as GS360_ERR_ARG / GS360_ERR_UNSUPPORTED. */
 int gs360_dev_alloc(gs360_ctx *ctx, size_t bytes, void **dptr);
 int gs360_dev_free(gs360_ctx *ctx, void *dptr);
 int gs360_host_alloc(gs360_ctx *ctx, size_t bytes, void **hptr); /* pinned */
