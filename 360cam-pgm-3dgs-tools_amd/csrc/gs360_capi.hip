@@ -435,6 +435,22 @@ int gs360_event_elapsed_ms(gs360_ctx* c, int slot, int from, int to, float* ms) 
     return GS360_OK;
 }
 
+int gs360_event_sync(gs360_ctx* c, int slot, int idx) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (idx < 0 || idx >= kEventsPerSlot) return fail(GS360_ERR_ARG, "bad event index");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->event[slot][idx]));
+    return GS360_OK;
+}
+int gs360_stream_wait_event(gs360_ctx* c, int waiting_slot, int event_slot, int idx) {
+    if (int rc = check_ctx_slot(c, waiting_slot)) return rc;
+    if (int rc = check_ctx_slot(c, event_slot)) return rc;
+    if (idx < 0 || idx >= kEventsPerSlot) return fail(GS360_ERR_ARG, "bad event index");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamWaitEvent(c->stream[waiting_slot], c->event[event_slot][idx], 0));
+    return GS360_OK;
+}
+
 // ---- equirect -> views -------------------------------------------------------------------------
 namespace {
 int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void* const* mask_frames, int n_frames,
@@ -497,8 +513,11 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             !std::isfinite(views[k].vfov_deg))
             return fail(GS360_ERR_ARG, "view %d has a non-finite angle", k);
     }
-    for (int f = 0; f < n_frames; ++f)
+    for (int f = 0; f < n_frames; ++f) {
         if (!src_frames[f]) return fail(GS360_ERR_ARG, "src_frames[%d] is NULL", f);
+        if (C == 3 && esize == 1 && ((uintptr_t)src_frames[f] & 3))
+            return fail(GS360_ERR_ARG, "src_frames[%d] must be 4-byte aligned (the RGB tap reads are dword-aligned)", f);
+    }
     for (int i = 0; i < n_frames * n_views; ++i)
         if (!dst[i]) return fail(GS360_ERR_ARG, "dst[%d] is NULL", i);
     HIP_TRY(hipSetDevice(c->device));

@@ -30,7 +30,7 @@ EXPORTS = (
     "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
     "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
-    "gs360_png_unfilter",
+    "gs360_png_unfilter", "gs360_event_sync", "gs360_stream_wait_event",
 )
 
 
@@ -118,6 +118,8 @@ def load_library(path=None):
         L.gs360_equirect_views_u16_host.argtypes = L.gs360_equirect_views_u8_host.argtypes
         L.gs360_remap_table_u16_host.argtypes = L.gs360_remap_table_u8_host.argtypes
         L.gs360_png_unfilter.argtypes = [vp, i, i, i]
+        L.gs360_event_sync.argtypes = [vp, i, i]
+        L.gs360_stream_wait_event.argtypes = [vp, i, i, i]
         for name in EXPORTS:
             getattr(L, name).restype = C.c_int
         if path is None:
@@ -259,6 +261,12 @@ class Context:
 
     def event_record(self, slot, idx):
         _check(self.L.gs360_event_record(self.handle, slot, idx), self.L)
+
+    def event_sync(self, slot, idx):
+        _check(self.L.gs360_event_sync(self.handle, slot, idx), self.L)
+
+    def stream_wait_event(self, waiting_slot, event_slot, idx):
+        _check(self.L.gs360_stream_wait_event(self.handle, waiting_slot, event_slot, idx), self.L)
 
     def event_elapsed_ms(self, slot, i_from, i_to):
         ms = C.c_float()
