@@ -16,7 +16,38 @@ namespace gs360 {
 #define EQ_C4 (0.10597943514585495f)
 #define EQ_C5 (-0.06087981536984444f)
 
-// atan2(yy, xx) = r0 + K * pi/4 with |r0| <= pi/8 (sign folded into r0), K in [-4, 4]
+// n / d, correctly rounded, for EQ-SPEC's operands: 0 <= |n| <= d (or d = 1 with n = 0), d a NORMAL float in
+// [2^-100, 2^100] and the quotient zero or normal.  This is the IEEE sequence the compiler emits for `n / d`
+// (v_div_scale x2, v_rcp, Newton step on the reciprocal, quotient + two residual corrections, v_div_fmas, v_div_fixup) with
+// the three instructions that are the identity on this domain removed: v_div_scale only rescales when an operand, the
+// reciprocal or the quotient is denormal or the exponents differ by >= 96, and v_div_fixup only patches NaN / inf / zero
+// divisors.  In EQ-SPEC d is max(|a|, |b|) or a sum of two magnitudes of ray components (>= 6e-29 even for the
+// centre pixel of a pole view), the divisor-zero case is replaced by d = 1 before the call, and |n| <= d.
+// Same bits as `/`, 8 instead of 11 instructions, two divisions per pixel pair.
+__device__ __forceinline__ float eq_div(float n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+
+// sqrt(x), correctly rounded, x >= 0 finite.  For x >= 2^-96 this is the generic IEEE sequence (v_sqrt_f32 + the
+// two-sided one-ulp correction) without its input scaling for tiny operands and without the inf / zero class test; a
+// wavefront in which ANY lane holds a smaller operand (x = 0, or the centre pixel of a pole view: x^2 + b^2 ~ 4e-33)
+// takes the generic sequence as a whole (wave-uniform branch), so results are the same bits everywhere.
+__device__ __forceinline__ float eq_sqrt(float x) {
+    if (__builtin_expect(__any(!(x >= 0x1p-96f)), 0)) return __builtin_sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const int si = __builtin_bit_cast(int, s);
+    const float sd = __builtin_bit_cast(float, si - 1), su = __builtin_bit_cast(float, si + 1);
+    const float lo = __builtin_fmaf(-sd, s, x) <= 0.0f ? sd : s;
+    return __builtin_fmaf(-su, s, x) > 0.0f ? su : lo;
+}
+
+// atan2(yy, xx) = r0 + K * pi/4 with |r0| <= pi/8 (sign folded into r0), K in [-4, 4].
+// XPOS: the caller guarantees xx >= 0 (latitude: xx is a square root), which drops the left-half-plane fix-up.
+template <bool XPOS = false>
 __device__ __forceinline__ float eq_atan2_red(float yy, float xx, int& K) {
     float ax = __builtin_fabsf(xx), ay = __builtin_fabsf(yy);
     bool steep = ay > ax;
@@ -24,7 +55,7 @@ __device__ __forceinline__ float eq_atan2_red(float yy, float xx, int& K) {
     bool big = mn > EQ_T8 * mx;
     float num = big ? mn - mx : mn;
     float den = big ? mn + mx : mx;
-    float t = num / (den > 0.0f ? den : 1.0f);   // den == 0 only when num == 0: same value as the spec's guard, no branch
+    float t = eq_div(num, den > 0.0f ? den : 1.0f);   // den == 0 only when num == 0: same value as the spec's guard, no branch
     float z = t * t;
     float p = __builtin_fmaf(EQ_C5, z, EQ_C4);
     p = __builtin_fmaf(p, z, EQ_C3);
@@ -33,7 +64,9 @@ __device__ __forceinline__ float eq_atan2_red(float yy, float xx, int& K) {
     float r0 = __builtin_fmaf(p * z, t, t);
     int k = big ? 1 : 0;
     if (steep) { r0 = -r0; k = 2 - k; }
-    if (xx < 0.0f) { r0 = -r0; k = 4 - k; }
+    if constexpr (!XPOS) {
+        if (xx < 0.0f) { r0 = -r0; k = 4 - k; }
+    }
     if (yy < 0.0f) { r0 = -r0; k = -k; }
     K = k;
     return r0;
@@ -80,10 +113,10 @@ __device__ __forceinline__ void eq_coord_px(const EqLaunch& L, const EqView& V, 
         bz = __builtin_fmaf(V.sp, yv, V.cp);
         cy = __builtin_fmaf(-V.cp, yv, V.sp);
     }
-    const float h = __builtin_sqrtf(__builtin_fmaf(x, x, bz * bz));
+    const float h = eq_sqrt(__builtin_fmaf(x, x, bz * bz));
     int Kl, Kt;
     const float rl = eq_atan2_red(x, bz, Kl);
-    const float rt = eq_atan2_red(cy, h, Kt);
+    const float rt = eq_atan2_red<true>(cy, h, Kt);
     sx = eq_quant_lon(rl, Kl, L, V);
     sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
 }

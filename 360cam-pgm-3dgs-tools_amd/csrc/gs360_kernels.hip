@@ -220,7 +220,8 @@ struct EqTaps {
 template <int C>
 __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, int64_t stride, int W, int H, int sx, int sy) {
     const int ix = sx >> 5, iy = sy >> 5;
-    const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
+    // |lat| <= pi/2 by construction of eq_atan2_red, so sy lies in [-16, 32 H - 16] and iy in [-1, H - 1]: one clamp per row
+    const int y0 = max(iy, 0), y1 = min(iy + 1, H - 1);
     constexpr int kBack = (C == 3) ? 5 : 2;      // the 12-byte aligned read of RGB taps may run 6 bytes past them
     const int ixl = min(ix, W - kBack);
     // 32-bit byte offsets from the wave-uniform frame base (host guarantees H * stride < 2^32, stride < 2^24):
@@ -593,8 +594,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
             const float xx = (float)(2 * xs + 1 - V.out_w) * V.sxu;
             int Kl, Kt;
             const float rl = eq_atan2_red(xx, 1.0f, Kl);
-            const float h = __builtin_sqrtf(__builtin_fmaf(xx, xx, 1.0f));
-            const float rt = eq_atan2_red(cy, h, Kt);
+            const float h = eq_sqrt(__builtin_fmaf(xx, xx, 1.0f));
+            const float rt = eq_atan2_red<true>(cy, h, Kt);
             const int q = Kt * 8 * L.H + (int)__builtin_rintf(rt * L.ky32);
             sys[s] = L.y0i32 - q;
             sys[s + 2] = L.y0i32 + q;
@@ -605,13 +606,13 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         int Kl;
         const float rl = eq_atan2_red(x, 1.0f, Kl);       // b = fma(0, yv, 1) = 1 for every row
         const int sx_left = eq_quant_lon(rl, Kl, L, V), sx_mirror = eq_quant_lon(-rl, -Kl, L, V);
-        const float h = __builtin_sqrtf(__builtin_fmaf(x, x, 1.0f));
+        const float h = eq_sqrt(__builtin_fmaf(x, x, 1.0f));
 #pragma unroll
         for (int s = 0; s < kHalfRows; ++s) {
             const float yv = (float)(2 * ys[s] + 1 - V.out_h) * V.syv;
             const float cy = __builtin_fmaf(-V.cp, yv, V.sp);
             int Kt;
-            const float rt = eq_atan2_red(cy, h, Kt);
+            const float rt = eq_atan2_red<true>(cy, h, Kt);
             const int q = Kt * 8 * L.H + (int)__builtin_rintf(rt * L.ky32);
             sys[s] = L.y0i32 - q;
             sys[s + kHalfRows] = L.y0i32 + q;
@@ -632,10 +633,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         for (int s = 0; s < kRowsPerWave; ++s) {
             const int xs = min(x0 + 16 * s + (lane & 15), half_w - 1);
             const float xx = (float)(2 * xs + 1 - V.out_w) * V.sxu;
-            const float h = __builtin_sqrtf(__builtin_fmaf(xx, xx, bzl * bzl));
+            const float h = eq_sqrt(__builtin_fmaf(xx, xx, bzl * bzl));
             int Kl, Kt;
             const float rl = eq_atan2_red(xx, bzl, Kl);
-            const float rt = eq_atan2_red(cyl, h, Kt);
+            const float rt = eq_atan2_red<true>(cyl, h, Kt);
             sxl[s] = eq_quant_lon(rl, Kl, L, V);
             sxm[s] = eq_quant_lon(-rl, -Kl, L, V);
             sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
@@ -656,10 +657,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
                 bz = __builtin_fmaf(V.sp, yv, V.cp);    // forward component after pitch
                 cy = __builtin_fmaf(-V.cp, yv, V.sp);   // up component after pitch
             }
-            const float h = __builtin_sqrtf(__builtin_fmaf(xr, xr, bz * bz));
+            const float h = eq_sqrt(__builtin_fmaf(xr, xr, bz * bz));
             int Kl, Kt;
             const float rl = eq_atan2_red(xr, bz, Kl);
-            const float rt = eq_atan2_red(cy, h, Kt);
+            const float rt = eq_atan2_red<true>(cy, h, Kt);
             sxl[s] = eq_quant_lon(rl, Kl, L, V);
             sxm[s] = eq_quant_lon(-rl, -Kl, L, V);
             sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
