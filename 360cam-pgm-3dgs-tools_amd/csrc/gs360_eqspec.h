@@ -36,6 +36,13 @@ __device__ __forceinline__ float eq_div(float n, float d) {
 // two-sided one-ulp correction) without its input scaling for tiny operands and without the inf / zero class test; a
 // wavefront in which ANY lane holds a smaller operand (x = 0, or the centre pixel of a pole view: x^2 + b^2 ~ 4e-33)
 // takes the generic sequence as a whole (wave-uniform branch), so results are the same bits everywhere.
+__device__ __forceinline__ float eq_sqrt_normal(float x) {   // x in [2^-96, 2^96]: no fallback needed
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const int si = __builtin_bit_cast(int, s);
+    const float sd = __builtin_bit_cast(float, si - 1), su = __builtin_bit_cast(float, si + 1);
+    const float lo = __builtin_fmaf(-sd, s, x) <= 0.0f ? sd : s;
+    return __builtin_fmaf(-su, s, x) > 0.0f ? su : lo;
+}
 __device__ __forceinline__ float eq_sqrt(float x) {
     if (__builtin_expect(__any(!(x >= 0x1p-96f)), 0)) return __builtin_sqrtf(x);
     const float s = __builtin_amdgcn_sqrtf(x);

@@ -1052,9 +1052,11 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
         float z1 = __builtin_fmaf(V.sp, yv, V.cp);
         float X = __builtin_fmaf(V.cy, x, V.sy * z1);
         float Z = __builtin_fmaf(-V.sy, x, V.cy * z1);
-        float N = __builtin_sqrtf(__builtin_fmaf(x, x, __builtin_fmaf(yv, yv, 1.0f)));
+        // N >= 1; d = N (N + Z) is 0 or >= ~1e-7 and <= ~1e7, so 2 / d and both square roots stay far from the denormal /
+        // overflow ranges in which the generic IEEE expansions differ from the reduced ones (gs360_eqspec.h)
+        float N = eq_sqrt_normal(__builtin_fmaf(x, x, __builtin_fmaf(yv, yv, 1.0f)));
         float d = N * (N + Z);
-        float s = d > 0.0f ? __builtin_sqrtf(2.0f / d) : 0.0f;
+        float s = d > 0.0f ? eq_sqrt_normal(eq_div(2.0f, d)) : 0.0f;
         float xn = X * s, yn = -(Y * s);
         float r2 = __builtin_fmaf(xn, xn, yn * yn);
         float r4 = r2 * r2;
