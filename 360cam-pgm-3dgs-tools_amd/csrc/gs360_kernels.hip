@@ -1072,7 +1072,8 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
         float my = __builtin_fmaf(yd, V.f, V.cy0);
         mxs[rr] = mx;
         mys[rr] = my;
-        oks[rr] = (Z >= V.cos_tmax * N) && (mx >= 0.0f) && (mx <= V.wmax) && (my >= 0.0f) && (my <= V.hmax);
+        // bitwise: short-circuit && turned into nested exec-mask branches with scalar loads inside each of the four slots
+        oks[rr] = (Z >= V.cos_tmax * N) & (mx >= 0.0f) & (mx <= V.wmax) & (my >= 0.0f) & (my <= V.hmax);
     }
     uint32_t px[kRowsPerWave][4];
     if ((INTERP == GS360_INTERP_CUBIC) && (C == 3) && L.pipelined) {

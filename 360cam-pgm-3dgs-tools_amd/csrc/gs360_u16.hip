@@ -63,6 +63,31 @@ __global__ __launch_bounds__(64 * kWaves) void eq_views_u16_kernel(const EqLaunc
             const uint16_t* r0 = src + (size_t)y0 * ss;
             const uint16_t* r1 = src + (size_t)y1 * ss;
             const uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
+            if constexpr (C == 3) {
+                // the two RGB taps of a row are 12 contiguous bytes: one dword-aligned 16-byte read per row (the frame base
+                // is 4-byte aligned, device buffers carry 64 bytes of slack) shifted into place, instead of six 2-byte loads
+                if (ix1 != 0 && ix + 3 <= W && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)L.src_stride) & 3) == 0) {
+                    uint32_t d[2][3];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const uint16_t* p = (rr ? r1 : r0) + (size_t)ix * 3;
+                        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;        // 0 or 2
+                        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const uint8_t*>(p) - o, 4));
+                        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                        d[rr][0] = __builtin_amdgcn_alignbyte(q1, q0, o);
+                        d[rr][1] = __builtin_amdgcn_alignbyte(q2, q1, o);
+                        d[rr][2] = __builtin_amdgcn_alignbyte(q3, q2, o);
+                    }
+                    // samples: R0 G0 | B0 R1 | G1 B1
+                    const uint32_t s00[3] = {d[0][0] & 0xffffu, d[0][0] >> 16, d[0][1] & 0xffffu};
+                    const uint32_t s01[3] = {d[0][1] >> 16, d[0][2] & 0xffffu, d[0][2] >> 16};
+                    const uint32_t s10[3] = {d[1][0] & 0xffffu, d[1][0] >> 16, d[1][1] & 0xffffu};
+                    const uint32_t s11[3] = {d[1][1] >> 16, d[1][2] & 0xffffu, d[1][2] >> 16};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) out[c] = (uint16_t)(((s00[c] * a0 + s01[c] * a1) * b0 + (s10[c] * a0 + s11[c] * a1) * b1 + 512u) >> 10);
+                    continue;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const uint32_t acc = ((uint32_t)r0[ix * C + c] * a0 + (uint32_t)r0[ix1 * C + c] * a1) * b0 +

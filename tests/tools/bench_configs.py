@@ -44,7 +44,9 @@ def time_steps(ctx, call, steps, warmup=5):
     return ctx.event_elapsed_ms(0, 0, 1) / steps
 
 
-def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR, with_mask=False):
+def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR, with_mask=False, dtype=np.uint8):
+    if dtype == np.uint16:
+        return equirect_u16_cfg(ctx, name, W, H, specs, n_frames, steps, interp)
     frames = [synth(H, W, k) for k in range(n_frames)]
     d_fr = [ctx.to_device(f) for f in frames]
     views = [gs360.View.make(*s) for s in specs]
@@ -80,6 +82,30 @@ def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LI
             "MPix_per_s": round(out_px * n_frames / ms / 1e3, 0), "algorithmic_MB_per_frame": round(algo / n_frames / 1e6, 1),
             "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
             "parity_vs_oracle": bool(np.array_equal(got, want))}
+
+
+def equirect_u16_cfg(ctx, name, W, H, specs, n_frames, steps, interp):
+    """the first-cut 16-bit kernel (rgb48 frames): same workload shape, 2-byte samples"""
+    frames = [(synth(H, W, k).astype(np.uint16) * 257) ^ np.uint16(k + 1) for k in range(n_frames)]
+    d_fr = [ctx.to_device(f) for f in frames]
+    views = [gs360.View.make(*s) for s in specs]
+    d_out = [ctx.alloc(s[4] * s[5] * 6) for _ in range(n_frames) for s in specs]
+
+    def call():
+        ctx.equirect_views_dev(d_fr, W, H, 3, views, d_out, slot=0, interp=interp, dtype=np.uint16)
+    ms = time_steps(ctx, call, steps)
+    k = len(specs) // 2
+    got = ctx.download(d_out[k], (specs[k][5], specs[k][4], 3), dtype=np.uint16)
+    want = orc.equirect_views_u16(frames[0], [orc.make_view(*specs[k])], threads=0, interp=2 if interp == 2 else 1)[0]
+    uv = sum(orc.equirect_distinct_texels(orc.make_view(*s), W, H) for s in specs)
+    out_px = sum(s[4] * s[5] for s in specs)
+    algo = (out_px * 6 + uv * 6) * n_frames
+    for b in d_fr + d_out:
+        ctx.free(b)
+    return {"config": name, "frames_per_launch": n_frames, "views": len(specs), "ms_per_launch": round(ms, 4),
+            "us_per_frame": round(ms / n_frames * 1e3, 1), "MPix_per_s": round(out_px * n_frames / ms / 1e3, 0),
+            "algorithmic_MB_per_frame": round(algo / n_frames / 1e6, 1), "achieved_GB_per_s": round(algo / ms / 1e6, 0),
+            "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3), "parity_vs_oracle": bool(np.array_equal(got, want))}
 
 
 def fisheye_cfg(ctx, steps):
@@ -189,6 +215,10 @@ def main():
         "cfg2": lambda: equirect_cfg(ctx, "cfg2 7680x3840 -> 6x800^2 (headline, bench.py)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8, args.steps),
         "cfg2cubic": lambda: equirect_cfg(ctx, "cfg2 with INTER_CUBIC (reference default interp)", 7680, 3840, ring_views(6, 800, HFOV_12MM), 8,
                                           args.steps, interp=gs360.INTERP_CUBIC),
+        "cfg2u16": lambda: equirect_cfg(ctx, "cfg2 shape on rgb48 (uint16) frames, bilinear", 7680, 3840, ring_views(6, 800, HFOV_12MM), 4, args.steps,
+                                        dtype=np.uint16),
+        "cfg2u16cubic": lambda: equirect_cfg(ctx, "cfg2 shape on rgb48 (uint16) frames, cubic", 7680, 3840, ring_views(6, 800, HFOV_12MM), 4,
+                                             args.steps, interp=gs360.INTERP_CUBIC, dtype=np.uint16),
         "cfg3": lambda: equirect_cfg(ctx, "cfg3 7680x3840 -> full360coverage 12x1600^2", 7680, 3840,
                                      [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps),
         "cfg5": lambda: equirect_cfg(ctx, "cfg5 7680x3840 -> fisheyelike 10x2048^2 (u8, no fp16/mask fusion)", 7680, 3840,
