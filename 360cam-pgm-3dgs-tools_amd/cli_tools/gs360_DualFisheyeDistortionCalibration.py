@@ -13,7 +13,7 @@ GPU through libgs360hip.so.  Default `--map-mode table` samples the reference-id
 keep their depth) -> bit-identical to the CPU checker's restatement of cv2.remap for all four interpolations (against a
 real cv2 the parity is unpinned: none exists in the build or test images, tests/test_crosscheck_external.py runs where
 one does); `--map-mode fused` evaluates the map in-kernel (8-bit images).  `--input-lut` (.cube 3D LUT + optional Rec.709 -> sRGB re-encode,
-reference :494-725) also runs on the GPU, on the uploaded lens images before any resampling (8-bit images).
+reference :494-725) also runs on the GPU, on the uploaded lens images before any resampling (8- and 16-bit images).
 Not built here (outside the pixel path): the COLMAP / Metashape metadata export -- the flags are
 accepted, and asking for that stage is reported as an error instead of being silently skipped.
 """
@@ -52,13 +52,15 @@ _OPTIONS = (
     (("-o", "--output-dir"), dict(default=None, help="folder for undistorted fisheye images (default <input>_undistorted)")),
     (("--suffixes",), dict(default="_X,_Y", help="stem suffixes of the two lenses, comma separated")),
     (("--ext",), dict(default="jpg,jpeg,png,tif,tiff", help="input extensions to pick up, comma separated")),
-    (("--input-lut",), dict(default=None, help=".cube 3D LUT applied to the lens images on the GPU before resampling (8-bit images)")),
+    (("--input-lut",), dict(default=None, help=".cube 3D LUT applied to the lens images on the GPU before resampling (8- and 16-bit images)")),
     (("--lut-output-color-space",), dict(metavar="{passthrough,srgb}", default="srgb", help="colour space written after the LUT")),
     (("--input-color-profile",), dict(choices=("native", "osmo360-dlogm"), default="native", help=H)),
     (("--dlogm-lut",), dict(default=str(DEFAULT_DLOGM_LUT), help=H)),
     (("--sensor-id-x",), dict(default=None, help="force this sensor id for the X lens")),
     (("--sensor-id-y",), dict(default=None, help="force this sensor id for the Y lens")),
-    (("--interpolation",), dict(choices=tuple(INTERPOLATION_MAP.keys()), default="cubic", help="resampling kernel")),
+    (("--interpolation",), dict(choices=tuple(INTERPOLATION_MAP.keys()), default="cubic",
+                                help="resampling kernel (GPU cost per pair of 6 x 1750^2 views on 8-bit RGB: nearest / linear ~0.08 ms, "
+                                     "cubic ~0.2 ms, lanczos4 ~2.8 ms -- its 8x8 window runs through the straight-line sampler)")),
     (("--undistort-zoom",), dict(default="auto", help="zoom of the undistorted fisheye output: a positive number or 'auto'")),
     (("--mask-outside-model",), dict(dest="mask_outside_model", action="store_true", help="paint pixels outside the lens model with --mask-value")),
     (("--no-mask-outside-model",), dict(dest="mask_outside_model", action="store_false", help="leave pixels outside the lens model as sampled")),

@@ -799,6 +799,97 @@ int gs360_color_apply_u8(gs360_ctx* c, const gs360_color_plan* p, const void* sr
     return GS360_OK;
 }
 
+struct gs360_color_plan16 {
+    int device = 0;
+    gs360::Color16Launch L;
+    float* d_lut = nullptr;
+    float* d_thr = nullptr;
+};
+
+int gs360_color_plan16_create(gs360_ctx* c, const float* lut, int lut_size, const float* domain_min, const float* domain_max,
+                              int n_pieces, const float* piece_start, const int32_t* piece_base, const int32_t* piece_off,
+                              const float* thresholds, gs360_color_plan16** out) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (!lut || !domain_min || !domain_max || !out) return fail(GS360_ERR_ARG, "NULL argument");
+    if (lut_size < 2 || lut_size > 256) return fail(GS360_ERR_ARG, "LUT size %d outside [2,256]", lut_size);
+    if (n_pieces < 0 || n_pieces > 4) return fail(GS360_ERR_ARG, "n_pieces must be in [0,4]");
+    if (n_pieces && (!piece_start || !piece_base || !piece_off || !thresholds)) return fail(GS360_ERR_ARG, "NULL piece tables");
+    gs360_color_plan16* p = new (std::nothrow) gs360_color_plan16();
+    if (!p) return fail(GS360_ERR_NOMEM, "out of host memory");
+    std::memset(&p->L, 0, sizeof(p->L));
+    for (int k = 0; k < 3; ++k) {
+        p->L.dmin[k] = domain_min[k];
+        p->L.span[k] = domain_max[k] - domain_min[k];                 // float32 subtraction, DF:641
+        if (!(p->L.span[k] > 0.0f)) { delete p; return fail(GS360_ERR_ARG, "invalid LUT domain on channel %d", k); }
+    }
+    int total = 0;
+    for (int q = 0; q < n_pieces; ++q) {
+        const int lo = piece_off[q], hi = piece_off[q + 1];
+        if (lo != total || hi < lo || hi > (1 << 20)) { delete p; return fail(GS360_ERR_ARG, "piece_off must be contiguous and ascending"); }
+        for (int i = lo + 1; i < hi; ++i)
+            if (!(thresholds[i] >= thresholds[i - 1])) { delete p; return fail(GS360_ERR_ARG, "thresholds of piece %d are not sorted (entry %d)", q, i); }
+        if (piece_base[q] < 0 || piece_base[q] + (hi - lo) > 65535) { delete p; return fail(GS360_ERR_ARG, "piece %d would produce levels above 65535", q); }
+        if (q > 0 && !(piece_start[q] >= piece_start[q - 1])) { delete p; return fail(GS360_ERR_ARG, "piece_start must be ascending"); }
+        p->L.start[q] = q ? piece_start[q] : 0.0f;
+        p->L.base[q] = piece_base[q];
+        p->L.off[q] = lo;
+        total = hi;
+    }
+    p->L.off[n_pieces] = total;
+    p->L.n_pieces = n_pieces;
+    p->L.lut_size = lut_size;
+    p->device = c->device;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n3 = (size_t)lut_size * lut_size * lut_size * 3;
+    hipError_t e = hipMalloc((void**)&p->d_lut, n3 * sizeof(float) + kSlack);
+    if (e == hipSuccess) e = hipMemcpy(p->d_lut, lut, n3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && total) e = hipMalloc((void**)&p->d_thr, (size_t)total * sizeof(float));
+    if (e == hipSuccess && total) e = hipMemcpy(p->d_thr, thresholds, (size_t)total * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->d_lut) (void)hipFree(p->d_lut);
+        if (p->d_thr) (void)hipFree(p->d_thr);
+        delete p;
+        return fail(GS360_ERR_HIP, "colour plan setup failed: %s", hipGetErrorString(e));
+    }
+    p->L.lut = p->d_lut;
+    p->L.thr = p->d_thr;
+    *out = p;
+    return GS360_OK;
+}
+
+int gs360_color_plan16_destroy(gs360_ctx* c, gs360_color_plan16* p) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (!p) return GS360_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (p->d_lut) HIP_TRY(hipFree(p->d_lut));
+    if (p->d_thr) HIP_TRY(hipFree(p->d_thr));
+    delete p;
+    return GS360_OK;
+}
+
+int gs360_color_apply_u16(gs360_ctx* c, const gs360_color_plan16* p, const void* src, int H, int W, int C, size_t src_stride,
+                          int red_index, void* dst, size_t dst_stride, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!p || !src || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (p->device != c->device) return fail(GS360_ERR_ARG, "colour plan belongs to device %d, ctx is device %d", p->device, c->device);
+    if (C != 3 && C != 4) return fail(GS360_ERR_ARG, "the LUT stage needs 3 or 4 channels (got %d)", C);
+    if (red_index != 0 && red_index != 2) return fail(GS360_ERR_ARG, "red_index must be 0 (RGB) or 2 (BGR)");
+    if (H < 0 || W < 0) return fail(GS360_ERR_ARG, "bad size");
+    if (H == 0 || W == 0) return GS360_OK;
+    if (H > 65535) return fail(GS360_ERR_UNSUPPORTED, "image height %d above 65535", H);
+    if (src_stride == 0) src_stride = (size_t)W * C * 2;
+    if (dst_stride == 0) dst_stride = (size_t)W * C * 2;
+    if (src_stride < (size_t)W * C * 2 || dst_stride < (size_t)W * C * 2 || ((src_stride | dst_stride) & 1))
+        return fail(GS360_ERR_ARG, "16-bit images need even strides of at least one row");
+    HIP_TRY(hipSetDevice(c->device));
+    gs360::Color16Launch L = p->L;
+    L.src = src; L.dst = dst; L.H = H; L.W = W; L.red_index = red_index;
+    L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
+    HIP_TRY(launch_color16(L, C, c->stream[slot]));
+    return GS360_OK;
+}
+
 // ---- image-codec helper (host only) ---------------------------------------------------------------
 // PNG scanline reconstruction (filter types 0-4) in place: `data` holds h rows of (1 + stride) bytes as inflated from the
 // IDAT stream; on return row y's pixels sit at data + y * (stride + 1) + 1.  Both directions of a PNG filter are

@@ -233,6 +233,74 @@ __global__ void color_rtab_kernel(const float* lut /* [b][g][r][3] */, const flo
     rtab[idx] = o;
 }
 
+// ---- 16-bit images (DF:603-618 handle uint16 like uint8, with 65535 levels) ------------------------------------------------
+// With 65536 input levels per channel nothing is tabulated on the input side: float01 conversion, domain mapping, cell
+// lookup and all three interpolation stages are evaluated per pixel with the reference's own float32 operations (IEEE
+// division: the library is built with correctly rounded division).  Output side: `passthrough` is rint(clip(x) * 65535)
+// in-kernel; the sRGB re-encode goes through NumPy's implementation-defined float32 power, so it arrives as sorted
+// thresholds like the 8-bit path -- but in PIECES (the composite is only piecewise monotone at 16-bit resolution: Rec.709
+// knee, sRGB toe): piece p covers clip(x) in [start[p], start[p+1]), level = base[p] + #(thresholds of p <= clip(x)).
+struct Color16Args {
+    const uint16_t* src;
+    uint16_t* dst;
+    const float* lut;        // [b][g][r][3]
+    const float* thr;        // concatenated per-piece thresholds (sorted within a piece)
+    float dmin[3], span[3];
+    float start[4];          // piece lower bounds (start[0] unused)
+    int32_t base[4], off[5];
+    int32_t n_pieces;        // 0: passthrough
+    int32_t H, W, n, red;
+    int64_t src_stride, dst_stride;   // bytes
+};
+
+__device__ __forceinline__ int level16_of(const Color16Args& A, float x) {
+    const float xc = fminf(fmaxf(x, 0.0f), 1.0f);
+    if (A.n_pieces == 0) return (int)__builtin_rintf(xc * 65535.0f);
+    int p = 0;
+    if (A.n_pieces > 1 && xc >= A.start[1]) p = 1;
+    if (A.n_pieces > 2 && xc >= A.start[2]) p = 2;
+    if (A.n_pieces > 3 && xc >= A.start[3]) p = 3;
+    const float* t = A.thr + A.off[p];
+    int lo = 0, hi = A.off[p + 1] - A.off[p];          // count of thresholds <= xc (upper bound)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (t[mid] <= xc) lo = mid + 1; else hi = mid;
+    }
+    return A.base[p] + lo;
+}
+
+template <int C>
+__global__ __launch_bounds__(kColorThreads) void color_lut_u16_kernel(Color16Args A) {
+    const int x = blockIdx.x * kColorThreads + threadIdx.x;
+    if (x >= A.W) return;
+    const uint16_t* sp = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(A.src) + (int64_t)blockIdx.y * A.src_stride) + (int64_t)x * C;
+    uint16_t* dp = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(A.dst) + (int64_t)blockIdx.y * A.dst_stride) + (int64_t)x * C;
+    const int iR = A.red, iB = 2 - A.red;
+    const int v[3] = {sp[iR], sp[1], sp[iB]};
+    const int alpha = (C == 4) ? sp[3] : 0;
+    const int n = A.n, nmax = n - 1;
+    Cell c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float f01 = (float)v[k] / 65535.0f;                                        // DF:609-610
+        const float coord = fminf(fmaxf((f01 - A.dmin[k]) / A.span[k], 0.0f), 1.0f);     // DF:647
+        c[k] = cell_of(coord * (float)nmax, nmax);                                       // DF:648-653
+    }
+    const float* T = A.lut;
+    auto at = [&](int bi, int gi, int ri, int ch) { return T[(((size_t)bi * n + gi) * n + ri) * 3 + ch]; };
+    int q[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float c00 = lerp_ref(at(c[2].i0, c[1].i0, c[0].i0, ch), at(c[2].i0, c[1].i0, c[0].i1, ch), c[0].f);   // DF:672-675
+        const float c10 = lerp_ref(at(c[2].i0, c[1].i1, c[0].i0, ch), at(c[2].i0, c[1].i1, c[0].i1, ch), c[0].f);
+        const float c01 = lerp_ref(at(c[2].i1, c[1].i0, c[0].i0, ch), at(c[2].i1, c[1].i0, c[0].i1, ch), c[0].f);
+        const float c11 = lerp_ref(at(c[2].i1, c[1].i1, c[0].i0, ch), at(c[2].i1, c[1].i1, c[0].i1, ch), c[0].f);
+        q[ch] = level16_of(A, lerp_ref(lerp_ref(c00, c10, c[1].f), lerp_ref(c01, c11, c[1].f), c[2].f));            // DF:676-679
+    }
+    dp[iR] = (uint16_t)q[0]; dp[1] = (uint16_t)q[1]; dp[iB] = (uint16_t)q[2];
+    if (C == 4) dp[3] = (uint16_t)alpha;
+}
+
 template <int C, int FIX>
 void launch_variant(const ColorArgs& A, bool aligned, hipStream_t s) {
     if (aligned) {
@@ -271,6 +339,20 @@ int color_build_bins(const float* thr /* 256, [0] unused */, uint8_t* bins /* kB
 hipError_t build_color_rtab(const float* d_lut, const float* d_pos_r, void* d_rtab, int lut_size, hipStream_t s) {
     const int total = lut_size * lut_size * 256;
     hipLaunchKernelGGL(color_rtab_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_lut, d_pos_r, (F3*)d_rtab, lut_size);
+    return hipGetLastError();
+}
+
+hipError_t launch_color16(const Color16Launch& L, int C, hipStream_t s) {
+    Color16Args A;
+    A.src = (const uint16_t*)L.src; A.dst = (uint16_t*)L.dst; A.lut = L.lut; A.thr = L.thr;
+    for (int k = 0; k < 3; ++k) { A.dmin[k] = L.dmin[k]; A.span[k] = L.span[k]; }
+    for (int k = 0; k < 4; ++k) { A.start[k] = L.start[k]; A.base[k] = L.base[k]; }
+    for (int k = 0; k < 5; ++k) A.off[k] = L.off[k];
+    A.n_pieces = L.n_pieces; A.H = L.H; A.W = L.W; A.n = L.lut_size; A.red = L.red_index;
+    A.src_stride = L.src_stride; A.dst_stride = L.dst_stride;
+    dim3 grid((unsigned)((L.W + kColorThreads - 1) / kColorThreads), (unsigned)L.H);
+    if (C == 3) hipLaunchKernelGGL((color_lut_u16_kernel<3>), grid, dim3(kColorThreads), 0, s, A);
+    else hipLaunchKernelGGL((color_lut_u16_kernel<4>), grid, dim3(kColorThreads), 0, s, A);
     return hipGetLastError();
 }
 

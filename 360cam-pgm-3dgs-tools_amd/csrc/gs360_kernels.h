@@ -131,6 +131,18 @@ struct ColorLaunch {
     int32_t fixups;         // 1 or 2 in-bin threshold compares, 0 = binary search (color_build_bins)
     int64_t src_stride, dst_stride;
 };
+struct Color16Launch {     // 16-bit images: everything per pixel, output thresholds in monotone pieces (gs360_color.hip)
+    const void* src;
+    void* dst;
+    const float* lut;       // device [b][g][r][3]
+    const float* thr;       // device, concatenated pieces
+    float dmin[3], span[3];
+    float start[4];
+    int32_t base[4], off[5];
+    int32_t n_pieces, H, W, lut_size, red_index;
+    int64_t src_stride, dst_stride;
+};
+hipError_t launch_color16(const Color16Launch& L, int C, hipStream_t s);
 size_t color_rtab_bytes(int lut_size);
 size_t color_tables_floats();
 int color_build_bins(const float* thresholds, uint8_t* bins);

@@ -31,6 +31,7 @@ EXPORTS = (
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
     "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
     "gs360_png_unfilter", "gs360_event_sync", "gs360_stream_wait_event",
+    "gs360_color_plan16_create", "gs360_color_plan16_destroy", "gs360_color_apply_u16",
 )
 
 
@@ -118,6 +119,9 @@ def load_library(path=None):
         L.gs360_equirect_views_u16_host.argtypes = L.gs360_equirect_views_u8_host.argtypes
         L.gs360_remap_table_u16_host.argtypes = L.gs360_remap_table_u8_host.argtypes
         L.gs360_png_unfilter.argtypes = [vp, i, i, i]
+        L.gs360_color_plan16_create.argtypes = [vp, vp, i, vp, vp, i, vp, vp, vp, vp, pvp]
+        L.gs360_color_plan16_destroy.argtypes = [vp, vp]
+        L.gs360_color_apply_u16.argtypes = [vp, vp, vp, i, i, i, sz, i, vp, sz, i]
         L.gs360_event_sync.argtypes = [vp, i, i]
         L.gs360_stream_wait_event.argtypes = [vp, i, i, i]
         for name in EXPORTS:
@@ -356,6 +360,33 @@ class Context:
     def color_plan_free(self, plan):
         if plan:
             _check(self.L.gs360_color_plan_destroy(self.handle, plan), self.L)
+
+    def color_plan16(self, lut_table, domain_min, domain_max, n_pieces, start, base, off, thresholds):
+        """16-bit colour plan (include/gs360.h): LUT + domain + the piecewise output thresholds of gs360.color.output_pieces16."""
+        lut = np.ascontiguousarray(lut_table, dtype=np.float32)
+        if lut.ndim != 4 or lut.shape[3] != 3 or not (lut.shape[0] == lut.shape[1] == lut.shape[2]):
+            raise ValueError("lut_table must be [n][n][n][3]")
+        dmin = np.ascontiguousarray(domain_min, dtype=np.float32)
+        dmax = np.ascontiguousarray(domain_max, dtype=np.float32)
+        st = np.ascontiguousarray(start, dtype=np.float32)
+        ba = np.ascontiguousarray(base, dtype=np.int32)
+        of = np.ascontiguousarray(off, dtype=np.int32)
+        th = np.ascontiguousarray(thresholds, dtype=np.float32)
+        if dmin.shape != (3,) or dmax.shape != (3,) or st.size < 4 or ba.size < 4 or of.size < 5:
+            raise ValueError("bad colour plan tables")
+        h = C.c_void_p()
+        _check(self.L.gs360_color_plan16_create(self.handle, lut.ctypes.data, int(lut.shape[0]), dmin.ctypes.data, dmax.ctypes.data,
+                                                int(n_pieces), st.ctypes.data, ba.ctypes.data, of.ctypes.data,
+                                                th.ctypes.data if th.size else None, C.byref(h)), self.L)
+        return h
+
+    def color_plan16_free(self, plan):
+        if plan:
+            _check(self.L.gs360_color_plan16_destroy(self.handle, plan), self.L)
+
+    def color_apply16_dev(self, plan, src, H, W, Cn, dst=None, red_index=0, src_stride=0, dst_stride=0, slot=0):
+        _check(self.L.gs360_color_apply_u16(self.handle, plan, src.ptr, H, W, Cn, src_stride, red_index,
+                                            (dst or src).ptr, dst_stride, slot), self.L)
 
     def color_apply_dev(self, plan, src, H, W, Cn, dst=None, red_index=0, src_stride=0, dst_stride=0, slot=0):
         """Apply a colour plan to a device-resident H x W x C image (in place when dst is None)."""

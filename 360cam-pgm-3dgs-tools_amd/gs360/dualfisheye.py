@@ -129,10 +129,10 @@ class PairRenderer:
             try:
                 if color_stage is not None:
                     for k, v in imgs.items():
-                        color_stage.apply_dev(self.ctx, dev[k], v.shape, red_index=0, slot=0)   # arrays here are RGB(A)
+                        color_stage.apply_dev(self.ctx, dev[k], v.shape, red_index=0, slot=0, dtype=v.dtype)   # arrays here are RGB(A)
                 if want_color:
                     for k, v in imgs.items():
-                        out["color"][k] = self.ctx.download(dev[k], v.shape, slot=0) if color_stage is not None else v
+                        out["color"][k] = self.ctx.download(dev[k], v.shape, dtype=v.dtype, slot=0) if color_stage is not None else v
                 # borderValue=float(mask_value) -> cv::Scalar(v,0,0,0): only channel 0 gets v, and channel 0 of a
                 # cv2.imread image is BLUE.  Arrays here are RGB(A), so the value goes to index 2 for colour images.
                 C_in = imgs["X"].shape[2]

@@ -235,6 +235,23 @@ int gs360_remap_table_u16(gs360_ctx *ctx, const void *src, int H, int W, int C, 
                           int interp, const double *border_value, int fill_value,
                           void *dst, size_t dst_stride, int slot);
 
+/*
+ * The same stage for 16-bit images (DF:603-618 treat uint16 like uint8 with 65535 levels).  Nothing is tabulated on the
+ * input side (float01 conversion, domain mapping and all three interpolation stages run per pixel in the reference's
+ * float32 order).  Output side: n_pieces = 0 means `passthrough` = rint(clip(x) * 65535) in-kernel; otherwise the encode
+ * step (Rec.709 -> sRGB through NumPy's float32 power) arrives as thresholds in n_pieces <= 4 monotone pieces of clip(x):
+ * piece q covers [piece_start[q], piece_start[q+1]) (piece_start[0] is taken as 0), its thresholds are
+ * thresholds[piece_off[q] .. piece_off[q+1]) (sorted), and the level is piece_base[q] + the number of them <= clip(x).
+ * All pointers are HOST pointers, copied at plan creation.
+ */
+typedef struct gs360_color_plan16 gs360_color_plan16;
+int gs360_color_plan16_create(gs360_ctx *ctx, const float *lut, int lut_size, const float *domain_min, const float *domain_max,
+                              int n_pieces, const float *piece_start, const int32_t *piece_base, const int32_t *piece_off,
+                              const float *thresholds, gs360_color_plan16 **out);
+int gs360_color_plan16_destroy(gs360_ctx *ctx, gs360_color_plan16 *plan);
+int gs360_color_apply_u16(gs360_ctx *ctx, const gs360_color_plan16 *plan, const void *src, int H, int W, int C,
+                          size_t src_stride, int red_index, void *dst, size_t dst_stride, int slot);
+
 /* ---- host-buffer conveniences (synchronous: H2D -> kernel -> D2H on `slot`) ----------------- */
 int gs360_equirect_views_u8_host(gs360_ctx *ctx, const uint8_t *src, int W, int H, int C, size_t src_stride,
                                  const gs360_view *views, int n_views,

@@ -166,8 +166,31 @@ def test_stage_rejects_what_the_reference_rejects():
         color.ColorStage.check_image((4, 4), np.uint8)
     with pytest.raises(ValueError, match="at least 3-channel"):
         color.ColorStage.check_image((4, 4, 1), np.uint8)
+    color.ColorStage.check_image((4, 4, 3), np.uint16)            # 16-bit images are handled since round 2
     with pytest.raises(TypeError):
-        color.ColorStage.check_image((4, 4, 3), np.uint16)
+        color.ColorStage.check_image((4, 4, 3), np.float32)
+
+
+@pytest.mark.parametrize("space", ["srgb", "passthrough"])
+def test_output_pieces16_reproduce_the_encode_step(space):
+    """the 16-bit quantiser data handed to the kernel: piece selection + threshold count == NumPy's own encode, including
+    the non-monotone step across the Rec.709 knee (piece 2 starts BELOW the level piece 1 ends on)"""
+    n, start, base, off, thr = color.output_pieces16(space)
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.random(300000, dtype=np.float32), np.float32([-1.0, 0.0, 1.0, 2.0, 0.081, 0.0140886]),
+                        np.nextafter(np.float32(0.081), np.float32(0)).reshape(1)])
+    xc = np.clip(x, 0, 1)
+    if n == 0:
+        assert thr.size == 0
+        got = np.rint(xc * np.float32(65535.0)).astype(np.int64)
+    else:
+        assert n == 3 and off[3] == thr.size and base[2] < base[1] + (off[2] - off[1])
+        piece = (xc >= start[1]).astype(int) + (xc >= start[2]).astype(int)
+        got = np.empty(x.size, np.int64)
+        for q in range(3):
+            m = piece == q
+            got[m] = base[q] + np.searchsorted(thr[off[q]:off[q + 1]], xc[m], side="right")
+    assert np.array_equal(got, color.encode_levels16(x, space).astype(np.int64))
 
 
 # ---- GPU parity --------------------------------------------------------------------------------------------------
@@ -271,3 +294,33 @@ def test_gpu_plan_argument_checks(ctx):
         ctx.color_apply_dev(plan, buf, 2, 2, 1)
     ctx.free(buf)
     ctx.color_plan_free(plan)
+
+
+# ---- 16-bit images on the GPU -------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("lut,img,space", sorted(c for c in golden_cases() if c[1] == "u16"))
+def test_gpu_u16_matches_reference_vectors_and_oracle(ctx, lut, img, space):
+    table, dmin, dmax = lut_of(lut)
+    stage = color.ColorStage(color.CubeLUT(table.shape[0], table, dmin, dmax), space)
+    image = G[f"img_{img}"]
+    assert image.dtype == np.uint16
+    for red in (2, 0):
+        got = stage.apply(ctx, image, red_index=red)
+        want = color_np.color_pipeline(image, table, dmin, dmax, space, red_index=red)
+        assert got.dtype == np.uint16 and np.array_equal(got, want), (lut, space, red)
+        if red == 2:      # the reference's own output (NumPy power differs between hosts by one ulp -> one 16-bit level)
+            assert_levels_close(got, G[f"out_{lut}_{img}_{space}"], exact=(space == "passthrough" or same_power_as_golden_host()))
+    stage.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,space", [((37, 101, 3), "srgb"), ((5, 1023, 4), "srgb"), ((64, 256, 3), "passthrough"), ((1, 7, 4), "passthrough"),
+                                          ((400, 1600, 3), "srgb")])
+def test_gpu_u16_shapes_alpha_and_full_range(ctx, shape, space):
+    table, dmin, dmax = lut_of("dom9")
+    stage = color.ColorStage(color.CubeLUT(9, table, dmin, dmax), space)
+    image = np.random.default_rng(shape[1]).integers(0, 65536, shape, dtype=np.uint16)
+    image[0, :, 0] = np.linspace(0, 65535, shape[1]).astype(np.uint16)        # sweeps every piece of the quantiser
+    got = stage.apply(ctx, image, red_index=0)
+    assert np.array_equal(got, color_np.color_pipeline(image, table, dmin, dmax, space, red_index=0))
+    stage.close()

@@ -258,3 +258,39 @@ def test_pair_pipeline_16bit_sources_keep_their_depth(tmp_path, orc):
     got = imageio.read_image(d.resolve().with_name("shots_undistorted") / "frame_0000_Y.png")
     want = orc.valid_fill(orc.remap_u16(imgs["Y"], und.map_x, und.map_y, interp=2, border_value=(0, 0, 9, 0)), und.valid_mask, 9)
     assert got.dtype == np.uint16 and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_pair_pipeline_16bit_with_input_lut(tmp_path, orc):
+    """16-bit lens images through --input-lut (16-bit colour stage) and then the CV_16U samplers: colour first, resampling
+    second (DF:1938-1947), everything at native depth"""
+    from gs360 import color
+    from oracle import color_np
+    d = tmp_path / "shots"
+    d.mkdir()
+    rng = np.random.default_rng(16)
+    imgs = {}
+    for lens in "XY":
+        a = rng.integers(0, 65536, (240, 240, 3), dtype=np.uint16)
+        imageio.write_image(d / f"frame_0000_{lens}.png", a)
+        imgs[lens] = a
+    xml = tmp_path / "c.xml"
+    xml.write_text(SMALL_XML)
+    cube = tmp_path / "look.cube"
+    write_cube(cube)
+    r = run(["-i", str(d), "-x", str(xml), "--interpolation", "linear", "--perspective-size", "64", "--perspective-ext", "png",
+             "--input-lut", str(cube), "--lut-output-color-space", "srgb", "--save-color-corrected-output"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lut = color.load_cube_lut(cube)
+    conv = {k: color_np.color_pipeline(v, lut.table, lut.domain_min, lut.domain_max, "srgb", red_index=0) for k, v in imgs.items()}
+    for lens in "XY":
+        got = imageio.read_image(d.resolve().with_name("shots_colorcorrected") / f"frame_0000_{lens}.png")
+        assert got.dtype == np.uint16 and np.array_equal(got, conv[lens])
+    sensors, _ = fe.load_metashape_calibration(xml)
+    specs = fe.sfm10_specs(64, 14.0, "36 36", 40.0, 40.0)
+    tables = fe.choose_lens_tables(sensors, "0", "0", specs, 0.0, 180.0, 190.0)
+    for spec in specs:
+        t = tables[spec["view_id"]]
+        got = imageio.read_image(d.resolve().with_name("shots_perspective_colmap") / "Images" / f"frame_0000_{spec['view_id']}.png")
+        want = orc.valid_fill(orc.remap_u16(conv[t["lens_key"]], t["map_x"], t["map_y"], interp=1, border_value=0.0), t["valid"], 0)
+        assert np.array_equal(got, want), spec["view_id"]
