@@ -191,6 +191,81 @@ def fuzz_color(ctx, rng, case):
     return True
 
 
+def fuzz_u16(ctx, rng, case):
+    """16-bit samplers and colour stage: random shapes, strides are tight (host conveniences), all interpolations"""
+    from gs360 import color
+    from oracle import color_np
+    kind = int(rng.integers(0, 3))
+    c = int(rng.choice([1, 3, 3, 4]))
+    if kind == 0:        # equirect u16
+        W, H = int(rng.integers(8, 500)), int(rng.integers(2, 260))
+        src = rng.integers(0, 65536, (H, W, c), dtype=np.uint16)
+        specs = [(float(rng.uniform(-400, 400)), 0.0 if rng.random() < 0.4 else float(rng.uniform(-95, 95)), float(rng.uniform(5, 179)),
+                  float(rng.uniform(5, 179)), int(rng.integers(1, 160)), int(rng.integers(1, 100))) for _ in range(int(rng.integers(1, 4)))]
+        interp = int(rng.choice([1, 2]))
+        fish = rng.random() < 0.25
+        got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], interp=interp, flags=gs360.EQ_FISHEYE_OUT if fish else 0)
+        want = orc.equirect_views_u16(src, [orc.make_view(*s) for s in specs], interp=interp, fisheye=fish, threads=0)
+        ok = all(np.array_equal(g, w) for g, w in zip(got, want))
+        what = f"equirect src {W}x{H}x{c} interp={interp} fish={fish} views={specs}"
+    elif kind == 1:      # table remap u16
+        W, H, w, h = int(rng.integers(1, 260)), int(rng.integers(1, 160)), int(rng.integers(1, 200)), int(rng.integers(1, 80))
+        src = rng.integers(0, 65536, (H, W, c), dtype=np.uint16)
+        mx = rng.uniform(-8, W + 8, (h, w)).astype(np.float32)
+        my = rng.uniform(-8, H + 8, (h, w)).astype(np.float32)
+        if rng.random() < 0.4:
+            mx = (rng.integers(-64, 32 * W + 64, (h, w)) / 32.0 + rng.choice([0.0, 1 / 64.0], (h, w))).astype(np.float32)
+        sel = rng.random((h, w))
+        mx[sel < 0.02] = np.nan
+        my[(sel > 0.02) & (sel < 0.04)] = np.inf
+        interp = int(rng.choice([0, 1, 2, 4]))
+        bv = tuple(float(v) for v in rng.integers(0, 70000, 4))
+        valid = (rng.random((h, w)) > 0.2) if rng.random() < 0.5 else None
+        fill = int(rng.integers(0, 65536))
+        got = ctx.remap(src, mx, my, interpolation=interp, border_value=bv, valid=valid, fill_value=fill)
+        want = orc.remap_u16(src, mx, my, interp=interp, border_value=bv, threads=0)
+        if valid is not None:
+            want = orc.valid_fill(want.copy(), valid, fill)
+        ok = np.array_equal(got.reshape(want.shape), want)
+        what = f"table src {W}x{H}x{c} map {w}x{h} interp={interp}"
+    else:                # colour stage u16
+        n = int(rng.integers(2, 20))
+        g = np.linspace(0, 1, n, dtype=np.float32)
+        bb, gg, rr = np.meshgrid(g, g, g, indexing="ij")
+        table = np.stack([rr ** np.float32(rng.uniform(0.4, 2.0)), gg * np.float32(0.8) + bb * np.float32(0.2),
+                          bb ** np.float32(rng.uniform(0.4, 2.0))], -1).astype(np.float32)
+        if rng.random() < 0.3:
+            table = (rng.random((n, n, n, 3), dtype=np.float32) * np.float32(1.3) - np.float32(0.15)).astype(np.float32)
+        dmin = np.float32(rng.uniform(0, 0.2, 3)) if rng.random() < 0.4 else np.zeros(3, np.float32)
+        dmax = np.float32(rng.uniform(0.7, 1.0, 3)) if rng.random() < 0.4 else np.ones(3, np.float32)
+        space = str(rng.choice(["srgb", "passthrough"]))
+        cc = int(rng.choice([3, 4]))
+        img = rng.integers(0, 65536, (int(rng.integers(1, 60)), int(rng.integers(1, 200)), cc), dtype=np.uint16)
+        red = int(rng.choice([0, 2]))
+        stage = _stage16(n, table, dmin, dmax, space)
+        got = stage.apply(ctx, img, red_index=red)
+        stage.close()
+        want = color_np.color_pipeline(img, table, dmin, dmax, space, red_index=red)
+        ok = np.array_equal(got, want)
+        what = f"colour lut {n}^3 {space} img {img.shape} red={red}"
+    if not ok:
+        print(f"[u16] case {case}: {what}: differs from the oracle")
+    return ok
+
+
+_PIECES16 = {}
+
+
+def _stage16(n, table, dmin, dmax, space):
+    """ColorStage whose 16-bit output tables (a pure function of the colour space) are computed once per run"""
+    from gs360 import color
+    stage = color.ColorStage(color.CubeLUT(n, table, dmin, dmax), space)
+    if space not in _PIECES16:
+        _PIECES16[space] = color.output_pieces16(space)
+    stage._pieces16 = _PIECES16[space]
+    return stage
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -198,11 +273,11 @@ def main():
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=2)
     t0 = time.time()
-    counts = {"equirect": 0, "table": 0, "fisheye": 0, "color": 0}
-    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye, "color": fuzz_color}
+    counts = {"equirect": 0, "table": 0, "fisheye": 0, "color": 0, "u16": 0}
+    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye, "color": fuzz_color, "u16": fuzz_u16}
     case, failures = 0, 0
     while time.time() - t0 < args.seconds and failures < 5:
-        name = ("equirect", "table", "fisheye", "color")[case % 4]
+        name = ("equirect", "table", "fisheye", "color", "u16")[case % 5]
         rng = np.random.default_rng([args.seed, case])
         if not fns[name](ctx, rng, f"{args.seed}:{case}"):
             failures += 1
