@@ -103,6 +103,40 @@ __global__ __launch_bounds__(64 * kWaves) void eq_views_u16_kernel(const EqLaunc
                 cols[kx] = xx < 0 ? xx + W : (xx >= W ? xx - W : xx);
             }
             int64_t acc[4] = {0, 0, 0, 0};
+            if constexpr (C == 3) {
+                // the four RGB taps of a window row are 24 contiguous bytes: seven dwords from the dword boundary below them
+                // (dwordx4 + dwordx3) shifted into place, instead of twelve 2-byte loads per row
+                if (ix >= 1 && ix + 4 <= W && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)L.src_stride) & 3) == 0) {
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky) {
+                        const uint16_t* p = src + (size_t)min(max(iy - 1 + ky, 0), H - 1) * ss + (size_t)(ix - 1) * 3;
+                        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;        // 0 or 2
+                        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const uint8_t*>(p) - o, 4));
+                        uint32_t r[7];
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) r[t] = q[t];
+                        uint32_t d[6];
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(r[t + 1], r[t], o);
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            const int w = wt[ky * 4 + kx];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const int e = kx * 3 + c;                                      // sample index within the row's 12
+                                const int v = (int)((e & 1) ? (d[e >> 1] >> 16) : (d[e >> 1] & 0xffffu));
+                                acc[c] += (int64_t)(v * w);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int64_t v = (acc[c] + (1 << 14)) >> 15;
+                        out[c] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int ky = 0; ky < 4; ++ky) {
                 const uint16_t* row = src + (size_t)min(max(iy - 1 + ky, 0), H - 1) * ss;
