@@ -114,6 +114,18 @@ def cpu_baseline(np, frame, budget_s=10.0):
                             "unit": "MPix/s", "sample": "3 passes at every host thread"}}, outs
 
 
+_JSON_FD = None     # set when stdout had to be parked on stderr (torch.distributed runs): the one JSON line goes here
+
+
+def emit(line: dict) -> None:
+    text = json.dumps(line) + "\n"
+    if _JSON_FD is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, text.encode())
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -194,7 +206,7 @@ def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
                        "pcie_bound_frames_per_s_per_gpu": round(63e9 / max(in_b, out_b), 1)},
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(line))
+        emit(line)
 
 
 def main():
@@ -251,23 +263,20 @@ def main():
                   "--backend gloo lets ranks share devices for control-flow tests", file=sys.stderr)
             sys.exit(3)
         torch.cuda.set_device(local_rank)
-        # RCCL prints a version banner on stdout when the first communicator comes up; stdout must carry exactly one
-        # JSON line, so fd 1 points at stderr while the group is created and warmed up.
+        # RCCL prints banner lines on stdout ("Librccl path : ...", version) whenever a communicator comes up -- at init,
+        # lazily at the first collective, sometimes at teardown.  stdout must carry exactly ONE JSON line, so fd 1 points at
+        # stderr for the rest of the process and the JSON line is written to the saved descriptor (emit()).
         sys.stdout.flush()
-        saved_stdout = os.dup(1)
+        global _JSON_FD
+        _JSON_FD = os.dup(1)
         os.dup2(2, 1)
-        try:
-            if args.backend == "nccl":
-                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+        torch.cuda.synchronize()
 
     import numpy as np
     import gs360
@@ -370,7 +379,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        emit(line)
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
