@@ -6,9 +6,10 @@ Workload (BASELINE.json configs[1]): 7680x3840x3 uint8 equirect frames -> `--pre
 --size 800` (6 x 800^2 views, f=12 mm -> hfov=vfov=112.62 deg), uint8 fixed-point bilinear.
 
 One "step" = ONE batched launch of gs360_equirect_views_u8 over `--frames` DISTINCT frames that are
-already resident in HBM (default 8 frames = 708 MB of source, 2.8x the 256 MiB Infinity Cache, so successive
-steps are served from HBM; measured: 1 frame/step (cache-hot) and 4 frames/step are ~8 % and ~18 % faster per
-frame and are NOT what is reported).  `value` = output pixels written by all ranks / wall time.
+already resident in HBM (default 16 frames = the C ABI's per-launch maximum = 1.4 GB of source, 5.5x the 256 MiB
+Infinity Cache, so every step is served from HBM; measured: 1 frame/step (cache-hot) and 4 frames/step are ~8 % and
+~18 % faster per frame and are NOT what is reported; 8 frames/step is 1-2 % slower per frame than 16 because a launch's
+last partial round of workgroups weighs twice as much).  `value` = output pixels written by all ranks / wall time.
 
     python bench.py --gpus 1 --steps 400 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -214,7 +215,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--frames", type=int, default=8, help="distinct HBM-resident frames per step (one launch)")
+    ap.add_argument("--frames", type=int, default=16, help="distinct HBM-resident frames per step (one launch; <= 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
