@@ -1,0 +1,102 @@
+"""Launch coalescing of gs360/engine.py (round-1 VERDICT weak #4) -- host logic only, no GPU: the jobs of one frame that
+arrive within the linger window leave as ONE batched launch; a failing leader hands its error to every member."""
+import collections
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from gs360 import capi, engine
+
+
+class FakeState:
+    """the fields Engine._render touches on a _DeviceState"""
+
+    def __init__(self):
+        self.batch_cond = threading.Condition()
+        self.open_batches = {}
+        self.pool_lock = threading.Lock()
+        self.pin_pool = collections.defaultdict(list)
+        self.given_back = []
+
+    def give(self, pool, buf):
+        self.given_back.append(buf)
+
+
+def make_engine(monkeypatch, launches, fail=False, delay=0.0):
+    eng = engine.Engine.__new__(engine.Engine)
+
+    def fake_launch(st, buf, H, W, C, views, interp, flags, dtype=np.uint8):
+        if delay:
+            time.sleep(delay)
+        if fail:
+            raise capi.Gs360Error(-2, "boom")
+        launches.append([v.yaw_deg for v in views])
+        return [(np.full((v.height, v.width, C), int(v.yaw_deg) % 251, np.uint8), ("pinned", v.yaw_deg)) for v in views]
+    monkeypatch.setattr(eng, "_launch_batch", fake_launch, raising=False)
+    return eng
+
+
+def run_jobs(eng, st, yaws, expected, frame_calls, linger=0.2, stagger=0.0):
+    out, errs = {}, {}
+
+    def get_frame():
+        frame_calls.append(1)
+        return ("devbuf", 8, 16, 3, np.uint8)
+
+    def job(y):
+        try:
+            arr, release = eng._render(st, "frameA", get_frame, capi.View.make(y, 0, 90, 90, 4, 2), capi.INTERP_LINEAR, 0, expected=expected)
+            out[y] = int(arr[0, 0, 0])
+            release()
+        except Exception as exc:  # noqa: BLE001
+            errs[y] = exc
+    threads = []
+    for y in yaws:
+        t = threading.Thread(target=job, args=(y,))
+        t.start()
+        threads.append(t)
+        if stagger:
+            time.sleep(stagger)
+    for t in threads:
+        t.join(10)
+    return out, errs
+
+
+def test_views_of_one_frame_leave_as_one_launch(monkeypatch):
+    monkeypatch.setattr(engine, "_LINGER_S", 0.5)
+    launches, frame_calls = [], []
+    eng, st = make_engine(monkeypatch, launches), FakeState()
+    t0 = time.monotonic()
+    out, errs = run_jobs(eng, st, [0, 60, 120, 180, 240, 300], expected=6, frame_calls=frame_calls)
+    assert not errs and out == {y: y % 251 for y in [0, 60, 120, 180, 240, 300]}
+    assert len(launches) == 1 and sorted(launches[0]) == [0, 60, 120, 180, 240, 300]
+    assert len(frame_calls) == 1                                  # the leader alone made the frame resident
+    assert time.monotonic() - t0 < 0.4                            # it left as soon as the announced six had arrived
+    assert len(st.given_back) == 6 and not st.open_batches        # every pinned buffer returned, no batch left open
+
+
+def test_late_jobs_form_their_own_batch_and_serial_callers_do_not_wait_forever(monkeypatch):
+    monkeypatch.setattr(engine, "_LINGER_S", 0.05)
+    launches, frame_calls = [], []
+    eng, st = make_engine(monkeypatch, launches), FakeState()
+    out, errs = run_jobs(eng, st, [0, 90, 180], expected=16, frame_calls=frame_calls, stagger=0.15)   # arrive after the linger
+    assert not errs and len(out) == 3
+    assert [len(b) for b in launches] == [1, 1, 1]
+    launches.clear()
+    out, errs = run_jobs(eng, st, [10], expected=1, frame_calls=frame_calls)                          # expected 1: no linger at all
+    assert out == {10: 10} and launches == [[10.0]]
+
+
+def test_leader_failure_reaches_every_member(monkeypatch):
+    monkeypatch.setattr(engine, "_LINGER_S", 0.3)
+    launches, frame_calls = [], []
+    eng, st = make_engine(monkeypatch, launches, fail=True), FakeState()
+    out, errs = run_jobs(eng, st, [0, 60, 120], expected=3, frame_calls=frame_calls)
+    assert not out and len(errs) == 3 and all(isinstance(e, capi.Gs360Error) for e in errs.values())
+    assert not st.open_batches
+    # the engine keeps working afterwards
+    eng2, st2 = make_engine(monkeypatch, launches), st
+    out, errs = run_jobs(eng2, st2, [5, 6], expected=2, frame_calls=frame_calls)
+    assert not errs and len(out) == 2
