@@ -202,6 +202,58 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
         const float* cy = tab + fy * ks;
         const float* cx = tab + fx * ks;
         const bool inside = x0 >= 0 && x0 + ks <= W && y0 >= 0 && y0 + ks <= H;
+        if constexpr (C == 3) {
+            // windows inside the image, RGB: the ks taps of a window row are 6 ks contiguous bytes -> dword-aligned wide reads
+            // shifted into place (2-byte loads otherwise); the float32 accumulation order is the one spelled out in the header
+            if (inside && interp != GS360_INTERP_LANCZOS4 && x0 + ks + 2 <= W &&
+                ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)T.src_stride) & 3) == 0) {
+                float sum[3] = {0.f, 0.f, 0.f};
+                if (interp == GS360_INTERP_LINEAR) {
+                    float v[2][6];
+#pragma unroll
+                    for (int ky = 0; ky < 2; ++ky) {
+                        const uint16_t* pp = src + (size_t)(y0 + ky) * ss + (size_t)x0 * 3;
+                        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(pp) & 3u;
+                        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const uint8_t*>(pp) - o, 4));
+                        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                        const uint32_t d0 = __builtin_amdgcn_alignbyte(q1, q0, o), d1 = __builtin_amdgcn_alignbyte(q2, q1, o),
+                                       d2 = __builtin_amdgcn_alignbyte(q3, q2, o);
+                        v[ky][0] = (float)(d0 & 0xffffu); v[ky][1] = (float)(d0 >> 16); v[ky][2] = (float)(d1 & 0xffffu);
+                        v[ky][3] = (float)(d1 >> 16); v[ky][4] = (float)(d2 & 0xffffu); v[ky][5] = (float)(d2 >> 16);
+                    }
+                    const float w00 = cy[0] * cx[0], w01 = cy[0] * cx[1], w10 = cy[1] * cx[0], w11 = cy[1] * cx[1];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) sum[c] = v[0][c] * w00 + v[0][3 + c] * w01 + v[1][c] * w10 + v[1][3 + c] * w11;
+                } else {
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky) {
+                        const uint16_t* pp = src + (size_t)(y0 + ky) * ss + (size_t)x0 * 3;
+                        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(pp) & 3u;
+                        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const uint8_t*>(pp) - o, 4));
+                        uint32_t r[7], d[6];
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) r[t] = q[t];
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(r[t + 1], r[t], o);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float rs = 0.f;
+#pragma unroll
+                            for (int kx = 0; kx < 4; ++kx) {
+                                const int e = kx * 3 + c;
+                                const float v = (float)((e & 1) ? (d[e >> 1] >> 16) : (d[e >> 1] & 0xffffu));
+                                const float term = v * (cy[ky] * cx[kx]);
+                                rs = kx == 0 ? term : rs + term;
+                            }
+                            sum[c] = ky == 0 ? rs : sum[c] + rs;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) out[c] = sat_u16(sum[c]);
+                continue;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float sum;
