@@ -814,6 +814,37 @@ __device__ __forceinline__ void cv_sample_lanczos4(const uint8_t* __restrict__ s
     int x0 = sat_s16(sx >> 5) - 3, y0 = sat_s16(sy >> 5) - 3;
     bool outside = x0 >= W || x0 + 8 <= 0 || y0 >= H || y0 + 8 <= 0;
     const uint4* wq = reinterpret_cast<const uint4*>(tab + (fy * 32 + fx) * 64);
+    if constexpr (C == 3) {
+        // window inside the image (and its aligned 28-byte row reads inside the row): the 8 RGB taps of a window row are 24
+        // contiguous bytes -> seven dwords from the dword boundary below them, shifted into place; two taps x two packed
+        // int16 weights per v_dot2 (12 per row) instead of 24 byte loads and 24 multiply-adds per row.  Exact integers.
+        if (x0 >= 0 && y0 >= 0 && x0 + 10 <= W && y0 + 8 <= H && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0) {
+            int a3[3] = {0, 0, 0};
+#pragma unroll
+            for (int ky = 0; ky < 8; ++ky) {
+                const uint4 wr = wq[ky];
+                const uint32_t wpk[4] = {wr.x, wr.y, wr.z, wr.w};
+                const uint8_t* p = src + (int64_t)(y0 + ky) * stride + (int64_t)x0 * 3;
+                const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
+                uint32_t r[7], d[6];
+#pragma unroll
+                for (int t = 0; t < 7; ++t) r[t] = q[t];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(r[t + 1], r[t], o);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int p0 = 6 * m + c, p1 = p0 + 3;            // bytes of taps 2m and 2m+1, channel c
+                        a3[c] = dot2_i16(__builtin_amdgcn_perm(d[p1 >> 2], d[p0 >> 2], GS360_PAIR(p0 & 3, 4 + (p1 & 3))), wpk[m], a3[c]);
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((a3[c] + (1 << 14)) >> 15, 0), 255);
+            return;
+        }
+    }
     int acc[4] = {0, 0, 0, 0};
 #pragma unroll 2
     for (int ky = 0; ky < 8; ++ky) {
