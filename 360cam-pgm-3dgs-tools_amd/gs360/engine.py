@@ -287,8 +287,9 @@ class Engine:
         with self._announce_lock:
             return self._expected.get(str(src), capi.MAX_VIEWS)
 
-    def run_job(self, job: JobSpec, stop_event=None):
-        """Execute one (frame, view) job; returns the output array after writing job.dst."""
+    def run_job(self, job: JobSpec, stop_event=None, want_array: bool = False):
+        """Execute one (frame, view) job: render (coalesced with the frame's other views) and write job.dst.  Returns a copy
+        of the view when want_array is set (the result itself lives in pooled pinned memory), else None."""
         view, flags = self._view_for(job)
         interp = self._interp_for(job)
         st = self.states[self.device_for(job.src)]
@@ -306,7 +307,7 @@ class Engine:
                 self.release_frame(st, entry)
         try:
             imageio.write_image(job.dst, arr, jpeg_q=job.jpeg_q)
-            return np.array(arr)
+            return np.array(arr) if want_array else None
         finally:
             release()
 

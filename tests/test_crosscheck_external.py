@@ -58,6 +58,32 @@ def test_hip_remap_equals_cv2(ctx, channels, interp):
     assert np.array_equal(got.reshape(want.shape), want), f"HIP != cv2.remap (C={channels}, interp={interp}, cv2 {cv2.__version__})"
 
 
+@pytest.mark.parametrize("channels", [1, 3, 4])
+@pytest.mark.parametrize("interp", INTERPS)
+def test_oracle_remap_u16_equals_cv2(orc, channels, interp):
+    """CV_16U: OpenCV's float-weight samplers (the accumulation order is the part restated from memory)"""
+    cv2 = pytest.importorskip("cv2")
+    H, W, h, w = 97, 131, 75, 108
+    src = np.random.default_rng(24).integers(0, 65536, (H, W, channels), dtype=np.uint16)
+    mx, my = _maps(h, w, H, W, 22)
+    bv = (40000.0, 123.0, 0.0, 70000.0)
+    want = cv2.remap(src, mx, my, interpolation=interp, borderMode=cv2.BORDER_CONSTANT, borderValue=bv)
+    got = orc.remap_u16(src, mx, my, interp=interp, border_value=bv)
+    assert np.array_equal(got.reshape(want.shape), want), f"oracle != cv2.remap CV_16U (C={channels}, interp={interp}, cv2 {cv2.__version__})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", INTERPS)
+def test_hip_remap_u16_equals_cv2(ctx, interp):
+    cv2 = pytest.importorskip("cv2")
+    H, W, h, w = 97, 131, 75, 108
+    src = np.random.default_rng(25).integers(0, 65536, (H, W, 3), dtype=np.uint16)
+    mx, my = _maps(h, w, H, W, 22)
+    want = cv2.remap(src, mx, my, interpolation=interp, borderMode=cv2.BORDER_CONSTANT, borderValue=float(9))
+    got = ctx.remap(src, mx, my, interpolation=interp, border_value=9.0)
+    assert np.array_equal(got, want), f"HIP != cv2.remap CV_16U (interp={interp}, cv2 {cv2.__version__})"
+
+
 def _smooth_pano(H, W):
     x = np.arange(W, dtype=np.float64)[None, :] / W
     y = np.arange(H, dtype=np.float64)[:, None] / H
