@@ -65,7 +65,7 @@ def run_jobs(eng, st, yaws, expected, frame_calls, linger=0.2, stagger=0.0):
 
 
 def test_views_of_one_frame_leave_as_one_launch(monkeypatch):
-    monkeypatch.setattr(engine, "_LINGER_S", 0.5)
+    monkeypatch.setattr(engine, "_LINGER_S", 3.0)
     launches, frame_calls = [], []
     eng, st = make_engine(monkeypatch, launches), FakeState()
     t0 = time.monotonic()
@@ -73,7 +73,7 @@ def test_views_of_one_frame_leave_as_one_launch(monkeypatch):
     assert not errs and out == {y: y % 251 for y in [0, 60, 120, 180, 240, 300]}
     assert len(launches) == 1 and sorted(launches[0]) == [0, 60, 120, 180, 240, 300]
     assert len(frame_calls) == 1                                  # the leader alone made the frame resident
-    assert time.monotonic() - t0 < 0.4                            # it left as soon as the announced six had arrived
+    assert time.monotonic() - t0 < 2.0                            # it left as soon as the announced six had arrived, not after 3 s
     assert len(st.given_back) == 6 and not st.open_batches        # every pinned buffer returned, no batch left open
 
 
