@@ -925,6 +925,72 @@ int gs360_png_unfilter(uint8_t* data, int h, int stride, int bpp) {
     return GS360_OK;
 }
 
+// TIFF LZW strip decoder (compression 5: MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, "early change").
+// Host helper like gs360_png_unfilter: 16-bit TIFF panoramas are commonly LZW-compressed and the Python-side codec cannot loop
+// over codes at image scale.  Writes at most out_cap bytes; *out_len receives the number produced.
+int gs360_tiff_lzw_decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, size_t* out_len) {
+    if (!in || !out || !out_len) return fail(GS360_ERR_ARG, "NULL argument");
+    struct Entry { uint32_t pos, len; };                 // every string is a slice of the output written so far
+    std::vector<Entry> tab(4096);
+    size_t op = 0, bitpos = 0;
+    int next = 258, width = 9;
+    int64_t prev = -1;
+    const size_t nbits = in_len * 8;
+    auto emit = [&](const uint8_t* srcp, uint32_t len) -> bool {
+        if (op + len > out_cap) len = (uint32_t)(out_cap - op);
+        for (uint32_t i = 0; i < len; ++i) out[op + i] = srcp[i];      // may overlap forwards: byte copy
+        op += len;
+        return op < out_cap;
+    };
+    while (bitpos + width <= nbits) {
+        uint32_t code = 0;
+        for (int b = 0; b < width; ++b) {
+            const size_t bp = bitpos + b;
+            code = (code << 1) | ((in[bp >> 3] >> (7 - (bp & 7))) & 1u);
+        }
+        bitpos += width;
+        if (code == 257) break;
+        if (code == 256) { next = 258; width = 9; prev = -1; continue; }
+        const uint32_t start = (uint32_t)op;
+        if (prev < 0) {                                   // first code after a clear: a literal
+            if (code > 255) return fail(GS360_ERR_ARG, "corrupt LZW stream (code %u after clear)", code);
+            const uint8_t lit = (uint8_t)code;
+            tab[code] = Entry{start, 1};
+            if (!emit(&lit, 1)) break;
+            prev = code;
+            continue;
+        }
+        const Entry pe = prev < 256 ? Entry{0, 1} : tab[prev];
+        uint8_t plit = (uint8_t)prev;
+        const uint8_t* pstr = prev < 256 ? &plit : out + pe.pos;
+        bool more;
+        if (code < 256) {
+            const uint8_t lit = (uint8_t)code;
+            more = emit(&lit, 1);
+        } else if ((int)code < next) {
+            const Entry e = tab[code];
+            more = emit(out + e.pos, e.len);
+        } else if ((int)code == next) {                  // KwKwK: previous string + its own first byte
+            const uint32_t plen = prev < 256 ? 1u : pe.len;
+            const uint8_t first = pstr[0];
+            more = emit(pstr, plen);
+            if (more) more = emit(&first, 1);
+        } else {
+            return fail(GS360_ERR_ARG, "corrupt LZW stream (code %u, table size %d)", code, next);
+        }
+        if (next < 4096) {                                // new entry = previous string + first byte of this one; it is
+            const uint32_t plen = prev < 256 ? 1u : pe.len;   // exactly the bytes [start - plen, start + 1) of the output
+            tab[next] = Entry{start - plen, plen + 1};
+            ++next;
+            if (next + 1 >= (1 << width) && width < 12) ++width;       // early change
+        }
+        prev = code;
+        if (!more) break;
+    }
+    *out_len = op;
+    return GS360_OK;
+}
+
 // ---- host-buffer conveniences ------------------------------------------------------------------
 namespace {
 int equirect_views_host_impl(gs360_ctx* c, const void* src, int W, int H, int C, size_t src_stride,

@@ -31,7 +31,7 @@ EXPORTS = (
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
     "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
     "gs360_png_unfilter", "gs360_event_sync", "gs360_stream_wait_event",
-    "gs360_color_plan16_create", "gs360_color_plan16_destroy", "gs360_color_apply_u16",
+    "gs360_color_plan16_create", "gs360_color_plan16_destroy", "gs360_color_apply_u16", "gs360_tiff_lzw_decode",
 )
 
 
@@ -119,6 +119,7 @@ def load_library(path=None):
         L.gs360_equirect_views_u16_host.argtypes = L.gs360_equirect_views_u8_host.argtypes
         L.gs360_remap_table_u16_host.argtypes = L.gs360_remap_table_u8_host.argtypes
         L.gs360_png_unfilter.argtypes = [vp, i, i, i]
+        L.gs360_tiff_lzw_decode.argtypes = [vp, sz, vp, sz, C.POINTER(C.c_size_t)]
         L.gs360_color_plan16_create.argtypes = [vp, vp, i, vp, vp, i, vp, vp, vp, vp, pvp]
         L.gs360_color_plan16_destroy.argtypes = [vp, vp]
         L.gs360_color_apply_u16.argtypes = [vp, vp, vp, i, i, i, sz, i, vp, sz, i]

@@ -6,8 +6,8 @@ for 16-bit sources, which the reference keeps at native depth (DF:735 cv2.imread
 
 8-bit files go through Pillow when it is importable (a self-contained 8-bit PNG codec keeps the tools usable without it).
 16-bit files never go through Pillow (it delivers 16-bit RGB as 8-bit): PNG is decoded here (zlib + the library's
-gs360_png_unfilter helper) and written with filter type 0; TIFF is read / written as baseline TIFF (uncompressed or
-Deflate, chunky, strips, predictor 1 or 2) -- anything else 16-bit raises ImageIOError rather than losing depth.
+gs360_png_unfilter helper) and written with filter type 0; TIFF is read / written as baseline TIFF (uncompressed,
+LZW or Deflate, chunky, strips, predictor 1 or 2) -- anything else 16-bit raises ImageIOError rather than losing depth.
 """
 import pathlib
 import struct
@@ -148,6 +148,22 @@ def _tiff_tags(data: bytes):
     return e, tags
 
 
+def _lzw_decode(blob: bytes, nbytes: int) -> bytes:
+    """TIFF LZW strip -> bytes through the library's host helper (no pure-Python fallback: it would take minutes per image)"""
+    import ctypes as C
+    try:
+        from . import capi
+        L = capi.load_library()
+    except Exception as exc:  # noqa: BLE001
+        raise ImageIOError(f"LZW-compressed 16-bit TIFF needs libgs360hip.so ({exc})") from exc
+    src = np.frombuffer(blob, np.uint8)
+    out = np.empty(nbytes, np.uint8)
+    n = C.c_size_t(0)
+    if L.gs360_tiff_lzw_decode(src.ctypes.data, src.size, out.ctypes.data, out.size, C.byref(n)) != 0 or n.value != nbytes:
+        raise ImageIOError("corrupt or truncated LZW strip")
+    return out.tobytes()
+
+
 def _tiff_read16(data: bytes) -> np.ndarray:
     e, t = _tiff_tags(data)
     w, h = t[256][0], t[257][0]
@@ -159,8 +175,8 @@ def _tiff_read16(data: bytes) -> np.ndarray:
     fmt = t.get(339, (1,))[0]
     if any(b != 16 for b in bits) or spp not in (1, 3, 4) or planar != 1 or fmt != 1:
         raise ImageIOError("16-bit TIFF reader handles chunky unsigned 16-bit gray / RGB / RGBA only")
-    if comp not in (1, 8, 32946):
-        raise ImageIOError(f"16-bit TIFF with compression {comp} is not supported (use none or Deflate); refusing to reduce it to 8 bits")
+    if comp not in (1, 5, 8, 32946):
+        raise ImageIOError(f"16-bit TIFF with compression {comp} is not supported (use none, LZW or Deflate); refusing to reduce it to 8 bits")
     if 324 in t:
         raise ImageIOError("tiled 16-bit TIFF is not supported")
     offs, cnts = t[273], t[279]
@@ -169,9 +185,11 @@ def _tiff_read16(data: bytes) -> np.ndarray:
     y = 0
     for o, c in zip(offs, cnts):
         blob = data[o:o + c]
-        if comp != 1:
-            blob = zlib.decompress(blob)
         rows = min(rps, h - y)
+        if comp == 5:
+            blob = _lzw_decode(blob, rows * w * spp * 2)
+        elif comp != 1:
+            blob = zlib.decompress(blob)
         a = np.frombuffer(blob, dtype=e + "u2", count=rows * w * spp).astype(np.uint16).reshape(rows, w * spp)
         if pred == 2:                        # horizontal differencing per sample
             a = np.cumsum(a.reshape(rows, w, spp).astype(np.uint32), axis=1).astype(np.uint16).reshape(rows, w * spp)

@@ -273,6 +273,8 @@ int gs360_remap_table_u16_host(gs360_ctx *ctx, const uint16_t *src, int H, int W
  * In-place PNG scanline reconstruction (filter types 0-4) of h rows of (1 + stride) inflated bytes; bpp = bytes per
  * complete pixel.  Used by the package's own 16-bit PNG reader; image codecs are outside the measured path. */
 int gs360_png_unfilter(uint8_t *data, int h, int stride, int bpp);
+/* TIFF LZW (compression 5) strip decoder for the package's 16-bit TIFF reader: at most out_cap bytes are produced. */
+int gs360_tiff_lzw_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len);
 
 #ifdef __cplusplus
 }

@@ -79,12 +79,74 @@ def test_16bit_files_are_never_reduced_silently(tmp_path):
     assert np.array_equal(imageio.read_image(tmp_path / "g.png")[:, :, 0], g)
     Image.fromarray(g).save(tmp_path / "d.tif", compression="tiff_adobe_deflate")
     assert np.array_equal(imageio.read_image(tmp_path / "d.tif")[:, :, 0], g)
-    Image.fromarray(g).save(tmp_path / "l.tif", compression="tiff_lzw")
+    Image.fromarray(g).save(tmp_path / "l.tif", compression="tiff_lzw")          # LZW through the library's host helper
+    assert np.array_equal(imageio.read_image(tmp_path / "l.tif")[:, :, 0], g)
+    runs = np.zeros((130, 517), np.uint16)
+    runs[40:50] = 777                                                              # long runs: the KwKwK case of LZW
+    Image.fromarray(runs).save(tmp_path / "r.tif", compression="tiff_lzw")
+    assert np.array_equal(imageio.read_image(tmp_path / "r.tif")[:, :, 0], runs)
+    Image.fromarray(g).save(tmp_path / "p.tif", compression="packbits")
     with pytest.raises(imageio.ImageIOError) as e:
-        imageio.read_image(tmp_path / "l.tif")
+        imageio.read_image(tmp_path / "p.tif")
     assert "not supported" in str(e.value)
     # JPEG is an 8-bit container: 16-bit data is scaled, not truncated
     rgb = rand16(16, 16, 3)
     assert np.array_equal(imageio.to_uint8(np.array([[[0, 32768, 65535]]], np.uint16))[0, 0], [0, 128, 255])
     imageio.write_image(tmp_path / "j.jpg", rgb, jpeg_q=1)
     assert imageio.read_image(tmp_path / "j.jpg").dtype == np.uint8
+
+
+def _craft_tiff(arr, big_endian, predictor, rows_per_strip, deflate):
+    """baseline TIFF writer of the test: chunky 16-bit, several strips, optional horizontal predictor / Deflate, either byte order"""
+    h, w, ch = arr.shape
+    e = ">" if big_endian else "<"
+    strips = []
+    for y in range(0, h, rows_per_strip):
+        a = arr[y:y + rows_per_strip].astype(np.uint32)
+        if predictor == 2:
+            d = a.copy()
+            d[:, 1:] = (a[:, 1:] - a[:, :-1]) & 0xFFFF
+            a = d
+        raw = a.astype(e + "u2").tobytes()
+        strips.append(zlib.compress(raw) if deflate else raw)
+    n_s = len(strips)
+    entries = [(256, 4, [w]), (257, 4, [h]), (258, 3, [16] * ch), (259, 3, [8 if deflate else 1]), (262, 3, [2 if ch >= 3 else 1]),
+               (273, 4, None), (277, 3, [ch]), (278, 4, [rows_per_strip]), (279, 4, [len(s_) for s_ in strips]), (284, 3, [1]),
+               (317, 3, [predictor])]
+    if ch == 4:
+        entries.append((338, 3, [2]))
+    entries.sort()
+    ifd_off = 8
+    extra_off = ifd_off + 2 + 12 * len(entries) + 4
+    # strip offsets are known once the extra area is sized: lay out extras first with placeholder offsets
+    fmt = {3: "H", 4: "I"}
+
+    def pack(vals, typ):
+        return struct.pack(e + fmt[typ] * len(vals), *vals)
+    sizes = sum(len(pack(v if v is not None else [0] * n_s, t)) for _tag, t, v in entries if len(pack(v if v is not None else [0] * n_s, t)) > 4)
+    data_off = extra_off + sizes + (sizes & 1)
+    offs, pos = [], data_off
+    for s_ in strips:
+        offs.append(pos)
+        pos += len(s_)
+    extra, recs = b"", []
+    for tag, typ, vals in entries:
+        vals = offs if vals is None else vals
+        blob = pack(vals, typ)
+        if len(blob) <= 4:
+            recs.append(struct.pack(e + "HHI", tag, typ, len(vals)) + blob.ljust(4, b"\0"))
+        else:
+            recs.append(struct.pack(e + "HHII", tag, typ, len(vals), extra_off + len(extra)))
+            extra += blob
+    extra += b"\0" * (data_off - extra_off - len(extra))
+    return (b"MM" if big_endian else b"II") + struct.pack(e + "HI", 42, ifd_off) + struct.pack(e + "H", len(entries)) + \
+        b"".join(recs) + struct.pack(e + "I", 0) + extra + b"".join(strips)
+
+
+@pytest.mark.parametrize("big_endian,predictor,deflate", [(True, 1, False), (False, 2, False), (True, 2, True), (False, 1, True)])
+@pytest.mark.parametrize("channels", [1, 3, 4])
+def test_tiff16_byte_orders_predictor_strips(tmp_path, big_endian, predictor, deflate, channels):
+    a = rand16(23, 31, channels, seed=7)
+    (tmp_path / "t.tif").write_bytes(_craft_tiff(a, big_endian, predictor, 5, deflate))
+    b = imageio.read_image(tmp_path / "t.tif")
+    assert b.dtype == np.uint16 and np.array_equal(a, b)
