@@ -6,8 +6,9 @@
           absent ffmpeg binary as the PPM-pipe decoder) -> `--preset full360coverage` (12 x 1600^2 per frame)
 
 and reports frames/s, views/s, how the wall time splits into image decode / GPU / image encode (thread-summed), the
-number of batched launches the engine issued (gs360/engine.py coalesces the view jobs of a frame) and the share of the
-wall time during which a launch+copy section held a stream ("gpu_busy_share").  Informational: the image codecs run on
+number of batched launches the engine issued (gs360/engine.py coalesces the view jobs of a frame) and "gpu_busy_share" =
+thread-summed wall time spent inside launch + copy + sync sections (waiting for a free stream slot included) / wall time
+-- an UPPER bound of the share of time the GPU is busy (with many workers the sections of different frames overlap).  Informational: the image codecs run on
 the host and bound both figures; bench.py's `value` is the device-resident hot path.
 
     python scripts/bench_cli_e2e.py [--frames 6] [--video-frames 8] [--jobs 16] [--ext jpg] [--only stills|video]
