@@ -451,6 +451,27 @@ int gs360_stream_wait_event(gs360_ctx* c, int waiting_slot, int event_slot, int 
     return GS360_OK;
 }
 
+// Self-test: the kernels replace `/` and sqrtf by shorter instruction sequences that are bit-identical on the operand domains
+// of EQ-SPEC / FE-SPEC (gs360_eqspec.h).  This runs both forms on `n_millions` x 10^6 pseudo-random operand sets per form.
+int gs360_selftest_arith(gs360_ctx* c, uint32_t seed, int n_millions, uint64_t* n_checked, uint64_t* n_mismatch) {
+    if (int rc = check_ctx_slot(c, 0)) return rc;
+    if (!n_checked || !n_mismatch || n_millions < 1 || n_millions > 100000) return fail(GS360_ERR_ARG, "bad self-test arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* d_bad = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), c->stream[0]);
+    const int iters = 1000, blocks = (int)(((long long)n_millions * 1000000 + 256LL * iters - 1) / (256LL * iters));
+    if (e == hipSuccess) e = launch_arith_selftest(seed, blocks, iters, d_bad, c->stream[0]);
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream[0]);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(GS360_ERR_HIP, "arithmetic self-test failed to run: %s", hipGetErrorString(e));
+    *n_checked = (uint64_t)blocks * 256ull * (uint64_t)iters;
+    *n_mismatch = bad;
+    return GS360_OK;
+}
+
 // ---- equirect -> views -------------------------------------------------------------------------
 namespace {
 int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void* const* mask_frames, int n_frames,

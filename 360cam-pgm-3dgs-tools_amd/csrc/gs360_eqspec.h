@@ -16,13 +16,17 @@ namespace gs360 {
 #define EQ_C4 (0.10597943514585495f)
 #define EQ_C5 (-0.06087981536984444f)
 
-// n / d, correctly rounded, for EQ-SPEC's operands: 0 <= |n| <= d (or d = 1 with n = 0), d a NORMAL float in
-// [2^-100, 2^100] and the quotient zero or normal.  This is the IEEE sequence the compiler emits for `n / d`
+// n / d, correctly rounded, for EQ-SPEC's operands: d a NORMAL float in [2^-100, 2^100]; n = 0 or 2^-103 <= |n| <= 2 d; the
+// quotient zero or normal.  This is the IEEE sequence the compiler emits for `n / d`
 // (v_div_scale x2, v_rcp, Newton step on the reciprocal, quotient + two residual corrections, v_div_fmas, v_div_fixup) with
 // the three instructions that are the identity on this domain removed: v_div_scale only rescales when an operand, the
-// reciprocal or the quotient is denormal or the exponents differ by >= 96, and v_div_fixup only patches NaN / inf / zero
-// divisors.  In EQ-SPEC d is max(|a|, |b|) or a sum of two magnitudes of ray components (>= 6e-29 even for the
-// centre pixel of a pole view), the divisor-zero case is replaced by d = 1 before the call, and |n| <= d.
+// reciprocal or the quotient is denormal, the numerator is below 2^-103 or the exponents differ by >= 96, and v_div_fixup only
+// patches NaN / inf / zero divisors.  In EQ-SPEC d is max(|a|, |b|) or a sum of two magnitudes of ray components (>= 6e-29
+// even for the centre pixel of a pole view), the divisor-zero case is replaced by d = 1 before the call, and a NON-ZERO
+// numerator is a ray component or a difference of two: pixel coordinates are >= 2.7e-10 or exactly 0, a cancelling
+// fma(sin p, yv, cos p) is a multiple of 2^-47 |cos p| with |cos p| >= 2^-32 whenever yv can cancel it (else it is cos p >= 6e-17
+// itself, times a polynomial value that is 0 or >= 6e-8 in fisheye mode) -- never below 2^-101.  gs360_selftest_arith checks the two forms against
+// each other on 10^9 operand sets of this domain (a numerator of 2^-125 over a divisor of 2^-99 does differ).
 // Same bits as `/`, 8 instead of 11 instructions, two divisions per pixel pair.
 __device__ __forceinline__ float eq_div(float n, float d) {
     float r = __builtin_amdgcn_rcpf(d);

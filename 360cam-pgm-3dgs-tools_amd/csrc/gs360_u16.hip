@@ -293,6 +293,43 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
 
 }  // namespace
 
+namespace {
+// Self-test of the reduced IEEE sequences of gs360_eqspec.h against the generic ones (`/`, sqrtf: correctly rounded with this
+// build's flags) on pseudo-random operands drawn from -- and well beyond -- the operand domains EQ-SPEC / FE-SPEC produce.
+__global__ __launch_bounds__(256) void arith_selftest_kernel(uint32_t seed, int iters, unsigned long long* bad) {
+    uint32_t s = seed ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u + 1u);
+    auto next = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+    unsigned long long wrong = 0;
+    for (int it = 0; it < iters; ++it) {
+        // divisor: any mantissa, exponent in [2^-100, 2^100]; numerator: 0, a fraction of the divisor that stays >= 2^-103
+        // (|n| <= d), or 2 (FE-SPEC's 2 / d)
+        const uint32_t r0 = next(), r1 = next(), r2 = next();
+        const float d = __builtin_bit_cast(float, ((27u + r0 % 201u) << 23) | (r1 & 0x7fffffu));
+        const float u = __builtin_bit_cast(float, ((100u + r2 % 28u) << 23) | (next() & 0x7fffffu));     // (2^-27, 2)
+        float n = (r2 & 0x80000000u) ? d * fminf(u, 1.0f) : 0.0f;
+        if (n != 0.0f && n < 0x1p-103f) n = 0.0f;          // below that v_div_scale rescales the numerator
+        if ((r0 >> 28) == 0) n = -n;                                      // EQ-SPEC's (mn - mx) numerators are <= 0
+        if ((r0 >> 24) == 0x55) n = d;                                    // quotient exactly 1
+        if (eq_div(n, d) != n / d) ++wrong;
+        if (d > 0x1p-24f && d < 0x1p24f && eq_div(2.0f, d) != 2.0f / d) ++wrong;
+        // square roots: operands in [2^-96, 2^96]
+        const float x = __builtin_bit_cast(float, ((31u + r1 % 193u) << 23) | (r0 & 0x7fffffu));
+        if (eq_sqrt_normal(x) != __builtin_sqrtf(x)) ++wrong;
+        if (eq_sqrt(x) != __builtin_sqrtf(x)) ++wrong;
+    }
+    // tiny / zero operands take eq_sqrt's wave-uniform fallback
+    const float tiny = __builtin_bit_cast(float, (next() % 31u) << 23 | (next() & 0x7fffffu));
+    if (eq_sqrt(tiny) != __builtin_sqrtf(tiny)) ++wrong;
+    if (eq_sqrt(0.0f) != 0.0f) ++wrong;
+    if (wrong) atomicAdd(bad, wrong);
+}
+}  // namespace
+
+hipError_t launch_arith_selftest(uint32_t seed, int blocks, int iters, unsigned long long* d_bad, hipStream_t s) {
+    hipLaunchKernelGGL(arith_selftest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, seed, iters, d_bad);
+    return hipGetLastError();
+}
+
 hipError_t launch_equirect_u16(const EqLaunch& L, int C, bool cubic, hipStream_t s) {
     dim3 grid((unsigned)(L.chunk * 8)), block(64 * kWaves);
     if (cubic) {

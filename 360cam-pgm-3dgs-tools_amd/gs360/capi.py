@@ -31,7 +31,7 @@ EXPORTS = (
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
     "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
     "gs360_png_unfilter", "gs360_event_sync", "gs360_stream_wait_event",
-    "gs360_color_plan16_create", "gs360_color_plan16_destroy", "gs360_color_apply_u16", "gs360_tiff_lzw_decode",
+    "gs360_color_plan16_create", "gs360_color_plan16_destroy", "gs360_color_apply_u16", "gs360_tiff_lzw_decode", "gs360_selftest_arith",
 )
 
 
@@ -119,6 +119,7 @@ def load_library(path=None):
         L.gs360_equirect_views_u16_host.argtypes = L.gs360_equirect_views_u8_host.argtypes
         L.gs360_remap_table_u16_host.argtypes = L.gs360_remap_table_u8_host.argtypes
         L.gs360_png_unfilter.argtypes = [vp, i, i, i]
+        L.gs360_selftest_arith.argtypes = [vp, u32, i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gs360_tiff_lzw_decode.argtypes = [vp, sz, vp, sz, C.POINTER(C.c_size_t)]
         L.gs360_color_plan16_create.argtypes = [vp, vp, i, vp, vp, i, vp, vp, vp, vp, pvp]
         L.gs360_color_plan16_destroy.argtypes = [vp, vp]
@@ -266,6 +267,12 @@ class Context:
 
     def event_record(self, slot, idx):
         _check(self.L.gs360_event_record(self.handle, slot, idx), self.L)
+
+    def selftest_arith(self, seed=1, n_millions=256):
+        """-> (operand sets checked, mismatches) of the reduced division / square-root sequences against IEEE `/`, sqrt"""
+        n, bad = C.c_uint64(0), C.c_uint64(0)
+        _check(self.L.gs360_selftest_arith(self.handle, int(seed) & 0xFFFFFFFF, int(n_millions), C.byref(n), C.byref(bad)), self.L)
+        return int(n.value), int(bad.value)
 
     def event_sync(self, slot, idx):
         _check(self.L.gs360_event_sync(self.handle, slot, idx), self.L)

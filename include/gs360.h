@@ -269,6 +269,12 @@ int gs360_remap_table_u16_host(gs360_ctx *ctx, const uint16_t *src, int H, int W
                                int interp, const double *border_value, int fill_value,
                                uint16_t *dst, size_t dst_stride, int slot);
 
+/* ---- self-test ------------------------------------------------------------------------------------------------
+ * The kernels evaluate EQ-SPEC / FE-SPEC's divisions and square roots with shorter instruction sequences that are bit-identical
+ * to IEEE `/` and sqrt on the specs' operand domains.  This compares both forms on the GPU for n_millions x 10^6 pseudo-random
+ * operand sets (and the tiny-operand fallback); *n_mismatch must come back 0. */
+int gs360_selftest_arith(gs360_ctx *ctx, uint32_t seed, int n_millions, uint64_t *n_checked, uint64_t *n_mismatch);
+
 /* ---- image-codec helper (host only, no GPU) ------------------------------------------------------
  * In-place PNG scanline reconstruction (filter types 0-4) of h rows of (1 + stride) inflated bytes; bpp = bytes per
  * complete pixel.  Used by the package's own 16-bit PNG reader; image codecs are outside the measured path. */

@@ -410,3 +410,11 @@ def test_api_limits_are_reported_not_crashed(ctx):
     for interp in (0, 1, 2, 4):
         out = ctx.remap(one, mm, np.zeros_like(mm), interpolation=interp, border_value=(1, 2, 3, 4))
         assert out[0, 0].tolist() == [10, 20, 30] and out[0, 3].tolist() == [1, 2, 3]
+
+
+def test_reduced_division_and_sqrt_sequences_equal_ieee(ctx):
+    """gs360_eqspec.h replaces `/` and sqrtf by shorter sequences that must be bit-identical on the specs' operand domains:
+    1.5 x 10^9 pseudo-random divisions and as many square roots on the GPU, both forms, zero mismatches"""
+    for seed in (1, 20260424, 0xDEADBEEF):
+        n, bad = ctx.selftest_arith(seed=seed, n_millions=512)
+        assert n >= 512_000_000 and bad == 0, (seed, n, bad)
