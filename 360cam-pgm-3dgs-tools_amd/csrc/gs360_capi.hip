@@ -543,28 +543,84 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         if (!dst[i]) return fail(GS360_ERR_ARG, "dst[%d] is NULL", i);
     HIP_TRY(hipSetDevice(c->device));
 
-    for (int v0 = 0; v0 < n_views; v0 += GS360_MAX_VIEWS) {
-        int nv = n_views - v0 < GS360_MAX_VIEWS ? n_views - v0 : GS360_MAX_VIEWS;
+    // ---- yaw rings -----------------------------------------------------------------------------------------------
+    // Views whose EQ-SPEC constants agree in everything but the integer longitude offset x0i32 -- and possibly the sign of the
+    // pitch -- form a ring: the kernel evaluates a tile's coordinates once and samples it for every member (the presets'
+    // yaw steps are whole texels: `yaw = i * 360 / count`, PC:794).  Float equality of the rounded constants is the criterion,
+    // so the grouping can never change a result.  The 16-bit kernel evaluates per pixel: one-view rings.
+    static_assert(sizeof(EqLaunch) <= 4096, "EqLaunch travels as a kernel argument");
+    const bool fish = (flags & GS360_EQ_FISHEYE_OUT) != 0;
+    try {
+    std::vector<EqView> ev((size_t)n_views);
+    for (int k = 0; k < n_views; ++k) {
+        make_eq_view(views[k], W, fish, &ev[k]);
+        ev[k].flip = 0;
+        if (esize == 2) {        // the 16-bit kernel walks whole rows of the full view: plain 64 x 16 tiling
+            ev[k].level = 0;
+            ev[k].blocked = 0;
+            ev[k].tiles_x = (views[k].width + kTileW - 1) / kTileW;
+            ev[k].tiles_y = (views[k].height + kTileH - 1) / kTileH;
+        }
+    }
+    // Ring size: unlimited for the row-per-slot lane map (arithmetic-bound views: cfg3 119 -> 99 -> 95 -> 93 us per frame for
+    // rings of 1 / 2 / 3 / 4-8 views).  Views on the blocked lane map are memory-bound and gain nothing from shared arithmetic,
+    // while a workgroup that walks six views in a row lengthens the launch's tail (cfg2 20.3 -> 22.6 us per frame): no sharing.
+    int ring_max = esize == 2 ? 1 : GS360_MAX_VIEWS, ring_max_blocked = 1;
+    if (const char* e = std::getenv("GS360_RING")) {       // tests / probes: 1 = no sharing anywhere, n = at most n views per ring
+        int v = std::atoi(e);
+        if (v >= 1 && esize != 2) ring_max = ring_max_blocked = v < GS360_MAX_VIEWS ? v : GS360_MAX_VIEWS;
+    }
+    std::vector<std::vector<int>> rings;
+    for (int k = 0; k < n_views; ++k) {
+        const EqView& b = ev[k];
+        int hit = -1;
+        for (size_t r = 0; r < rings.size() && hit < 0; ++r) {
+            const EqView& a = ev[rings[r][0]];
+            if ((int)rings[r].size() < (b.blocked ? ring_max_blocked : ring_max) && a.sxu == b.sxu && a.syv == b.syv && a.cp == b.cp && (a.sp == b.sp || a.sp == -b.sp) &&
+                a.x0f32 == b.x0f32 && a.out_w == b.out_w && a.out_h == b.out_h && a.level == b.level && a.fish == b.fish &&
+                a.blocked == b.blocked)
+                hit = (int)r;
+        }
+        if (hit < 0) { rings.emplace_back(); hit = (int)rings.size() - 1; }
+        rings[hit].push_back(k);
+        ev[k].flip = ev[rings[hit][0]].sp != b.sp ? 1 : 0;
+    }
+
+    size_t r0 = 0;
+    while (r0 < rings.size()) {
+        size_t r1 = r0;
+        int nv = 0;
+        while (r1 < rings.size() && nv + (int)rings[r1].size() <= GS360_MAX_VIEWS) nv += (int)rings[r1++].size();
         for (int f0 = 0; f0 < n_frames; f0 += GS360_MAX_FRAMES) {
             int nf = n_frames - f0 < GS360_MAX_FRAMES ? n_frames - f0 : GS360_MAX_FRAMES;
             EqLaunch L;
             std::memset(&L, 0, sizeof(L));
-            int base = 0;
-            for (int k = 0; k < nv; ++k) {
-                make_eq_view(views[v0 + k], W, (flags & GS360_EQ_FISHEYE_OUT) != 0, &L.view[k]);
-                if (esize == 2) {        // the 16-bit kernel walks whole rows of the full view: plain 64 x 16 tiling
-                    L.view[k].level = 0;
-                    L.view[k].blocked = 0;
-                    L.view[k].tiles_x = (views[v0 + k].width + kTileW - 1) / kTileW;
-                    L.view[k].tiles_y = (views[v0 + k].height + kTileH - 1) / kTileH;
+            int order[GS360_MAX_VIEWS];
+            int base = 0, j = 0;
+            for (size_t r = r0; r < r1; ++r) {
+                const EqView& lead = ev[rings[r][0]];
+                L.ring_first[r - r0] = j;
+                L.ring_count[r - r0] = (int32_t)rings[r].size();
+                for (int idx : rings[r]) {
+                    L.view[j] = ev[idx];
+                    L.view[j].tile_base = base;
+                    order[j++] = idx;
                 }
-                L.view[k].tile_base = base;
-                base += L.view[k].tiles_x * L.view[k].tiles_y;
+                base += lead.tiles_x * lead.tiles_y;
+            }
+            L.n_rings = (int)(r1 - r0);
+            // tiles of rings with different member counts differ in cost: deal them to the XCDs in short runs instead of chunks
+            L.xcd_group_log2 = -1;
+            for (size_t r = r0; r < r1; ++r)
+                if (rings[r].size() != rings[r0].size()) L.xcd_group_log2 = 5;
+            if (const char* e = std::getenv("GS360_XCD_GROUP")) {   // probes: -1 = chunks, g = runs of 2^g tiles
+                int v = std::atoi(e);
+                if (v >= -1 && v <= 12) L.xcd_group_log2 = v;
             }
             for (int f = 0; f < nf; ++f) {
                 L.src[f] = (const uint8_t*)src_frames[f0 + f];
                 L.mask[f] = mask_frames ? (const uint8_t*)mask_frames[f0 + f] : nullptr;
-                for (int k = 0; k < nv; ++k) L.dst[f * nv + k] = (uint8_t*)dst[(size_t)(f0 + f) * n_views + v0 + k];
+                for (int k = 0; k < nv; ++k) L.dst[f * nv + k] = (uint8_t*)dst[(size_t)(f0 + f) * n_views + order[k]];
             }
             L.kx32 = (float)(32.0 * (double)W / (2.0 * kPi));
             L.ky32 = (float)(32.0 * (double)H / kPi);
@@ -586,6 +642,10 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
                 HIP_TRY(launch_equirect(L, C, c->stream[slot]));
             }
         }
+        r0 = r1;
+    }
+    } catch (const std::bad_alloc&) {
+        return fail(GS360_ERR_NOMEM, "out of host memory while planning %d views", n_views);
     }
     return GS360_OK;
 }

@@ -98,13 +98,20 @@ __device__ __forceinline__ float eq_poly8(const float* k, float q) {
     return p;
 }
 
-// quantised longitude coordinate (1/32 px, wrapped to [0, 32W))
-__device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, const EqView& V) {
-    int sx = (int)__builtin_rintf(__builtin_fmaf(r0, L.kx32, V.x0f32)) + V.x0i32 + K * 4 * L.W;
-    const int W32 = 32 * L.W;
+// quantised longitude coordinate (1/32 px, wrapped to [0, 32W)), in two steps: the part every view of a yaw ring shares
+// (in [-18W, 18W + 32]) and the view's own integer offset x0i32 in [0, 32W) with the single wrap.  Integer addition is
+// associative, so the split is the per-view formula bit for bit.
+__device__ __forceinline__ int eq_lon_base(float r0, int K, const EqLaunch& L, float x0f32) {
+    return (int)__builtin_rintf(__builtin_fmaf(r0, L.kx32, x0f32)) + K * 4 * L.W;
+}
+__device__ __forceinline__ int eq_lon_wrap(int base, int x0i32, int W32) {
+    int sx = base + x0i32;
     if (sx < 0) sx += W32;
     if (sx >= W32) sx -= W32;
     return sx;
+}
+__device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, const EqView& V) {
+    return eq_lon_wrap(eq_lon_base(r0, K, L, V.x0f32), V.x0i32, 32 * L.W);
 }
 
 // EQ-SPEC v1 source coordinate of ONE output pixel (i, j) in 1/32-px units (sx wrapped to [0, 32W), sy unclamped):

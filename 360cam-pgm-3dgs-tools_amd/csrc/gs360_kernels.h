@@ -2,6 +2,7 @@
 // gfx950 only; no portability layer.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/gs360.h"
@@ -29,14 +30,18 @@ struct EqView {
     float sxu, syv;      // tan(hfov/2)/out_w, tan(vfov/2)/out_h
     float sp, cp;        // sin / cos of pitch
     float x0f32;         // 32 * frac((yaw/360 + 1/2) * W - 1/2)
-    int32_t x0i32;       // 32 * (floor(...) mod W)
     int32_t out_w, out_h;
     int32_t tiles_x, tiles_y;
-    int32_t tile_base;   // first tile index of this view inside one frame
+    int32_t tile_base;   // first tile index of this view's RING inside one frame
     int32_t level;       // pitch == 0 exactly (sp == 0, cp == 1): horizon-symmetric fast path
     int32_t fish;        // equidistant-fisheye output (GS360_EQ_FISHEYE_OUT): sxu/syv = fov/180/size, general row path
     int32_t blocked;     // RGB bilinear only: 4-row x 16-column gather patches instead of 64-pixel rows (strong minification)
+    int32_t pad_;
+    // the two per-member scalars of a yaw ring, adjacent and 8-byte aligned: the kernel reads them with one scalar load
+    int32_t x0i32;       // 32 * (floor((yaw/360 + 1/2) * W - 1/2) mod W)
+    int32_t flip;        // ring member whose pitch is MINUS the ring's first view's pitch: rows run bottom-up, latitude negated
 };
+static_assert(sizeof(EqView) == 64 && offsetof(EqView, x0i32) % 8 == 0, "EqView layout");
 
 struct EqLaunch {
     const uint8_t* src[GS360_MAX_FRAMES];
@@ -52,6 +57,15 @@ struct EqLaunch {
     int64_t src_stride;
     int64_t mask_stride;
     int64_t dst_stride;  // 0 = tight (out_w * C)
+    // Yaw rings: views [ring_first[g], ring_first[g] + ring_count[g]) share every EQ-SPEC constant except the integer
+    // longitude offset x0i32 (and the sign of the pitch: `flip`), so one workgroup evaluates the coordinates of a tile once
+    // and samples it for every member.  Tiles are numbered per RING (view[ring_first[g]].tile_base); the 16-bit kernel
+    // runs with one-view rings.
+    int32_t n_rings;
+    int32_t xcd_group_log2;   // >= 0: XCD x takes runs of 2^g consecutive tiles round-robin (rings of unequal size in one launch:
+                              // contiguous chunks would hand whole rings to single XCDs); -1: contiguous chunks (`chunk`)
+    int32_t ring_first[GS360_MAX_VIEWS];   // 32-bit on purpose: sub-dword fields of the kernel argument are fetched with VECTOR loads
+    int32_t ring_count[GS360_MAX_VIEWS];   // (a memory round trip per wavefront), dwords with scalar loads
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -23,6 +23,8 @@
 //
 // Compile with -ffp-contract=off: the float32 specs are defined operation by operation and must match the
 // CPU oracle bit for bit; only explicit __builtin_fmaf may fuse.
+#include <type_traits>
+
 #include "gs360_kernels.h"
 #include "gs360_eqspec.h"
 
@@ -42,6 +44,21 @@ __device__ __forceinline__ uint2 ld_u64(const uint8_t* p) {
 }
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }
 
+// Lane index / uniform value behind an optimisation barrier.  The store helpers derive a dozen per-lane constants from the
+// lane index (dword slicing of 3-byte pixels); inside the ring-member loop of eq_views_kernel the compiler would hoist all
+// of them -- for every store variant -- out of the loop and spill (measured: 120 VGPRs spilled at a 96-register budget).
+// A value that comes out of a volatile asm cannot be hoisted or merged, so each store recomputes its few constants in place.
+__device__ __forceinline__ int lane_here() {
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    return l;
+}
+__device__ __forceinline__ int uniform_here(int v) {
+    v = __builtin_amdgcn_readfirstlane(v);     // wave-uniform by construction; a no-op when the value already sits in an SGPR
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 // 8 bytes starting at the (unaligned) address p, fetched as ONE dword-aligned 12-byte access and shifted into
 // place with v_alignbyte.  The texture-address path merges dword-aligned lane accesses of a quad into cache-line
 // requests; byte-misaligned ones are looked up lane by lane (measured: 96 tag lookups per 64-lane instruction).
@@ -60,6 +77,15 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_EQ_WAVES
 #define GS360_EQ_WAVES 5     // wavefronts per SIMD of the bilinear equirect kernel (measured optimum, see the kernel comment)
 #endif
+#ifndef GS360_EQC_WAVES
+#define GS360_EQC_WAVES 4    // wavefronts per SIMD of the cubic equirect kernel (124 registers; 40 KiB of LDS = four workgroups per CU)
+#endif
+#ifndef GS360_RING_PARK
+#define GS360_RING_PARK 0    // bilinear kernel: ring-shared coordinates that wait in LDS between members (0 none, 1 latitude, 3 all)
+#endif
+#ifndef GS360_RING_PARK_CUBIC
+#define GS360_RING_PARK_CUBIC 1
+#endif
 #ifndef GS360_PAIRED_FETCH
 #define GS360_PAIRED_FETCH 1
 #endif
@@ -73,25 +99,46 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // pixels), so both uses of a line meet in one instruction and are merged by the address coalescer.
 // v_permlane32_swap (gfx950) builds the two address vectors from (o0, o1) in one operation and puts the returned
 // dwords back in pixel order.  Each read is a dword-aligned 12-byte access shifted into place with v_alignbyte.
-__device__ __forceinline__ void ld_rows_rgb(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1, uint2& t0, uint2& t1) {
+// Two steps so that a wavefront can put ALL its gathers in flight before the first result is touched (the caller separates
+// the steps with a scheduling barrier: left to itself the scheduler interleaves load pairs with their consumers as soon as
+// the surrounding code tightens the register budget, which serialises the misses -- measured 20.7 -> 30.1 us per cfg2 frame):
+//   ld_rows_rgb_issue   address swap + the two 12-byte loads (raw dwords, still in fetch order)
+//   ld_rows_rgb_finish  swap the returned dwords back into pixel order and shift them into place
+struct RowsRaw { uint32_t a0, a1, a2, b0, b1, b2, sh; };   // sh = (o0 & 3) | (o1 & 3) << 2
+__device__ __forceinline__ RowsRaw ld_rows_rgb_issue(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1) {
+    RowsRaw r;
+    r.sh = (o0 & 3u) | ((o1 & 3u) << 2);
 #if GS360_PAIRED_FETCH
-    const uint32_t s0 = o0 & 3u, s1 = o1 & 3u;
     const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0 & ~3u, o1 & ~3u, false, false);
     const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
     const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
-    const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2];
-    const uint32_t b0 = qb[0], b1 = qb[1], b2 = qb[2];
-    const u32x2 d0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);   // .x = row y0, .y = row y1, own pixel
-    const u32x2 d1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-    const u32x2 d2 = __builtin_amdgcn_permlane32_swap(a2, b2, false, false);
+#else
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o0 & ~3u), 4));
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o1 & ~3u), 4));
+#endif
+    r.a0 = qa[0]; r.a1 = qa[1]; r.a2 = qa[2];
+    r.b0 = qb[0]; r.b1 = qb[1]; r.b2 = qb[2];
+    return r;
+}
+__device__ __forceinline__ void ld_rows_rgb_finish(const RowsRaw& r, uint2& t0, uint2& t1) {
+    const uint32_t s0 = r.sh & 3u, s1 = r.sh >> 2;
+#if GS360_PAIRED_FETCH
+    const u32x2 d0 = __builtin_amdgcn_permlane32_swap(r.a0, r.b0, false, false);   // .x = row y0, .y = row y1, own pixel
+    const u32x2 d1 = __builtin_amdgcn_permlane32_swap(r.a1, r.b1, false, false);
+    const u32x2 d2 = __builtin_amdgcn_permlane32_swap(r.a2, r.b2, false, false);
     t0.x = __builtin_amdgcn_alignbyte(d1.x, d0.x, s0);
     t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, s0);
     t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, s1);
     t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, s1);
 #else
-    t0 = ld_u64_via_aligned96(src + o0);
-    t1 = ld_u64_via_aligned96(src + o1);
+    t0.x = __builtin_amdgcn_alignbyte(r.a1, r.a0, s0);
+    t0.y = __builtin_amdgcn_alignbyte(r.a2, r.a1, s0);
+    t1.x = __builtin_amdgcn_alignbyte(r.b1, r.b0, s1);
+    t1.y = __builtin_amdgcn_alignbyte(r.b2, r.b1, s1);
 #endif
+}
+__device__ __forceinline__ void ld_rows_rgb(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1, uint2& t0, uint2& t1) {
+    ld_rows_rgb_finish(ld_rows_rgb_issue(src, o0, o1), t0, t1);
 }
 
 // bilinear blend of one channel, weights a0+a1 = 32, b0+b1 = 32  ->  (sum + 512) >> 10
@@ -106,18 +153,34 @@ __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s
 // row leaves as 4-byte stores (lane j writes bytes 4j..4j+3 = tail of pixel 4j/3 + head of the next one).
 // skip_first drops position 0 (the centre column of an odd-width view, which is its own mirror); the caller then
 // passes aligned4 = false and the per-lane byte path below handles it.
+// The two per-lane constants of the dword re-slicing are computed once per tile by the caller (RowPack): inside the
+// ring-member loop of eq_views_kernel they must neither be recomputed by every one of the 8 row stores of an iteration nor
+// be left to the compiler's hoisting, which drags every other invariant of the store paths along and spills.
+struct RowPack {
+    int a4;   // 4 * ((4 * lane) / 3): ds_bpermute address of the first pixel contributing to dword `lane` of the row
+    int sh;   // 8 * ((4 * lane) % 3): its bit offset
+    int lane;
+};
+__device__ __forceinline__ RowPack make_row_pack() {
+    const int lane = threadIdx.x & 63, t = lane / 3;
+    RowPack rp;
+    rp.a4 = 4 * (lane + t);
+    rp.sh = 8 * (lane - 3 * t);
+    rp.lane = lane;
+    return rp;
+}
 template <int C>
-__device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4, bool reversed = false,
-                                          bool skip_first = false) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4, const RowPack& rp,
+                                          bool reversed = false, bool skip_first = false) {
+    const int lane = rp.lane;
     if constexpr (C == 3) {
         if (aligned4) {
             uint32_t packed = px[0] | (px[1] << 8) | (px[2] << 16);
-            int a = lane + lane / 3;          // (4 * lane) / 3: first pixel contributing to dword `lane`
-            int s = lane - 3 * (lane / 3);    // (4 * lane) % 3
-            int la = reversed ? n_px - 1 - a : a, lb = reversed ? n_px - 2 - a : a + 1;
-            uint32_t pa = __shfl(packed, la & 63), pb = __shfl(packed, lb & 63);
-            uint32_t dw = (pa >> (8 * s)) | (pb << (24 - 8 * s));
+            // source lanes (as byte addresses, wrapped to the wavefront): pixel a and a + 1, or their mirror images
+            const int la4 = reversed ? 4 * (n_px - 1) - rp.a4 : rp.a4, lb4 = reversed ? la4 - 4 : la4 + 4;
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(la4 & 252, (int)packed);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)packed);
+            const uint32_t dw = (pa >> rp.sh) | (pb << (24 - rp.sh));
             int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
             if (lane < full) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
             if (lane == full && rem)
@@ -146,7 +209,7 @@ template <int NS>
 __device__ __forceinline__ void store_patch_rgb(uint8_t* dst, int64_t dstride, uint32_t* lds, const uint32_t (&px)[kRowsPerWave][4],
                                                 int s0, int y0, int ystep, int nrows, int col0, int n_w, bool aligned4,
                                                 bool reversed, bool skip_first) {
-    const int lane = threadIdx.x & 63, r = lane >> 4, c16 = lane & 15;
+    const int lane = lane_here(), r = lane >> 4, c16 = lane & 15;
     if (aligned4 && (n_w & 3) == 0) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -202,6 +265,7 @@ struct BlkStore {
     uint32_t* lds;       // this wavefront's 256-dword slice
     int mode;            // 1: general view, 4 slots = one 4x64 patch;  2: level view, slots {0,1} top patch, {2,3} its horizon mirror
     int y0, nrows;       // first image row of the (top) patch, valid rows
+    int ystep;           // mode 1: +1, or -1 for a flipped ring member (rows run upwards from y0)
     int yb, nrows_b;     // mode 2: first row of the mirrored patch (rows run upwards), valid rows
     int sub;             // mode 2: first tile column of this wavefront's 32-column half
 };
@@ -214,6 +278,7 @@ struct BlkStore {
 template <int C>
 struct EqTaps {
     uint2 t0, t1;   // raw bytes of rows y0 / y1 starting at column ix
+    RowsRaw raw;    // C == 3: the loads in flight (eq_taps_finish turns them into t0 / t1)
     bool fix;       // needs the slow (wrapping) path
 };
 
@@ -246,12 +311,16 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
         t.t0 = make_uint2(a, 0);
         t.t1 = make_uint2(b, 0);
     } else if constexpr (C == 3) {
-        ld_rows_rgb(src, o0, o1, t.t0, t.t1);
+        t.raw = ld_rows_rgb_issue(src, o0, o1);
     } else {
         t.t0 = ld_u64(r0);
         t.t1 = ld_u64(r1);
     }
     return t;
+}
+template <int C>
+__device__ __forceinline__ void eq_taps_finish(EqTaps<C>& t) {
+    if constexpr (C == 3) ld_rows_rgb_finish(t.raw, t.t0, t.t1);
 }
 
 // Integer multiply-adds as v_dot2_i32_i16: v_perm_b32 gathers two tap bytes into a zero-extended 16-bit pair and one
@@ -305,52 +374,66 @@ __device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, 
 }
 
 // ---- cubic variant of the equirect sampler (4x4 Keys taps, OpenCV fixed-point table) -------------------------------
-// eq_cubic_fetch issues the 4 row reads of one RGB pixel (12 contiguous bytes each, fetched as a dword-aligned 16-byte
-// read) plus the 32-byte weight entry without control flow; lanes whose window touches the seam or the last columns are
-// flagged and redone by eq_cubic_slow.
+// Two steps, like the bilinear fetch: cubic_issue_rgb puts the 4 row reads of one RGB pixel in flight (12 contiguous bytes
+// each, fetched as a dword-aligned 16-byte read) without control flow and without touching a result; cubic_finish_rgb shifts
+// the rows into place, reads the 32-byte weight entry (LDS: short latency, so it need not occupy 8 registers while the
+// gathers fly) and blends.  Lanes whose window touches the seam or the last columns are flagged and redone by eq_cubic_slow.
 struct EqCubicTaps {
-    uint32_t row[4][3];   // 12 tap bytes of each window row
-    uint4 wa, wb;         // 16 int16 weights
+    uint32_t raw[4][4];   // the four aligned dwords of each window row, as loaded
+    uint32_t sh;          // byte offset of the window inside the aligned read (the same for all four rows)
+    int phase;            // fy * 32 + fx
     bool fix;
 };
 
 // window anchored at texel (ix, iy) with phase (fx, fy); `fix` = the window's columns could not be read in place
-__device__ __forceinline__ EqCubicTaps cubic_fetch_rgb(const int16_t* wtab, const uint8_t* __restrict__ src, uint32_t stride, int W, int H,
+__device__ __forceinline__ EqCubicTaps cubic_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, int W, int H,
                                                        int ix, int iy, int fx, int fy) {
     EqCubicTaps t;
     const int x0 = min(max(ix - 1, 0), W - 6);              // 16-byte aligned read of 12 tap bytes stays in-row
     t.fix = (x0 != ix - 1);
-    const uint4* wq = reinterpret_cast<const uint4*>(wtab + (fy * 32 + fx) * 16);
-    t.wa = wq[0];
-    t.wb = wq[1];
+    t.phase = fy * 32 + fx;
     const uint32_t col = (uint32_t)x0 * 3u;
+    // rows start at multiples of the stride from a 4-byte aligned base; with a stride that is a multiple of 4 every row of the
+    // window has the same misalignment, otherwise it is taken per row (folded into the address, see below)
+    t.sh = 0;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
         const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
         const uint8_t* p = src + off;
         const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
         const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
-        t.row[ky][0] = __builtin_amdgcn_alignbyte(d1, d0, o);
-        t.row[ky][1] = __builtin_amdgcn_alignbyte(d2, d1, o);
-        t.row[ky][2] = __builtin_amdgcn_alignbyte(d3, d2, o);
+        t.raw[ky][0] = q[0]; t.raw[ky][1] = q[1]; t.raw[ky][2] = q[2]; t.raw[ky][3] = q[3];
+        t.sh |= o << (2 * ky);
     }
     return t;
 }
 
-__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqLaunch& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy) {
-    return cubic_fetch_rgb(wtab, src, (uint32_t)L.src_stride, L.W, L.H, sx >> 5, sy >> 5, sx & 31, sy & 31);
+// The launch constants the samplers need, as plain values (see the ring-member loop of eq_views_kernel: they are handed over
+// behind an optimisation barrier so that they stay in registers instead of being re-read from the kernel argument).
+struct EqSrc {
+    int W, H;
+    int64_t src_stride, mask_stride;
+};
+
+__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqSrc& L, const uint8_t* __restrict__ src, int sx, int sy) {
+    return cubic_issue_rgb(src, (uint32_t)L.src_stride, L.W, L.H, sx >> 5, sy >> 5, sx & 31, sy & 31);
 }
 
 // 48 multiply-adds per pixel as 24 v_dot2_i32_i16 (see eq_blend): constant selectors -- the 12 tap bytes of a row are
 // b0..b11, channel c owns b[c], b[3+c], b[6+c], b[9+c] -- and the table already stores the weights as int16 pairs.
+// `wtab` is the LDS copy in the equirect kernel and the global table in the cv2 kernels.
 
-__device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, uint32_t (&out)[4]) {
-    const uint32_t wpk[8] = {t.wa.x, t.wa.y, t.wa.z, t.wa.w, t.wb.x, t.wb.y, t.wb.z, t.wb.w};
+__device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, const int16_t* wtab, uint32_t (&out)[4]) {
+    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
+    const uint4 wa = wq[0], wb = wq[1];
+    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
     int acc[3] = {0, 0, 0};
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t d0 = t.row[ky][0], d1 = t.row[ky][1], d2 = t.row[ky][2];
+        const uint32_t o = (t.sh >> (2 * ky)) & 3u;
+        const uint32_t d0 = __builtin_amdgcn_alignbyte(t.raw[ky][1], t.raw[ky][0], o);
+        const uint32_t d1 = __builtin_amdgcn_alignbyte(t.raw[ky][2], t.raw[ky][1], o);
+        const uint32_t d2 = __builtin_amdgcn_alignbyte(t.raw[ky][3], t.raw[ky][2], o);
         const uint32_t w01 = wpk[2 * ky], w23 = wpk[2 * ky + 1];
         // perm(a, b, sel): bytes 0..3 come from b, 4..7 from a
         acc[0] = dot2_i16(__builtin_amdgcn_perm(d0, d0, GS360_PAIR(0, 3)), w01, acc[0]);            // b0, b3
@@ -366,7 +449,7 @@ __device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, uint32_t (&
 
 // generic cubic sample: columns wrap, rows clamp (any channel count; also the repair path of the RGB fast path)
 template <int C>
-__device__ __forceinline__ void eq_cubic_slow(const EqLaunch& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
+__device__ __forceinline__ void eq_cubic_slow(const EqSrc& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
     const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
     const uint4* wq = reinterpret_cast<const uint4*>(wtab + (fy * 32 + fx) * 16);
     const uint4 wa = wq[0], wb = wq[1];
@@ -398,7 +481,7 @@ __device__ __forceinline__ void eq_cubic_slow(const EqLaunch& L, const int16_t* 
 //   reversed = false: lane l is pixel l of the row segment starting at `col0`
 //   reversed = true : lane l is pixel n_px-1-l (the mirrored half of the view)
 // keep-mask sample of one pixel: nearest texel of the EQ-SPEC coordinate, wrap in x, clamp in y
-__device__ __forceinline__ uint32_t eq_mask_at(const EqLaunch& L, const uint8_t* __restrict__ mask, int sx, int sy) {
+__device__ __forceinline__ uint32_t eq_mask_at(const EqSrc& L, const uint8_t* __restrict__ mask, int sx, int sy) {
     int xn = (sx + 16) >> 5;
     if (xn >= L.W) xn -= L.W;
     const int yn = min(max((sy + 16) >> 5, 0), L.H - 1);
@@ -406,18 +489,19 @@ __device__ __forceinline__ uint32_t eq_mask_at(const EqLaunch& L, const uint8_t*
 }
 
 // Hand the wavefront's pixels to memory: blocked patches (store_patch_rgb) or one row per slot (store_row).
-template <int C>
+// MODE (compile time; the kernel switches once per tile, outside the ring-member loop, so that each loop body carries only
+// its own lane map's invariants): 0 = one row per slot, 1 = blocked patches of a general view, 2 = blocked level view.
+template <int C, int MODE>
 __device__ __forceinline__ void eq_store(uint8_t* dst, int64_t dstride, const uint32_t (&px)[kRowsPerWave][4],
                                          const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
                                          int col0, int n_px, bool reversed, bool aligned4, bool skip_first,
-                                         bool use_blk, const BlkStore blk) {
+                                         const BlkStore blk, const RowPack& rp) {
     if constexpr (C == 3 && kRowsPerWave == 4 && kWaves == 4) {   // == kBlocked of the kernel
-      if (use_blk) {                                      // wave-uniform: this view uses the blocked lane map
-        if (blk.mode == 1) {
-            store_patch_rgb<4>(dst, dstride, blk.lds, px, 0, blk.y0, 1, blk.nrows, col0, n_px, aligned4, reversed, skip_first);
+      if constexpr (MODE != 0) {
+        if constexpr (MODE == 1) {
+            store_patch_rgb<4>(dst, dstride, blk.lds, px, 0, blk.y0, blk.ystep, blk.nrows, col0, n_px, aligned4, reversed, skip_first);
             return;
-        }
-        {
+        } else {
             // this wavefront owns tile columns [sub, sub + n_w); in the mirrored pass they sit at the other end of the segment
             const int n_w = min(max(n_px - blk.sub, 0), 32);
             const int c0 = reversed ? col0 + n_px - blk.sub - n_w : col0 + blk.sub;
@@ -432,29 +516,30 @@ __device__ __forceinline__ void eq_store(uint8_t* dst, int64_t dstride, const ui
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s)
 #if GS360_EXPERIMENT == 1   // load-path probe: only one lane-row in a million is written
-        if (row_ok[s] && px[s][0] == 0x12345u) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+        if (row_ok[s] && px[s][0] == 0x12345u) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, rp, reversed, skip_first);
 #else
-        if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, reversed, skip_first);
+        if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, rp, reversed, skip_first);
 #endif
 }
 
-template <int C, bool CUBIC>
-__device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __restrict__ src, const uint8_t* __restrict__ mask,
+template <int C, bool CUBIC, int MODE, bool MASKED>
+__device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restrict__ src, const uint8_t* __restrict__ mask,
                                         uint8_t* dst, int64_t dstride,
                                         const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
                                         const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
                                         int col0, int n_px, bool reversed, bool aligned4, bool skip_first,
-                                        const int16_t* wtab, bool use_blk, const BlkStore blk) {
+                                        const int16_t* wtab, const BlkStore blk, const RowPack& rp) {
     if constexpr (CUBIC) {
         uint32_t px[kRowsPerWave][4];
         if constexpr (C == 3) {
             // two row slots at a time: 8 tap reads + 4 weight reads in flight, 24 tap dwords live
 #pragma unroll
             for (int s0 = 0; s0 < kRowsPerWave; s0 += 2) {
-                EqCubicTaps ta = eq_cubic_fetch(L, wtab, src, sxs[s0], sys[s0]);
-                EqCubicTaps tb = eq_cubic_fetch(L, wtab, src, sxs[s0 + 1], sys[s0 + 1]);
-                eq_cubic_blend(ta, px[s0]);
-                eq_cubic_blend(tb, px[s0 + 1]);
+                EqCubicTaps ta = eq_cubic_fetch(L, src, sxs[s0], sys[s0]);
+                EqCubicTaps tb = eq_cubic_fetch(L, src, sxs[s0 + 1], sys[s0 + 1]);
+                __builtin_amdgcn_sched_barrier(0);        // all 8 row reads in flight before the first result is touched
+                eq_cubic_blend(ta, wtab, px[s0]);
+                eq_cubic_blend(tb, wtab, px[s0 + 1]);
                 if (__any(ta.fix | tb.fix)) {
                     if (ta.fix) eq_cubic_slow<C>(L, wtab, src, sxs[s0], sys[s0], px[s0]);
                     if (tb.fix) eq_cubic_slow<C>(L, wtab, src, sxs[s0 + 1], sys[s0 + 1], px[s0 + 1]);
@@ -464,20 +549,20 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s) eq_cubic_slow<C>(L, wtab, src, sxs[s], sys[s], px[s]);
         }
-        if (mask) {                                       // wave-uniform
+        if constexpr (MASKED) {
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s)
                 if (eq_mask_at(L, mask, sxs[s], sys[s]) < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
         }
-        eq_store<C>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, use_blk, blk);
+        eq_store<C, MODE>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, blk, rp);
         return;
     }
     EqTaps<C> taps[kRowsPerWave];
     uint32_t keep[kRowsPerWave];
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s) keep[s] = 255u;
-    if (mask) {                                           // wave-uniform: mask reads join the tap reads in flight
-#pragma unroll
+    if constexpr (MASKED) {                               // compile time: the mask reads join the tap reads in flight (behind a
+#pragma unroll                                            // run-time test the compiler waits for each of them inside the branch)
         for (int s = 0; s < kRowsPerWave; ++s) keep[s] = eq_mask_at(L, mask, sxs[s], sys[s]);
     }
     bool any_fix = false;
@@ -486,20 +571,24 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
         taps[s] = eq_fetch<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s]);
         any_fix |= taps[s].fix;
     }
+    __builtin_amdgcn_sched_barrier(0);                    // every gather of the pass is in flight before the first is consumed
     uint32_t px[kRowsPerWave][4];
 #pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s) eq_blend<C>(taps[s], sxs[s], sys[s], px[s]);
+    for (int s = 0; s < kRowsPerWave; ++s) {
+        eq_taps_finish<C>(taps[s]);
+        eq_blend<C>(taps[s], sxs[s], sys[s], px[s]);
+    }
     if (__any(any_fix)) {
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s)
             if (taps[s].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
     }
-    if (mask) {
+    if constexpr (MASKED) {
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s)
             if (keep[s] < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
     }
-    eq_store<C>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, use_blk, blk);
+    eq_store<C, MODE>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, blk, rp);
 }
 
 // equirect -> rectilinear views.  The pinhole grid is mirror-symmetric about the view's vertical axis:
@@ -512,11 +601,16 @@ __device__ __forceinline__ void eq_pass(const EqLaunch& L, const uint8_t* __rest
 // row-per-slot lane map: 3 / 4 / 6 wavefronts: 27.4 / 23.1 / 24.3; blocked lane map: 3 / 4 / 5 / 6: 22.1 / 20.8 / 20.3 /
 // 23.3 (6 spills).  5 is also the better choice for the arithmetic-bound large-view configs (cfg1/3/5).  The cubic
 // variant needs 128 VGPRs and stays at 4.
-template <int C, bool CUBIC>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUBIC ? 4 : GS360_EQ_WAVES, CUBIC ? 4 : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
-    // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk)
+template <int C, bool CUBIC, bool MASKED>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUBIC ? GS360_EQC_WAVES : GS360_EQ_WAVES, CUBIC ? GS360_EQC_WAVES : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
+    // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk), or -- when the launch mixes rings of
+    // different sizes, whose tiles differ in cost -- runs of 2^g consecutive tiles dealt round-robin to the XCDs
     int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
+    if (L.xcd_group_log2 >= 0) {
+        const int q = b >> 3, g = L.xcd_group_log2;
+        t = ((((q >> g) << 3) + (b & 7)) << g) + (q & ((1 << g) - 1));
+    }
     if (t >= L.total_tiles) return;
     // cubic: the 32 KiB weight table would otherwise occupy the whole vector L1 and every lane reads a different
     // 32-byte entry of it; one coalesced copy per workgroup into LDS keeps the L1 for source lines
@@ -529,16 +623,25 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         __syncthreads();
     }
     constexpr bool kBlocked = (C == 3) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map, see below
-    __shared__ uint32_t s_blk[kBlocked ? kWaves * 256 + 4 : 4];
+    // LDS: the blocked store's transpose slices (256 dwords per wavefront; its read-back may touch the dword after the slice,
+    // which is the next slice or the first parked dword -- never used), then the parked ring coordinates (see below)
+    constexpr int kParkN = CUBIC ? GS360_RING_PARK_CUBIC : GS360_RING_PARK;     // 0 none, 1 latitude only, 3 all three
+    constexpr int kBlkDw = kBlocked ? kWaves * 256 : 0;
+    constexpr int kParkDw = kParkN * kRowsPerWave * 64 * kWaves;
+    __shared__ uint32_t s_lds[kBlkDw + (kParkDw ? kParkDw : 4)];
+    uint32_t* const s_blk = s_lds;
+    int* const s_park = reinterpret_cast<int*>(s_lds + kBlkDw);
     int f = t / L.tiles_per_frame;
     int r = t - f * L.tiles_per_frame;
-    int k = 0;
-    while (k + 1 < L.n_views && r >= L.view[k + 1].tile_base) ++k;
-    const EqView& V = L.view[k];
+    int g = 0;
+    while (g + 1 < L.n_rings && r >= L.view[L.ring_first[g + 1]].tile_base) ++g;
+    const int k0 = L.ring_first[g], n_members = L.ring_count[g];
+    const EqView& V = L.view[k0];          // the ring's geometry (every member has the same, up to x0i32 and the pitch sign)
     r -= V.tile_base;
     const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wavefront index as a scalar: everything derived from it (row slots, patch origins) then lives in SGPRs
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half_w = (V.out_w + 1) >> 1;               // columns [0, half_w) are computed, the rest mirrored
     const int x0 = tile_x * kTileW;
     const int n_px = min(kTileW, half_w - x0);
@@ -547,8 +650,6 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
     const uint8_t* __restrict__ src = L.src[f];
     const uint8_t* __restrict__ mask = L.mask[f];
     const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
-    uint8_t* dst = L.dst[f * L.n_views + k];
-    const bool base_aligned = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
     const float x = (float)(2 * xl + 1 - V.out_w) * V.sxu;
 
     // ---- row slots of this wavefront -------------------------------------------------------------
@@ -599,13 +700,13 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
             const int q = Kt * 8 * L.H + (int)__builtin_rintf(rt * L.ky32);
             sys[s] = L.y0i32 - q;
             sys[s + 2] = L.y0i32 + q;
-            sxl[s] = sxl[s + 2] = eq_quant_lon(rl, Kl, L, V);
-            sxm[s] = sxm[s + 2] = eq_quant_lon(-rl, -Kl, L, V);
+            sxl[s] = sxl[s + 2] = eq_lon_base(rl, Kl, L, V.x0f32);
+            sxm[s] = sxm[s + 2] = eq_lon_base(-rl, -Kl, L, V.x0f32);
         }
     } else if (level) {
         int Kl;
         const float rl = eq_atan2_red(x, 1.0f, Kl);       // b = fma(0, yv, 1) = 1 for every row
-        const int sx_left = eq_quant_lon(rl, Kl, L, V), sx_mirror = eq_quant_lon(-rl, -Kl, L, V);
+        const int sx_left = eq_lon_base(rl, Kl, L, V.x0f32), sx_mirror = eq_lon_base(-rl, -Kl, L, V.x0f32);
         const float h = eq_sqrt(__builtin_fmaf(x, x, 1.0f));
 #pragma unroll
         for (int s = 0; s < kHalfRows; ++s) {
@@ -637,8 +738,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
             int Kl, Kt;
             const float rl = eq_atan2_red(xx, bzl, Kl);
             const float rt = eq_atan2_red<true>(cyl, h, Kt);
-            sxl[s] = eq_quant_lon(rl, Kl, L, V);
-            sxm[s] = eq_quant_lon(-rl, -Kl, L, V);
+            sxl[s] = eq_lon_base(rl, Kl, L, V.x0f32);
+            sxm[s] = eq_lon_base(-rl, -Kl, L, V.x0f32);
             sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
         }
         } else {
@@ -661,16 +762,20 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
             int Kl, Kt;
             const float rl = eq_atan2_red(xr, bz, Kl);
             const float rt = eq_atan2_red<true>(cy, h, Kt);
-            sxl[s] = eq_quant_lon(rl, Kl, L, V);
-            sxm[s] = eq_quant_lon(-rl, -Kl, L, V);
+            sxl[s] = eq_lon_base(rl, Kl, L, V.x0f32);
+            sxm[s] = eq_lon_base(-rl, -Kl, L, V.x0f32);
             sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
         }
         }
     }
 
-    // ---- left half, then the mirrored half ---------------------------------------------------------
+    // ---- every member of the ring: left half, then the mirrored half ------------------------------------
+    // sxl / sxm hold the ring-shared longitude part (eq_lon_base); a member adds its integer offset and wraps.  A member
+    // with the opposite pitch sign is the ring's geometry upside down: with sp' = -sp and yv' = -yv (row h-1-j) the forward
+    // component fma(sp, yv, cp) is unchanged and the up component fma(-cp, yv, sp) changes sign, both exactly, so longitude is
+    // the same and latitude is negated (q -> -q, rint is odd) -- the same argument as the horizon mirror of level views.
     BlkStore bs;
-    bs.lds = nullptr; bs.mode = 0; bs.y0 = bs.nrows = bs.yb = bs.nrows_b = bs.sub = 0;
+    bs.lds = nullptr; bs.mode = 0; bs.y0 = bs.nrows = bs.yb = bs.nrows_b = bs.sub = 0; bs.ystep = 1;
     if (blocked) {
         bs.lds = s_blk + wave * 256;
         if (level) {
@@ -688,15 +793,89 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
             bs.nrows = min(max(V.out_h - bs.y0, 0), 4);
         }
     }
-    eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxl, sys, ys, row_ok, x0, n_px, false, base_aligned, false, s_wtab, blocked, bs);
-    // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
-    // centre column is its own mirror and was already written: drop it from the segment.
+    const int W32 = uniform_here(32 * L.W);
     const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
-    if (n_px > (centre_dup ? 1 : 0)) {
-        const int col0 = V.out_w - x0 - n_px;
-        const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
-        eq_pass<C, CUBIC>(L, src, mask, dst, dstride, sxm, sys, ys, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab, blocked, bs);
+    const RowPack rp = make_row_pack();
+    // The 12 shared coordinates of a lane would stay live across the whole member loop on top of the sampler's own peak
+    // (bilinear: 123 registers against the 96 of 5 wavefronts per SIMD).  Each thread parks its own values in LDS and takes
+    // them back at the top of every iteration -- no barrier, a thread only ever reads what it wrote.
+    if constexpr (kParkN > 0) {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            s_park[(kParkN * s + 0) * 64 * kWaves + threadIdx.x] = sys[s];
+            if constexpr (kParkN == 3) {
+                s_park[(3 * s + 1) * 64 * kWaves + threadIdx.x] = sxl[s];
+                s_park[(3 * s + 2) * 64 * kWaves + threadIdx.x] = sxm[s];
+            }
+        }
     }
+    // Everything the loop body reads from the kernel argument is taken into registers HERE, behind an optimisation barrier: left
+    // alone, the compiler re-reads kernel-argument fields inside the loop whenever scalar registers run short (each read is a
+    // scalar-cache round trip the wavefront waits for: five per iteration measured, +20 % time at equal instruction counts).
+    EqSrc S;
+    S.W = uniform_here(L.W);
+    S.H = uniform_here(L.H);
+    S.src_stride = (int64_t)(uint32_t)uniform_here((int)L.src_stride);          // < 2^24 (checked by the host)
+    S.mask_stride = (int64_t)(uint32_t)uniform_here((int)L.mask_stride);        // H * mask_stride < 2^32
+    const int out_h = uniform_here(V.out_h), out_w = uniform_here(V.out_w);
+    const int y0x2 = uniform_here(2 * L.y0i32);
+    const int dst_base = uniform_here(f * L.n_views + k0);
+    auto members = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    // the member's own scalars (x0i32, flip: one 8-byte read; dst) are fetched one iteration ahead
+    int2 mem_next = *reinterpret_cast<const int2*>(&L.view[k0].x0i32);
+    uint8_t* dst_next = L.dst[dst_base];
+#pragma unroll 1
+    for (int m = 0; m < n_members; ++m) {
+        if constexpr (kParkN > 0) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                sys[s] = s_park[(kParkN * s + 0) * 64 * kWaves + tid];
+                if constexpr (kParkN == 3) {
+                    sxl[s] = s_park[(3 * s + 1) * 64 * kWaves + tid];
+                    sxm[s] = s_park[(3 * s + 2) * 64 * kWaves + tid];
+                }
+            }
+        }
+        const int x0i = mem_next.x;
+        const bool flip = mem_next.y != 0;                // wave-uniform
+        uint8_t* dst = dst_next;
+        {
+            const int mn = min(m + 1, n_members - 1);
+            mem_next = *reinterpret_cast<const int2*>(&L.view[k0 + mn].x0i32);
+            dst_next = L.dst[dst_base + mn];
+        }
+        const bool base_aligned = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+        int sx_l[kRowsPerWave], sx_m[kRowsPerWave], sy_m[kRowsPerWave], ys_m[kRowsPerWave];
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            sx_l[s] = eq_lon_wrap(sxl[s], x0i, W32);
+            sx_m[s] = eq_lon_wrap(sxm[s], x0i, W32);
+            sy_m[s] = flip ? y0x2 - sys[s] : sys[s];
+            ys_m[s] = flip ? out_h - 1 - ys[s] : ys[s];
+        }
+        BlkStore bm = bs;
+        if (flip) { bm.y0 = out_h - 1 - bs.y0; bm.ystep = -1; }
+        eq_pass<C, CUBIC, MODE, MASKED>(S, src, mask, dst, dstride, sx_l, sy_m, ys_m, row_ok, x0, n_px, false, base_aligned, false, s_wtab, bm, rp);
+        // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
+        // centre column is its own mirror and was already written: drop it from the segment.
+        if (n_px > (centre_dup ? 1 : 0)) {
+            const int col0 = out_w - x0 - n_px;
+            const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
+            eq_pass<C, CUBIC, MODE, MASKED>(S, src, mask, dst, dstride, sx_m, sy_m, ys_m, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab, bm, rp);
+        }
+    }
+    };
+    if constexpr (kBlocked) {
+        if (blocked) {
+            if (level) members(std::integral_constant<int, 2>{});
+            else members(std::integral_constant<int, 1>{});
+            return;
+        }
+    }
+    members(std::integral_constant<int, 0>{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -938,10 +1117,11 @@ __device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ s
             const int sx = cv_round(mxs[s0 + u] * 32.0f), sy = cv_round(mys[s0 + u] * 32.0f);
             const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
             fast[s0 + u] = ix >= 1 && iy >= 1 && ix <= W - 5 && iy <= H - 3;
-            t[u] = cubic_fetch_rgb(tab, src, (uint32_t)stride, W, H, ix, iy, sx & 31, sy & 31);
+            t[u] = cubic_issue_rgb(src, (uint32_t)stride, W, H, ix, iy, sx & 31, sy & 31);
         }
-        eq_cubic_blend(t[0], px[s0]);
-        eq_cubic_blend(t[1], px[s0 + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        eq_cubic_blend(t[0], tab, px[s0]);
+        eq_cubic_blend(t[1], tab, px[s0 + 1]);
     }
     if (__any(!(fast[0] && fast[1] && fast[2] && fast[3]))) {
         // border windows: ONE copy of the straight-line sampler in a rolled loop (slot picked with uniform selects), so
@@ -982,6 +1162,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
     const int n_px = min(kTileW, L.w - x0);
     const int xc = min(x0 + lane, L.w - 1);
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
+    const RowPack rp = make_row_pack();
     constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
     if ((INTERP == GS360_INTERP_LINEAR || INTERP == GS360_INTERP_NEAREST || kFastCubic) && L.pipelined) {
         // maps of the wavefront's 4 rows -> all gathers in flight -> blend -> border/valid fix-ups -> packed stores
@@ -1024,7 +1205,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
                 for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.fill;
             }
             const int y = ybase + rr;
-            if (y < L.h) store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4);
+            if (y < L.h) store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
         }
         return;
     }
@@ -1042,7 +1223,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
 #pragma unroll
             for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.fill;
         }
-        store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4);
+        store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4, rp);
     }
 }
 
@@ -1069,6 +1250,7 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
     const int xc = min(x0 + lane, V.out_w - 1);
     const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
     const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(V.dst) & 3) == 0);
+    const RowPack rp = make_row_pack();
     const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
 
     const int ybase = tile_y * kTileH + wave * kRowsPerWave;
@@ -1152,7 +1334,7 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
 #pragma unroll
             for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.mask_value;
         }
-        store_row<C>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4);
+        store_row<C>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
         if (V.valid_out && lane < n_px) V.valid_out[(int64_t)y * V.out_w + x0 + lane] = oks[rr] ? 1 : 0;
     }
 }
@@ -1160,23 +1342,37 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+static unsigned eq_grid_blocks(const EqLaunch& L) {
+    if (L.xcd_group_log2 < 0) return (unsigned)(L.chunk * 8);
+    const int per = 8 << L.xcd_group_log2;                 // tiles per round over the XCDs
+    return (unsigned)((L.total_tiles + per - 1) / per * per);
+}
+
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
-    dim3 grid((unsigned)(L.chunk * 8)), block(64 * kWaves);
+    dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
+    const bool masked = L.mask[0] != nullptr;             // all frames or none (checked by the C ABI)
     switch (C) {
-        case 1: hipLaunchKernelGGL((eq_views_kernel<1, false>), grid, block, 0, s, L); break;
-        case 3: hipLaunchKernelGGL((eq_views_kernel<3, false>), grid, block, 0, s, L); break;
-        case 4: hipLaunchKernelGGL((eq_views_kernel<4, false>), grid, block, 0, s, L); break;
+        case 1: if (masked) hipLaunchKernelGGL((eq_views_kernel<1, false, true>), grid, block, 0, s, L);
+                else hipLaunchKernelGGL((eq_views_kernel<1, false, false>), grid, block, 0, s, L); break;
+        case 3: if (masked) hipLaunchKernelGGL((eq_views_kernel<3, false, true>), grid, block, 0, s, L);
+                else hipLaunchKernelGGL((eq_views_kernel<3, false, false>), grid, block, 0, s, L); break;
+        case 4: if (masked) hipLaunchKernelGGL((eq_views_kernel<4, false, true>), grid, block, 0, s, L);
+                else hipLaunchKernelGGL((eq_views_kernel<4, false, false>), grid, block, 0, s, L); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
-    dim3 grid((unsigned)(L.chunk * 8)), block(64 * kWaves);
+    dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
+    const bool masked = L.mask[0] != nullptr;
     switch (C) {
-        case 1: hipLaunchKernelGGL((eq_views_kernel<1, true>), grid, block, 0, s, L); break;
-        case 3: hipLaunchKernelGGL((eq_views_kernel<3, true>), grid, block, 0, s, L); break;
-        case 4: hipLaunchKernelGGL((eq_views_kernel<4, true>), grid, block, 0, s, L); break;
+        case 1: if (masked) hipLaunchKernelGGL((eq_views_kernel<1, true, true>), grid, block, 0, s, L);
+                else hipLaunchKernelGGL((eq_views_kernel<1, true, false>), grid, block, 0, s, L); break;
+        case 3: if (masked) hipLaunchKernelGGL((eq_views_kernel<3, true, true>), grid, block, 0, s, L);
+                else hipLaunchKernelGGL((eq_views_kernel<3, true, false>), grid, block, 0, s, L); break;
+        case 4: if (masked) hipLaunchKernelGGL((eq_views_kernel<4, true, true>), grid, block, 0, s, L);
+                else hipLaunchKernelGGL((eq_views_kernel<4, true, false>), grid, block, 0, s, L); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -9,13 +9,17 @@ from conftest import ROOT
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanemap", ["", "rows", "blocked"])
-def test_fuzz_parity_short(lanemap):
+@pytest.mark.parametrize("lanemap,ring", [("", ""), ("rows", ""), ("blocked", ""), ("", "1"), ("blocked", "3")])
+def test_fuzz_parity_short(lanemap, ring):
+    """lanemap forces one lane map of the equirect kernel, ring caps the members of a yaw ring (1 = no coordinate sharing)"""
     import os
     env = dict(os.environ)
     env.pop("GS360_LANEMAP", None)
+    env.pop("GS360_RING", None)
     if lanemap:
         env["GS360_LANEMAP"] = lanemap
+    if ring:
+        env["GS360_RING"] = ring
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "fuzz_parity.py"), "--seconds", "8", "--seed", "77"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -221,7 +221,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--only", default="", help="comma list of: equirect, fisheye, color (default all)")
-    ap.add_argument("--eq", default="", help="comma list of equirect rows: cfg1,cfg2,cfg2cubic,cfg3,cfg5,cfg5mask (default all)")
+    ap.add_argument("--eq", default="", help="comma list of equirect rows: cfg1,cfg2,cfg2cubic,cfg2u16,cfg2u16cubic,cfg3,cfg1cubic,cfg3cubic,cfg5,cfg5mask (default all)")
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=1)
     rows = []
@@ -246,6 +246,11 @@ def main():
                                              args.steps, interp=gs360.INTERP_CUBIC, dtype=np.uint16),
         "cfg3": lambda: equirect_cfg(ctx, "cfg3 7680x3840 -> full360coverage 12x1600^2", 7680, 3840,
                                      [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps),
+        "cfg1cubic": lambda: equirect_cfg(ctx, "cfg1 with INTER_CUBIC (the tool's own default interp, PC:730)", 5760, 2880, ring_views(8, 1600, HFOV_12MM), 8,
+                                          args.steps, interp=gs360.INTERP_CUBIC),
+        "cfg3cubic": lambda: equirect_cfg(ctx, "cfg3 with INTER_CUBIC", 7680, 3840,
+                                          [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps,
+                                          interp=gs360.INTERP_CUBIC),
         "cfg5": lambda: equirect_cfg(ctx, "cfg5 7680x3840 -> fisheyelike 10x2048^2 (u8, no fp16/mask fusion)", 7680, 3840,
                                      [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps),
         "cfg5mask": lambda: equirect_cfg(ctx, "cfg5 + fused keep-mask multiply (u8 mask, nearest, threshold 128)", 7680, 3840,

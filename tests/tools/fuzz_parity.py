@@ -41,6 +41,28 @@ def fuzz_equirect(ctx, rng, case):
         level = rng.random() < 0.4
         specs.append((float(rng.uniform(-400, 400)), 0.0 if level else float(rng.uniform(-95, 95)),
                       float(rng.uniform(5, 179)), float(rng.uniform(5, 179)), int(rng.integers(1, 200)), int(rng.integers(1, 120))))
+    if rng.random() < 0.5:
+        # yaw rings: the presets' shape (PC:794) -- one pitch magnitude / fov / size, yaw = i * 360 / count so that members differ by
+        # whole texels when count divides W, members with the pitch sign flipped, a duplicate, and (half the time) a member
+        # whose yaw breaks the common sub-texel phase; up to 20 views so that rings are split across launches
+        if rng.random() < 0.5:
+            W = int(rng.choice([8, 12, 24, 48, 96, 240, 360, 480, 600]))
+            src = rng.integers(0, 256, (H, W, c), dtype=np.uint8)
+        count = int(rng.choice([2, 3, 4, 6, 8, 12]))
+        base = specs[0]
+        pitch = 0.0 if rng.random() < 0.35 else float(rng.choice([30.0, -30.0, 90.0, float(rng.uniform(-95, 95))]))
+        off = float(rng.choice([0.0, 0.0, 45.0, float(rng.uniform(-180, 180))]))
+        nv = int(rng.integers(2, 21))
+        specs = []
+        for i in range(nv):
+            yaw = off + (i % count) * 360.0 / count
+            if rng.random() < 0.15:
+                yaw += float(rng.uniform(-3, 3))
+            sign = -1.0 if rng.random() < 0.4 else 1.0
+            specs.append((yaw, sign * pitch, base[2], base[3], base[4], base[5]))
+        if rng.random() < 0.3:
+            specs[int(rng.integers(0, nv))] = (float(rng.uniform(-400, 400)), float(rng.uniform(-95, 95)), float(rng.uniform(5, 179)),
+                                               float(rng.uniform(5, 179)), int(rng.integers(1, 200)), int(rng.integers(1, 120)))
     interp = int(rng.choice([1, 1, 2]))
     spad = int(rng.choice([0, 0, 1, 3, 4, 64]))
     dpad = int(rng.choice([0, 0, 1, 2, 4]))
