@@ -920,9 +920,9 @@ int gs360_color_plan16_create(gs360_ctx* c, const float* lut, int lut_size, cons
     p->L.n_pieces = n_pieces;
     p->L.lut_size = lut_size;
     p->device = c->device;
-    HIP_TRY(hipSetDevice(c->device));
     const size_t n3 = (size_t)lut_size * lut_size * lut_size * 3;
-    hipError_t e = hipMalloc((void**)&p->d_lut, n3 * sizeof(float) + kSlack);
+    hipError_t e = hipSetDevice(c->device);                     // (a failure here must release the host plan too)
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_lut, n3 * sizeof(float) + kSlack);
     if (e == hipSuccess) e = hipMemcpy(p->d_lut, lut, n3 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && total) e = hipMalloc((void**)&p->d_thr, (size_t)total * sizeof(float));
     if (e == hipSuccess && total) e = hipMemcpy(p->d_thr, thresholds, (size_t)total * sizeof(float), hipMemcpyHostToDevice);

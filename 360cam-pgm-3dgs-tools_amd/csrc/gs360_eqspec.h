@@ -110,6 +110,14 @@ __device__ __forceinline__ int eq_lon_wrap(int base, int x0i32, int W32) {
     if (sx >= W32) sx -= W32;
     return sx;
 }
+// The same wrap for the ring-member loop in three operations: with the shared part reduced to [0, 32W) once
+// (eq_lon_norm: it lies in (-32W, 32W) because 18W + 32 < 32W for W >= 3), base + x0i32 is in [0, 64W) and the unsigned minimum
+// of t and t - 32W is t mod 32W.
+__device__ __forceinline__ int eq_lon_norm(int base, int W32) { return base + ((base >> 31) & W32); }
+__device__ __forceinline__ int eq_lon_member(int base_norm, int x0i32, int W32) {
+    const uint32_t t = (uint32_t)(base_norm + x0i32);
+    return (int)min(t, t - (uint32_t)W32);
+}
 __device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, const EqView& V) {
     return eq_lon_wrap(eq_lon_base(r0, K, L, V.x0f32), V.x0i32, 32 * L.W);
 }

@@ -794,6 +794,11 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         }
     }
     const int W32 = uniform_here(32 * L.W);
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) {              // shared longitude parts into [0, 32W): members then wrap with one min
+        sxl[s] = eq_lon_norm(sxl[s], W32);
+        sxm[s] = eq_lon_norm(sxm[s], W32);
+    }
     const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
     const RowPack rp = make_row_pack();
     // The 12 shared coordinates of a lane would stay live across the whole member loop on top of the sampler's own peak
@@ -851,8 +856,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         int sx_l[kRowsPerWave], sx_m[kRowsPerWave], sy_m[kRowsPerWave], ys_m[kRowsPerWave];
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s) {
-            sx_l[s] = eq_lon_wrap(sxl[s], x0i, W32);
-            sx_m[s] = eq_lon_wrap(sxm[s], x0i, W32);
+            sx_l[s] = eq_lon_member(sxl[s], x0i, W32);
+            sx_m[s] = eq_lon_member(sxm[s], x0i, W32);
             sy_m[s] = flip ? y0x2 - sys[s] : sys[s];
             ys_m[s] = flip ? out_h - 1 - ys[s] : ys[s];
         }

@@ -18,7 +18,6 @@ import itertools
 import os
 import threading
 import time
-import zlib
 
 import numpy as np
 
@@ -32,7 +31,7 @@ _LINGER_S = float(os.environ.get("GS360_BATCH_LINGER_MS", "3")) * 1e-3
 
 class _Batch:
     """Views of ONE frame (same interpolation / projection flags) that go out as one launch."""
-    __slots__ = ("views", "state", "done", "results", "error")
+    __slots__ = ("views", "state", "done", "results", "error", "abandoned")
 
     def __init__(self):
         self.views = []                 # capi.View, in arrival order
@@ -40,6 +39,7 @@ class _Batch:
         self.done = threading.Event()
         self.results = None             # list of (ndarray aliasing a pinned buffer, PinnedBuffer)
         self.error = None
+        self.abandoned = set()          # indices of followers that left (cancel) before the results existed
 
 
 class _DeviceState:
@@ -94,10 +94,13 @@ class Engine:
         self.devices = list(devices) if devices is not None else list(range(n))
         self.states = [_DeviceState(d) for d in self.devices]
         self._warned_cubic = False
-        self.videos = {}                          # DecodePlan.key -> video.VideoSession
+        self.videos = {}                          # DecodePlan.key -> the video.VideoSession new view jobs join
+        self._video_done = {}                     # DecodePlan.key -> view jobs finished so far (all sessions of that video)
         self.videos_lock = threading.Lock()
         self._expected = {}                       # str(source path) -> view jobs that can arrive together (announce())
         self._announce_lock = threading.Lock()
+        self._assigned = {}                       # str(source path) -> index into self.states (device_for)
+        self._load = [0] * len(self.states)       # sources assigned per device
 
     def close(self):
         with self.videos_lock:
@@ -116,8 +119,18 @@ class Engine:
 
     # -- sharding ---------------------------------------------------------------------------------
     def device_for(self, src_path) -> int:
-        """frame -> device index (stable hash of the source path: all views of a frame share a device)."""
-        return zlib.crc32(os.fsencode(str(src_path))) % len(self.states)
+        """frame -> device index; all views of a frame share a device.  Sources are dealt to the least-loaded device in the
+        order they become known -- the order of the announced job list when the caller announces one (the drop-in CLI does),
+        else first come first served -- so a folder of n frames occupies min(n, devices) devices with at most one frame of
+        spread (a hash of the path left devices idle by chance on the 6-8 file folders of the presets' typical use)."""
+        key = str(src_path)
+        with self._announce_lock:
+            dev = self._assigned.get(key)
+            if dev is None:
+                dev = min(range(len(self.states)), key=lambda d: (self._load[d], d))
+                self._assigned[key] = dev
+                self._load[dev] += 1
+            return dev
 
     # -- frame residency --------------------------------------------------------------------------
     def _frame_key(self, path):
@@ -216,6 +229,10 @@ class Engine:
                 for d, hb, n in zip(d_out, h_out, sizes):
                     capi._check(L.gs360_download(ctx.handle, hb.ptr, d.ptr, n, slot), L)
                 ctx.sync(slot)
+        except BaseException:
+            for hb in h_out:                      # nobody will ever hold these results: the pinned blocks go back to the pool
+                st.give(st.pin_pool, hb)
+            raise
         finally:
             for d in d_out:
                 st.give(st.dev_pool, d)
@@ -252,7 +269,11 @@ class Engine:
                     b.state = "running"
                     del st.open_batches[key]
                     views = list(b.views)
-                b.results = self._launch_batch(st, buf, H, W, C, views, interp, flags, dtype)
+                res = self._launch_batch(st, buf, H, W, C, views, interp, flags, dtype)
+                with st.batch_cond:
+                    b.results = res
+                    for i in b.abandoned:         # followers that were cancelled meanwhile will not come for their view
+                        st.give(st.pin_pool, res[i][1])
             except BaseException as exc:  # noqa: BLE001  (handed to every member of the batch)
                 with st.batch_cond:
                     if st.open_batches.get(key) is b:
@@ -264,7 +285,12 @@ class Engine:
         else:
             while not b.done.wait(0.25):
                 if stop_event is not None and stop_event.is_set():
-                    break
+                    with st.batch_cond:
+                        if b.results is None:
+                            b.abandoned.add(idx)  # the leader returns this view's pinned block when the launch completes
+                        else:
+                            st.give(st.pin_pool, b.results[idx][1])
+                    raise capi.Gs360Error(-2, "cancelled")
         if b.error is not None:
             if leader:
                 raise b.error
@@ -282,6 +308,8 @@ class Engine:
         with self._announce_lock:
             for k, n in counts.items():
                 self._expected[k] = min(n, workers) if workers else n
+        for k in counts:                          # deal the sources to the devices in job-list order (Counter keeps it)
+            self.device_for(k)
 
     def _expected_for(self, src) -> int:
         with self._announce_lock:
@@ -320,29 +348,35 @@ class Engine:
 
     # -- video: one decode, frames resident in HBM, every view job walks them (gs360/video.py) -------------------
     def _video_session(self, plan, stop_event, register_proc):
+        """-> (session, token).  A job joins the video's current session; when that one has already retired its first frames
+        (a long video under a small budget and a job that starts late) a fresh session -- a second decode -- takes its place
+        for this job and every later one, and the old session is closed by its last job."""
         with self.videos_lock:
             sess = self.videos.get(plan.key)
-            if sess is None:
-                for key in [k for k, s in self.videos.items() if s.active_jobs == 0 and s.finished]:
+            token = sess.join() if sess is not None else None
+            if token is None:
+                for key in [k for k, s in self.videos.items() if s.active_jobs == 0 and s.finished and k != plan.key]:
                     self.videos.pop(key).close()          # idle sessions of other videos give their memory back
+                if sess is not None and sess.active_jobs == 0:
+                    sess.close()
                 sess = self.videos[plan.key] = video.VideoSession(self.states, plan, stop_event, register_proc)
-            sess.active_jobs += 1
-            return sess
+                token = sess.join()
+            return sess, token
 
     def run_video_job(self, job: JobSpec, plan, stop_event=None, register_proc=None, expected_jobs=None) -> int:
         """All frames of one view of a video; returns the number of frames written."""
         view, flags = self._view_for(job)
         interp = self._interp_for(job)
-        sess = self._video_session(plan, stop_event, register_proc)
+        sess, token = self._video_session(plan, stop_event, register_proc)
         written = 0
         try:
             while True:
-                fr = sess.frame(written)
+                fr = sess.frame(token, written)
                 if fr is None:
                     break
                 st, buf, H, W, fdtype = fr
                 # the view jobs of a video walk its frames together: frame k of every active view goes out as one launch
-                out, release = self._render(st, ("video", plan.key, written), lambda: (buf, H, W, 3, fdtype), view, interp, flags,
+                out, release = self._render(st, ("video", id(sess), written), lambda: (buf, H, W, 3, fdtype), view, interp, flags,
                                             expected=min(sess.active_jobs, expected_jobs or sess.active_jobs), stop_event=stop_event)
                 try:
                     imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)
@@ -351,11 +385,16 @@ class Engine:
                 written += 1
         finally:
             with self.videos_lock:
-                sess.active_jobs -= 1
-                sess.done_jobs += 1
-                if expected_jobs and sess.done_jobs >= expected_jobs and sess.active_jobs == 0:
-                    self.videos.pop(plan.key, None)
-                    sess.close()
+                sess.leave(token)
+                self._video_done[plan.key] = self._video_done.get(plan.key, 0) + 1
+                current = self.videos.get(plan.key)
+                all_done = bool(expected_jobs) and self._video_done[plan.key] >= expected_jobs
+                if sess.active_jobs == 0 and (sess is not current or all_done):
+                    sess.close()                          # a superseded session, or the video's last planned view job
+                    if sess is current:
+                        self.videos.pop(plan.key, None)
+                if all_done:
+                    self._video_done.pop(plan.key, None)
         return written
 
 

@@ -75,13 +75,19 @@ def _png_read(data: bytes) -> np.ndarray:
     pos, idat = 8, []
     while pos + 8 <= len(data):
         ln, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        if pos + 12 + ln > len(data):
+            raise ImageIOError(f"truncated PNG: chunk {typ!r} at byte {pos} runs past the end of the file")
         if typ == b"IDAT":
-            idat.append(data[pos + 8:pos + 8 + ln])
+            body = data[pos + 8:pos + 8 + ln]
+            if zlib.crc32(typ + body) & 0xFFFFFFFF != struct.unpack(">I", data[pos + 8 + ln:pos + 12 + ln])[0]:
+                raise ImageIOError(f"corrupt PNG: CRC mismatch in the IDAT chunk at byte {pos}")
+            idat.append(body)
         elif typ == b"IEND":
             break
         pos += 12 + ln
-    if depth not in (8, 16) or ctype not in (0, 2, 6) or interlace:
-        raise ImageIOError("built-in PNG reader handles 8/16-bit gray, RGB and RGBA, non-interlaced (no palette / gray+alpha)")
+    if depth not in (8, 16) or ctype not in (0, 2, 4, 6) or interlace:
+        raise ImageIOError("built-in PNG reader handles non-interlaced 8/16-bit gray, gray+alpha, RGB and RGBA; convert palette / "
+                           "interlaced / 1-2-4-bit files first (e.g. `magick in.png -interlace none -depth 16 out.png`)")
     ch = _COLOR_CH[ctype]
     bpp = ch * depth // 8
     stride = w * bpp
@@ -100,9 +106,10 @@ def _png_read(data: bytes) -> np.ndarray:
         rows = raw.reshape(h, stride + 1).copy()
         _unfilter_py(rows, h, stride, bpp)
     px = np.ascontiguousarray(rows[:, 1:])
-    if depth == 16:
-        return px.view(">u2").astype(np.uint16).reshape(h, w, ch)
-    return px.reshape(h, w, ch)
+    img = px.view(">u2").astype(np.uint16).reshape(h, w, ch) if depth == 16 else px.reshape(h, w, ch)
+    if ctype == 4:                           # gray + alpha -> 4 channels, as cv2.imread(IMREAD_UNCHANGED) delivers it (DF:735)
+        img = np.ascontiguousarray(np.concatenate([np.repeat(img[:, :, :1], 3, axis=2), img[:, :, 1:]], axis=2))
+    return img
 
 
 def _png_write(path: pathlib.Path, arr: np.ndarray, level: int = 3) -> None:
@@ -178,18 +185,31 @@ def _tiff_read16(data: bytes) -> np.ndarray:
     if comp not in (1, 5, 8, 32946):
         raise ImageIOError(f"16-bit TIFF with compression {comp} is not supported (use none, LZW or Deflate); refusing to reduce it to 8 bits")
     if 324 in t:
-        raise ImageIOError("tiled 16-bit TIFF is not supported")
+        raise ImageIOError("tiled 16-bit TIFF is not supported (rewrite it in strips, e.g. `tiffcp -s in.tif out.tif`)")
+    if 273 not in t or 279 not in t or len(t[273]) != len(t[279]):
+        raise ImageIOError("TIFF without consistent StripOffsets / StripByteCounts")
     offs, cnts = t[273], t[279]
     rps = t.get(278, (h,))[0]
+    if rps < 1 or len(offs) * rps < h:
+        raise ImageIOError(f"TIFF strips do not cover the image ({len(offs)} strips of {rps} rows for {h} rows)")
     out = np.empty((h, w * spp), np.uint16)
     y = 0
-    for o, c in zip(offs, cnts):
+    for k, (o, c) in enumerate(zip(offs, cnts)):
+        if y >= h:
+            break
+        if o + c > len(data):
+            raise ImageIOError(f"truncated TIFF: strip {k} ({c} bytes at offset {o}) runs past the end of the file ({len(data)} bytes)")
         blob = data[o:o + c]
         rows = min(rps, h - y)
         if comp == 5:
             blob = _lzw_decode(blob, rows * w * spp * 2)
         elif comp != 1:
-            blob = zlib.decompress(blob)
+            try:
+                blob = zlib.decompress(blob)
+            except zlib.error as exc:
+                raise ImageIOError(f"corrupt TIFF: strip {k} does not inflate ({exc})") from exc
+        if len(blob) < rows * w * spp * 2:
+            raise ImageIOError(f"corrupt TIFF: strip {k} holds {len(blob)} bytes, {rows * w * spp * 2} expected")
         a = np.frombuffer(blob, dtype=e + "u2", count=rows * w * spp).astype(np.uint16).reshape(rows, w * spp)
         if pred == 2:                        # horizontal differencing per sample
             a = np.cumsum(a.reshape(rows, w, spp).astype(np.uint32), axis=1).astype(np.uint16).reshape(rows, w * spp)
@@ -310,7 +330,11 @@ def write_image(path, arr: np.ndarray, jpeg_q: int = None) -> None:
         if ext in (".tif", ".tiff"):
             _tiff_write16(path, a)
             return
-        a = to_uint8(a)                      # JPEG is an 8-bit container (the reference's yuvj444p / cv2.imwrite do the same)
+        # JPEG is an 8-bit container.  PerspCut: ffmpeg converts to yuvj444p, i.e. scales the depth -- the same thing.  The
+        # dual-fisheye tool hands the uint16 array to cv2.imwrite (DF:749, 1215, 1838), whose JPEG encoder SATURATES
+        # (convertTo(CV_8U): everything above 255 becomes 255); writing round(v * 255 / 65535) instead is a deliberate
+        # deviation, not parity.
+        a = to_uint8(a)
     if Image is not None:
         mode = {1: "L", 3: "RGB", 4: "RGBA"}[a.shape[2]]
         im = Image.fromarray(a[:, :, 0] if a.shape[2] == 1 else a, mode)

@@ -4,9 +4,12 @@ The reference plans one ffmpeg process per (video, view) (PC:830-836); each of t
 runs v360 on one thread ("N_views single-thread ffmpeg procs, each re-decoding the input").  Here the
 first view job of a video starts a single decoder process -- the job's own ffmpeg command line with the v360 filter and
 the encoder options removed and `format=rgb24 ... -f image2pipe -c:v ppm pipe:1` appended -- and a reader thread
-uploads every frame to device memory (frames are dealt round-robin over the visible GPUs, so all views of a frame share
-a device and there is no exchange step).  An 8K RGB frame is 88.5 MB: a 288 GB MI355X keeps > 2000 of them, i.e. the
-whole 600-frame workload of BASELINE config 3 stays resident while the 12 view jobs run over it.
+uploads every frame to device memory through two pinned staging blocks per device (the pipe read of one frame overlaps
+the H2D copy of the previous one; frames are dealt round-robin over the visible GPUs, so all views of a frame share a
+device and there is no exchange step).  An 8K RGB frame is 88.5 MB: a 288 GB MI355X keeps > 2000 of them, i.e. the
+whole 600-frame workload of BASELINE config 3 stays resident while the 12 view jobs run over it.  Longer videos stream:
+past the budget (GS360_VIDEO_CACHE_GB per device) the frames every registered view job has consumed are retired and the
+reader waits for the view jobs instead of failing (ffmpeg itself streams, PC:318, PC:746-749).
 
 Two argv shapes are understood (anything else returns None and the caller falls back to the reference's subprocess):
   * the planner's:        -ss S -i V -to T -vf fps=F,colorspace=...,v360=... -vsync vfr -start_number 0 ... out_%07d_X.png
@@ -32,6 +35,7 @@ _ENCODER_OPTIONS = {"-c:v", "-q:v", "-qmin", "-qmax", "-pix_fmt", "-huffman", "-
                     "-color_trc", "-start_number", "-frame_pts", "-threads", "-frames:v", "-loglevel"}
 _DECODER_OPTIONS = {"-ss", "-to", "-t", "-vsync", "-fps_mode", "-r"}
 _BUDGET_BYTES = int(float(os.environ.get("GS360_VIDEO_CACHE_GB", "200")) * (1 << 30))
+_EVENT_BASE = 6                            # HIP events 6 / 7 of the upload slot mark the two staging blocks' copies
 
 
 @dataclass(frozen=True)
@@ -159,28 +163,67 @@ def read_exact_into(stream, mv: memoryview) -> None:
 
 # ---- session ---------------------------------------------------------------------------------------------------
 class VideoSession:
-    """Decoded frames of one video, resident on the engine's devices.  Thread-safe; view jobs call frame(k)."""
+    """Decoded frames of one video on the engine's devices, streamed: the reader keeps at most `budget` bytes resident, view
+    jobs walk the frames with a cursor each, and a frame every registered job has passed is retired when the reader needs
+    the room (before that it stays, so that a view job that joins later still finds the video from its first frame).  The
+    reader blocks -- back-pressure on the decoder's pipe -- while nothing can be retired.  A job that arrives after frames
+    were retired cannot join (join() returns None): the engine starts a second session for it and its fellow late-comers.
+    Thread-safe."""
 
-    def __init__(self, states, plan: DecodePlan, stop_event=None, register_proc=None, budget=_BUDGET_BYTES):
+    def __init__(self, states, plan: DecodePlan, stop_event=None, register_proc=None, budget=None):
         self.states = states
         self.plan = plan
         self.stop_event = stop_event
         self.register_proc = register_proc       # callable(proc, add: bool): lets the caller's cancel handler see the decoder
-        self.budget = budget * max(1, len(states))    # the budget is per device; frames are dealt round-robin
-        self.frames = []                          # (state, DeviceBuffer, H, W)
+        per_device = _BUDGET_BYTES if budget is None else budget
+        self.budget = per_device * max(1, len(states))    # the budget is per device; frames are dealt round-robin
+        self.frames = {}                          # k -> (state, DeviceBuffer, H, W, dtype), k in [first, count)
+        self.first = 0                            # frames below `first` have been retired
+        self.count = 0                            # frames published so far
         self.bytes = 0
+        self.peak_bytes = 0
+        self.retired = 0
         self.finished = False
         self.error: Optional[str] = None
         self.cond = threading.Condition()
+        self.cursors = {}                         # job token -> index of the frame the job is working on (all below are done)
+        self._next_token = 0
         self.active_jobs = 0
         self.done_jobs = 0
+        self.closing = False
         self.proc = None
         self.thread = threading.Thread(target=self._reader, name="gs360-video-decode", daemon=True)
         self.thread.start()
 
     # reader thread ---------------------------------------------------------------------------------------------
+    def _make_room(self, nbytes):
+        """Called by the reader with self.cond held: retire passed frames until `nbytes` more fit, waiting for the view jobs
+        to advance when nothing can go.  A single frame larger than the whole budget is admitted alone."""
+        while self.bytes + nbytes > self.budget and self.bytes > 0:
+            low = min(self.cursors.values()) if self.cursors else self.first      # no job registered: nothing has been passed
+            if self.first < low:
+                st, buf, h, w, dt = self.frames.pop(self.first)
+                self.bytes -= h * w * 3 * np.dtype(dt).itemsize
+                self.first += 1
+                self.retired += 1
+                if st.ctx.handle:
+                    st.ctx.free(buf)
+                continue
+            if self.closing or (self.stop_event is not None and self.stop_event.is_set()):
+                raise PpmError("cancelled")
+            self.cond.wait(timeout=0.25)
+
+    def _publish(self, st, buf, h, w, fdtype, nbytes):
+        with self.cond:
+            self.frames[self.count] = (st, buf, h, w, fdtype)
+            self.count += 1
+            self.bytes += nbytes
+            self.peak_bytes = max(self.peak_bytes, self.bytes)
+            self.cond.notify_all()
+
     def _reader(self):
-        pinned = {}
+        pinned = {}                               # (device, nbytes) -> [two pinned blocks]
+        pending = None                            # (state, event index, publish args) of the upload still in flight
         errlog = None
         try:
             # stderr goes to an unnamed temporary file, not a pipe: a damaged stream can make ffmpeg print more than a pipe
@@ -205,25 +248,36 @@ class VideoSession:
                     raise PpmError("decoder delivered {}-level samples; the engine takes 8- or 16-bit frames".format(maxval + 1))
                 fdtype = np.uint16 if maxval == 65535 else np.uint8
                 nbytes = w * h * 3 * np.dtype(fdtype).itemsize
-                if self.bytes + nbytes > self.budget:
-                    raise PpmError("decoded frames exceed the HBM budget of {:.0f} GB per GPU (GS360_VIDEO_CACHE_GB); lower "
-                                   "--fps, cut the range with --start/--end, or use --engine ffmpeg".format(
-                                       self.budget / len(self.states) / (1 << 30)))
                 st = self.states[k % len(self.states)]
-                stage = pinned.get((id(st), nbytes))
-                if stage is None:
-                    stage = pinned[(id(st), nbytes)] = st.ctx.pinned(nbytes)
+                # two pinned staging blocks per device: the pipe read of frame k overlaps the H2D copy of frame k-1
+                pair = pinned.get((id(st), nbytes))
+                if pair is None:
+                    pair = pinned[(id(st), nbytes)] = [st.ctx.pinned(nbytes), st.ctx.pinned(nbytes)]
+                which = (k // len(self.states)) & 1
+                stage = pair[which]
                 host = np.frombuffer(stage.view, dtype=np.uint8, count=nbytes)      # the pinned block as an array
                 read_exact_into(out, memoryview(host))
                 if fdtype == np.uint16:
                     host.view(np.uint16).byteswap(inplace=True)       # PPM samples are big-endian
-                buf = st.ctx.alloc(nbytes)
-                st.ctx.upload(buf, host, slot=st.upload_slot, sync=True)
+                if pending is not None:           # frame k-1 has had this whole pipe read to land
+                    pst, pev, pargs = pending
+                    pst.ctx.event_sync(pst.upload_slot, pev)
+                    self._publish(*pargs)
+                    pending = None
                 with self.cond:
-                    self.frames.append((st, buf, h, w, fdtype))
-                    self.bytes += nbytes
-                    self.cond.notify_all()
+                    self._make_room(nbytes)
+                buf = st.ctx.alloc(nbytes)
+                ev = _EVENT_BASE + which
+                with st.upload_lock:              # the engine's still-image uploads share this stream (engine.resident_frame)
+                    st.ctx.upload(buf, host, slot=st.upload_slot, sync=False)
+                    st.ctx.event_record(st.upload_slot, ev)
+                pending = (st, ev, (st, buf, h, w, fdtype, nbytes))
                 k += 1
+            if pending is not None:
+                pst, pev, pargs = pending
+                pst.ctx.event_sync(pst.upload_slot, pev)
+                self._publish(*pargs)
+                pending = None
             rc = self.proc.wait()
             if rc != 0:
                 errlog.seek(max(0, errlog.seek(0, os.SEEK_END) - 2000))
@@ -237,9 +291,17 @@ class VideoSession:
                     self.proc.kill()
                 except Exception:
                     pass
+            if pending is not None:               # the copy may still be running: let it finish before its blocks are freed
+                try:
+                    pending[0].ctx.event_sync(pending[0].upload_slot, pending[1])
+                    if pending[0].ctx.handle:
+                        pending[0].ctx.free(pending[2][1])
+                except Exception:
+                    pass
         finally:
-            for stage in pinned.values():
-                stage.free()
+            for pair in pinned.values():
+                for stage in pair:
+                    stage.free()
             if errlog is not None:
                 errlog.close()
             if self.proc is not None and self.register_proc:
@@ -249,14 +311,39 @@ class VideoSession:
                 self.cond.notify_all()
 
     # view jobs -------------------------------------------------------------------------------------------------
-    def frame(self, k: int):
-        """k-th decoded frame as (state, DeviceBuffer, H, W, dtype); None after the last one.  Raises on decoder failure."""
+    def join(self):
+        """Register a view job -> token, or None when the video's first frames have already been retired (a job can only
+        walk the video from its beginning)."""
         with self.cond:
-            while k >= len(self.frames) and not self.finished:
+            if self.first > 0:
+                return None
+            tok = self._next_token
+            self._next_token += 1
+            self.cursors[tok] = 0
+            self.active_jobs += 1
+            return tok
+
+    def leave(self, token):
+        with self.cond:
+            if self.cursors.pop(token, None) is not None:
+                self.active_jobs -= 1
+                self.done_jobs += 1
+            self.cond.notify_all()
+
+    def frame(self, token, k: int):
+        """k-th decoded frame as (state, DeviceBuffer, H, W, dtype) for the job `token`, which thereby declares frames < k
+        done; None after the last one.  Raises on decoder failure."""
+        with self.cond:
+            if token in self.cursors and k > self.cursors[token]:
+                self.cursors[token] = k
+                self.cond.notify_all()            # the reader may be waiting for exactly this
+            while k >= self.count and not self.finished:
                 self.cond.wait(timeout=0.25)
                 if self.stop_event is not None and self.stop_event.is_set():
                     return None
-            if k < len(self.frames):
+            if k < self.count:
+                if k < self.first:
+                    raise PpmError("frame {} was retired before this view job asked for it".format(k))
                 return self.frames[k]
             if self.error:
                 raise PpmError(self.error)
@@ -268,10 +355,14 @@ class VideoSession:
                 self.proc.kill()
             except Exception:
                 pass
+        with self.cond:
+            self.closing = True
+            self.cursors.clear()
+            self.cond.notify_all()
         self.thread.join(timeout=5.0)
         with self.cond:
-            for st, buf, _h, _w, _dt in self.frames:
+            for st, buf, _h, _w, _dt in self.frames.values():
                 if st.ctx.handle:
                     st.ctx.free(buf)
-            self.frames = []
+            self.frames = {}
             self.bytes = 0

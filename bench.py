@@ -11,14 +11,22 @@ Infinity Cache, so every step is served from HBM; measured: 1 frame/step (cache-
 ~18 % faster per frame and are NOT what is reported; 8 frames/step is 1-2 % slower per frame than 16 because a launch's
 last partial round of workgroups weighs twice as much).  `value` = output pixels written by all ranks / wall time.
 
+The timed job is FIXED: `--steps` x `--frames` frame renders.  With N ranks the frames of that job are dealt round-robin
+(gs360/sharding.py, the partition the engine uses), every rank renders its share from its own HBM-resident frames in
+launches of `--frames`, and `value` = the job's pixels / the slowest rank's time: strong scaling of a resident job
+(`"scaling": "strong"`; at N = 1 it is exactly the headline run).  Per-rank times travel in `config.per_rank_seconds`.
+
     python bench.py --gpus 1 --steps 400 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --gpus N ...            # no launcher in the environment: starts that torch.distributed.run itself
 
-Frames x views shard with no exchange step, so every rank runs the same per-GPU workload (weak scaling)
-and no collective touches the data path; torch.distributed is used only for the barrier and the
-max-over-ranks of the elapsed time.
+Frames x views shard with no exchange step, so no collective touches the data path; torch.distributed is used only
+for the barrier, the max-over-ranks of the elapsed time and the gather of the per-rank times.
+
+`--mode job` is BASELINE.json configs[2] kernel-only: `--job-frames` (600) synthetic 8K frames resident in HBM (53 GB on one
+GPU, 600/N per rank) -> `full360coverage` 12 x 1600^2, the state gs360/video.py leaves the devices in after the shared decode
+of a video; frames dealt to the ranks the same way, strong scaling.
 
 `--mode stream` is the host-fed STRONG-scaling companion (BASELINE.json configs[2], reference seam
 gs360_360PerspCut.py:1049-1078): 600 8K frames are dealt round-robin to the ranks (gs360/sharding.py), every frame
@@ -44,6 +52,11 @@ HFOV = 112.61986494804043          # fov_from_focal_mm(12, 36)  (reference PC:77
 #   sum_v U_v = 14,325,324 texels * 3 B = 42,975,972 B   (counted by the oracle; tests/test_oracle_equirect.py)
 ALGO_BYTES_PER_FRAME = 11_520_000 + 14_325_324 * 3
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# The bound a gather that moves whole 128-B lines can reach: every view has to pull each distinct
+# line its taps touch at least once -- 718,080 lines per frame summed over the six views (119,680 each; counted from the
+# oracle's map, tests/test_oracle_equirect.py) -- plus the stores, at the 6.29 TB/s the HBM sustains for streaming copies.
+LINE_BYTES_PER_FRAME = 718_080 * 128 + 11_520_000
+HBM_STREAM_GBS = 6290.0
 
 
 def norm_yaw(a):
@@ -210,6 +223,75 @@ def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
         emit(line)
 
 
+FULL360 = [(0, 0), (45, 30), (45, -30), (90, 0), (135, 30), (135, -30), (180, 0), (-135, 30), (-135, -30), (-90, 0), (-45, 30), (-45, -30)]
+HFOV_14MM = 104.2500326978036                    # fov_from_focal_mm(14, 36): the full360coverage preset (PC:614-626)
+
+
+def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
+    """BASELINE.json configs[2], kernel-only: the job's frames are dealt to the ranks, each rank keeps its share resident in HBM
+    (frame k = image B rolled 13 k px) and renders the 12 full360coverage views of every frame, 16 frames per launch."""
+    from gs360.sharding import frames_for_rank
+    size = args.job_size
+    specs = [(float(y), float(p), HFOV_14MM, HFOV_14MM, size, size) for y, p in FULL360]
+    views = [gs360.View.make(*v) for v in specs]
+    mine = frames_for_rank(args.job_frames, world, rank)
+    t_up = time.perf_counter()
+    d_frames = [ctx.to_device(synth_frame(np, k)) for k in mine]
+    t_up = time.perf_counter() - t_up
+    batch = gs360.capi.MAX_FRAMES
+    d_out = [ctx.alloc(size * size * C) for _ in range(batch * len(views))]
+    calls = []
+    for b0 in range(0, len(d_frames), batch):
+        fr = d_frames[b0:b0 + batch]
+        calls.append(ctx.make_equirect_call(fr, W, H, C, views, d_out[:len(fr) * len(views)], slot=0))
+    for c in calls[:2]:
+        c()
+    barrier()
+    ctx.event_record(0, 0)
+    t0 = time.perf_counter()
+    for c in calls:
+        c()
+    ctx.event_record(0, 1)
+    ctx.sync(-1)
+    local = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.event_elapsed_ms(0, 0, 1) if calls else 0.0
+    per_rank = [round(local, 6)]
+    if dist is not None:
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mine_t = torch.tensor([local], dtype=torch.float64, device=dev)
+        all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        per_rank = [round(float(x.item()), 6) for x in all_t]
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline and calls:
+        from oracle import orc
+        orc.build()
+        last0 = (len(calls) - 1) * batch                  # the last batch is still in d_out: two views of its first frame
+        want = orc.equirect_views_u8(synth_frame(np, mine[last0]), [orc.make_view(*specs[v]) for v in (1, 6)], threads=0)
+        parity = all(np.array_equal(ctx.download(d_out[v], (size, size, C)), w) for v, w in zip((1, 6), want))
+    if rank == 0:
+        px = args.job_frames * len(views) * size * size
+        emit({
+            "metric": "MPix/s remapped, 8K equirect->preset views", "value": round(px / elapsed / 1e6, 1), "unit": "MPix/s",
+            "n_gpus": world, "steps": args.job_frames, "warmup": 2, "ms_per_step": round(elapsed * 1e3 / max(1, args.job_frames), 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"RESIDENT JOB (not the headline): {args.job_frames} 7680x3840x3 frames resident in HBM, dealt round-robin to "
+                                   f"{world} rank(s) -> full360coverage 12x{size}x{size}, {batch} frames per launch, kernel-only "
+                                   "(BASELINE.json configs[2])",
+                       "frames_total": args.job_frames, "frames_rank0": len(mine), "views": len(views), "device": info["name"],
+                       "resident_GB_rank0": round(len(mine) * W * H * C / 1e9, 1), "upload_s_rank0": round(t_up, 1),
+                       "parallelism": f"frames sharded x{world}, no collective", "parity_vs_oracle": parity,
+                       "frames_per_s": round(args.job_frames / elapsed, 1), "per_rank_seconds": per_rank,
+                       "rank0_kernel_us_per_frame": round(kernel_ms * 1e3 / max(1, len(mine)), 2)},
+            "roofline": None, "cpu_baseline": None,
+        })
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,9 +303,12 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (gloo: control-flow tests on a box "
                          "with fewer GPUs than ranks; ranks then share devices round-robin)")
-    ap.add_argument("--mode", default="resident", choices=["resident", "stream"],
-                    help="resident (default, the headline): HBM-resident cfg2 launches, weak scaling; stream: host-fed cfg3 frames "
-                         "dealt to the ranks, strong scaling, PCIe-bound")
+    ap.add_argument("--mode", default="resident", choices=["resident", "job", "stream"],
+                    help="resident (default, the headline): a fixed job of steps x frames HBM-resident cfg2 frame renders dealt to the ranks; "
+                         "job: BASELINE configs[2] kernel-only (600 resident 8K frames -> 12 x 1600^2, dealt to the ranks); "
+                         "stream: host-fed cfg3 frames dealt to the ranks, PCIe-bound.  All three are strong scaling")
+    ap.add_argument("--job-frames", type=int, default=600, help="--mode job: frames of the job (all ranks); 88.5 MB of HBM each")
+    ap.add_argument("--job-size", type=int, default=1600, help="--mode job: view size (full360coverage: 1600)")
     ap.add_argument("--stream-frames", type=int, default=600, help="--mode stream: total frames of the job (all ranks)")
     ap.add_argument("--stream-size", type=int, default=1600, help="--mode stream: view size (full360coverage: 1600)")
     ap.add_argument("--stride-pad", type=int, default=0, help="experiments only: extra bytes per source row")
@@ -298,6 +383,13 @@ def main():
         if use_dist:
             dist.destroy_process_group()
         return
+    if args.mode == "job":
+        job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist if use_dist else None, torch)
+        ctx.close()
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    from gs360.sharding import frames_for_rank
     views = [gs360.View.make(*v) for v in view_table()]
     nf = max(1, min(args.frames, gs360.capi.MAX_FRAMES))
     frames_host = [synth_frame(np, k + 7 * rank) for k in range(nf)]
@@ -313,22 +405,41 @@ def main():
         d_frames = [ctx.to_device(f) for f in frames_host]
     d_out = [ctx.alloc(SIZE * SIZE * C) for _ in range(nf * N_VIEWS)]
     step = ctx.make_equirect_call(d_frames, W, H, C, views, d_out, slot=0, src_stride=stride if args.stride_pad else 0)
+    # the fixed job: steps x nf frame renders, dealt round-robin; this rank renders its share in launches of nf (+ one short one)
+    n_mine = len(frames_for_rank(args.steps * nf, world, rank))
+    full, rem = divmod(n_mine, nf)
+    step_rem = (ctx.make_equirect_call(d_frames[:rem], W, H, C, views, d_out[:rem * N_VIEWS], slot=0,
+                                       src_stride=stride if args.stride_pad else 0) if rem else None)
 
     for _ in range(args.warmup):
         step()
     barrier()
     ctx.event_record(0, 0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(full):
         step()
+    if step_rem is not None:
+        step_rem()
     ctx.event_record(0, 1)
+    ctx.sync(-1)
+    local = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ctx.event_elapsed_ms(0, 0, 1) / max(1, args.steps)   # HIP events on the launch stream
+    kernel_ms_total = ctx.event_elapsed_ms(0, 0, 1)                  # HIP events on the launch stream
+    kernel_ms = kernel_ms_total * nf / max(1, n_mine)                # per full launch of nf frames
+    per_rank = [round(local, 6)]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine_t = torch.tensor([local], dtype=torch.float64, device=dev)
+        all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        per_rank = [round(float(x.item()), 6) for x in all_t]
+    if rem or full == 0:
+        step()                                                       # leave a full batch in d_out for the check below
+        ctx.sync(-1)
 
     # correctness spot-check of what was timed (rank 0): frame 0 against the oracle, plus the CPU baseline
     cpu = None
@@ -348,7 +459,7 @@ def main():
     if rank == 0:
         px_per_step = nf * N_VIEWS * SIZE * SIZE
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
-        value = world * px_per_step * args.steps / elapsed / 1e6
+        value = px_per_step * args.steps / elapsed / 1e6             # the whole fixed job / the slowest rank's time
         baseline_shape = (W == 7680 and args.stride_pad == 0)   # ALGO_BYTES_PER_FRAME was counted for the 7680-wide source only
         algo_bytes = ALGO_BYTES_PER_FRAME * nf
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -364,20 +475,27 @@ def main():
         line = {
             "metric": "MPix/s remapped, 8K equirect->preset views",
             "value": round(value, 1), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("" if W == 7680 else f"EXPERIMENT {W}x{H} source, NOT the baseline workload: ") +
                                    "7680x3840x3 u8 equirect -> --preset default --count 6 --size 800 (6x800x800), "
                                    "bilinear 1/32-px fixed point (BASELINE.json configs[1])",
                        "frames_per_step": nf, "views": N_VIEWS, "out_px_per_step": px_per_step,
                        "device": info["name"], "parallelism": f"frames sharded x{world}, no collective",
+                       "job": f"{args.steps} steps x {nf} frames = {args.steps * nf} frame renders, dealt round-robin to {world} rank(s)",
+                       "frames_rank0": n_mine, "per_rank_seconds": per_rank,
                        "parity_vs_oracle": parity},
             "roofline": None if not baseline_shape else {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          # same launch time against the bytes the PMC counters saw move (whole 128-B lines), for context
                          "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                          "kernel": "eq_views_kernel<3>", "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         # the reachable bound next to the algorithmic one: distinct 128-B lines per view + stores at the
+                         # measured streaming rate; frac = launch time at that bound / measured launch time
+                         "line_bound": {"bytes_per_launch": LINE_BYTES_PER_FRAME * nf, "peak": HBM_STREAM_GBS, "unit": "GB/s",
+                                        "achieved": round(LINE_BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9, 1),
+                                        "frac": round(LINE_BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9 / HBM_STREAM_GBS, 4)}},
             "cpu_baseline": cpu,
         }
         emit(line)

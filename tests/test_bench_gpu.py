@@ -26,10 +26,25 @@ def _run(args, timeout=900):
 
 def test_bench_self_launch_two_ranks_share_device0():
     d = _run(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--frames", "2"])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["parity_vs_oracle"] is True
+    assert d["config"]["frames_rank0"] == 3 and len(d["config"]["per_rank_seconds"]) == 2      # 3 x 2 frame renders dealt to 2 ranks
     assert d["cpu_baseline"] is None                   # the timed CPU sample is an N=1 item
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel_ms"] > 0
+    assert 0 < d["roofline"]["line_bound"]["frac"] < 1.5
+
+
+def test_bench_single_rank_line_matches_the_contract():
+    d = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["frames_per_step"] == 16 and d["config"]["frames_rank0"] == 48
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 16 * 54495972
+    assert d["roofline"]["line_bound"]["bytes_per_launch"] == 16 * (718080 * 128 + 11520000)
+
+
+def test_bench_job_mode_two_ranks():
+    d = _run(["--gpus", "2", "--backend", "gloo", "--mode", "job", "--job-frames", "5", "--job-size", "256"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 5
+    assert d["config"]["frames_rank0"] == 3 and d["config"]["parity_vs_oracle"] is True and d["value"] > 0
 
 
 def test_bench_stream_mode_strong_scaling_two_ranks():

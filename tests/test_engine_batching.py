@@ -100,3 +100,34 @@ def test_leader_failure_reaches_every_member(monkeypatch):
     eng2, st2 = make_engine(monkeypatch, launches), st
     out, errs = run_jobs(eng2, st2, [5, 6], expected=2, frame_calls=frame_calls)
     assert not errs and len(out) == 2
+
+
+def test_cancelled_follower_does_not_strand_its_pinned_block(monkeypatch):
+    """a follower that leaves on stop_event while the launch is still running never collects its view: the leader hands the
+    pinned block back to the pool when the results exist (round-2 ADVICE, engine.py:211)"""
+    monkeypatch.setattr(engine, "_LINGER_S", 0.2)
+    launches = []
+    eng, st = make_engine(monkeypatch, launches, delay=0.8), FakeState()
+    stop = threading.Event()
+    res, errs = {}, {}
+
+    def job(y, ev):
+        try:
+            arr, release = eng._render(st, "frameA", lambda: ("devbuf", 8, 16, 3, np.uint8), capi.View.make(y, 0, 90, 90, 4, 2),
+                                       capi.INTERP_LINEAR, 0, expected=2, stop_event=ev)
+            res[y] = int(arr[0, 0, 0])
+            release()
+        except Exception as exc:  # noqa: BLE001
+            errs[y] = exc
+    lead = threading.Thread(target=job, args=(0, None))
+    lead.start()
+    time.sleep(0.05)
+    foll = threading.Thread(target=job, args=(60, stop))
+    foll.start()
+    time.sleep(0.4)                       # both joined, the (slow) launch is running
+    stop.set()
+    foll.join(5)
+    lead.join(5)
+    assert res == {0: 0} and list(errs) == [60] and "cancelled" in str(errs[60])
+    assert len(launches) == 1 and len(launches[0]) == 2
+    assert sorted(b[1] for b in st.given_back) == [0.0, 60.0]     # the leader's own block and the abandoned one both came back

@@ -114,6 +114,26 @@ def test_algorithmic_bytes_constant_of_bench(orc):
     assert [tuple(v) for v in bench.view_table()] == [tuple(s) for s in ring_views(6, 800, HFOV_12MM)]
 
 
+def test_line_bound_constant_of_bench(orc):
+    """bench.py's LINE_BYTES_PER_FRAME: distinct 128-B source lines the bilinear taps of each cfg2 view touch (frame base
+    128-B aligned, tight rows), summed over the six views, x 128 B + the stores."""
+    import bench
+    W, H = 7680, 3840
+    per_view = []
+    for spec in ring_views(6, 800, HFOV_12MM):
+        sx, sy = orc.equirect_map(orc.make_view(*spec), W, H)
+        ix, iy = (sx >> 5).astype(np.int64), (sy >> 5).astype(np.int64)
+        ix1 = np.where(ix + 1 == W, 0, ix + 1)
+        lines = []
+        for yy in (np.clip(iy, 0, H - 1), np.clip(iy + 1, 0, H - 1)):
+            for xx in (ix, ix1):
+                first = (yy * W + xx) * 3
+                lines += [(first >> 7).ravel(), ((first + 2) >> 7).ravel()]
+        per_view.append(int(np.unique(np.concatenate(lines)).size))
+    assert per_view == [119_680] * 6
+    assert bench.LINE_BYTES_PER_FRAME == sum(per_view) * 128 + 6 * 800 * 800 * 3 == 103_434_240
+
+
 # ---- equidistant-fisheye OUTPUT (the fisheyeXY preset's v360 output=fisheye jobs, PC:351-414) ---------------------
 def truth_fisheye_xy(spec, W, H):
     """float64: image-plane radius r <-> 90 r degrees off axis (equidistant), pitch about X, yaw about Y, lon/lat"""

@@ -227,3 +227,150 @@ def test_video_gui_selection_numbering_and_decoder_failure(tmp_path, orc):
     odd[odd.index("-pix_fmt") + 1] = "gbrp12le"
     rc, text = cut.run_one(odd)
     assert rc == 3 and "only the PPM pipe decoder role" in text
+
+
+# ---- streaming residency (host logic; the decoder double runs as a real child process, device memory is faked) ------------
+class _FakeCtx:
+    handle = 1
+
+    def __init__(self):
+        self.live = {}
+        self.n = 0
+        self.lock = __import__("threading").Lock()
+
+    class _Pinned:
+        def __init__(self, n):
+            self.view = memoryview(bytearray(n))
+
+        def free(self):
+            pass
+
+    def pinned(self, nbytes):
+        return self._Pinned(nbytes)
+
+    def alloc(self, nbytes):
+        with self.lock:
+            self.n += 1
+            self.live[self.n] = None
+            return self.n
+
+    def upload(self, buf, host, slot=0, sync=True):
+        self.live[buf] = np.array(host, copy=True)
+
+    def event_record(self, slot, idx):
+        pass
+
+    def event_sync(self, slot, idx):
+        pass
+
+    def free(self, buf):
+        with self.lock:
+            del self.live[buf]
+
+
+class _FakeState:
+    def __init__(self):
+        import threading
+        self.ctx = _FakeCtx()
+        self.upload_slot = 3
+        self.upload_lock = threading.Lock()
+
+
+def _decode_plan(tmp_path, clip_name="clip.npy"):
+    argv = (sys.executable, str(FAKE), "-hide_banner", "-loglevel", "error", "-nostdin", "-i", str(tmp_path / clip_name),
+            "-vf", "format=rgb24", "-an", "-f", "image2pipe", "-c:v", "ppm", "pipe:1")
+    return video.DecodePlan(argv, (str(tmp_path / clip_name), argv[1:]), None, 0)
+
+
+def test_session_streams_three_times_its_budget_and_late_joiners_fall_back(tmp_path):
+    """12 frames of 24 KB through a 2-device session with 16 KB per device (32 KB = one frame and a bit): the reader must retire
+    what both view jobs have passed and wait for them otherwise; every job still sees every frame, in order, intact; a job that
+    arrives after the first frames are gone cannot join."""
+    import threading
+    import time
+    clip = make_clip(tmp_path / "clip.npy", n=12, h=64, w=128)
+    states = [_FakeState(), _FakeState()]
+    sess = video.VideoSession(states, _decode_plan(tmp_path), budget=16 << 10)
+    toks = [sess.join(), sess.join()]
+    assert toks == [0, 1]
+    seen = {0: [], 1: []}
+
+    def walk(tok, delay):
+        k = 0
+        while True:
+            fr = sess.frame(tok, k)
+            if fr is None:
+                break
+            st, buf, h, w, dt = fr
+            seen[tok].append(st.ctx.live[buf].reshape(h, w, 3).copy())
+            time.sleep(delay)
+            k += 1
+        sess.leave(tok)
+    threads = [threading.Thread(target=walk, args=(0, 0.0)), threading.Thread(target=walk, args=(1, 0.01))]
+    for t in threads:
+        t.start()
+    time.sleep(0.15)
+    probe = sess.join()                                       # once frames were retired a newcomer is turned away
+    if probe is not None:
+        assert sess.first == 0
+        sess.leave(probe)                                     # (it would otherwise hold every frame back)
+    for t in threads:
+        t.join(20)
+    assert sess.error is None and sess.finished
+    for tok in (0, 1):
+        assert len(seen[tok]) == 12 and all(np.array_equal(a, b) for a, b in zip(seen[tok], clip))
+    assert sess.retired >= 9 and sess.peak_bytes <= 2 * (16 << 10) + 24576   # streamed: never more than the budget (+ the frame in flight)
+    assert sess.join() is None                                # frames 0.. are gone: late joiners need their own decode
+    sess.close()
+    assert all(not st.ctx.live for st in states)              # every device frame was freed
+
+
+def test_session_without_pressure_keeps_everything_for_late_joiners(tmp_path):
+    clip = make_clip(tmp_path / "clip.npy", n=5, h=16, w=32)
+    sess = video.VideoSession([_FakeState()], _decode_plan(tmp_path), budget=1 << 20)
+    a = sess.join()
+    k = 0
+    while sess.frame(a, k) is not None:
+        k += 1
+    sess.leave(a)
+    assert k == 5 and sess.retired == 0
+    b = sess.join()                                           # a view job that starts after the first one finished
+    assert b is not None
+    st, buf, h, w, dt = sess.frame(b, 4)
+    assert np.array_equal(st.ctx.live[buf].reshape(h, w, 3), clip[4])
+    sess.leave(b)
+    sess.close()
+
+
+def test_closing_a_blocked_session_releases_the_reader(tmp_path):
+    make_clip(tmp_path / "clip.npy", n=8, h=64, w=128)
+    sess = video.VideoSession([_FakeState()], _decode_plan(tmp_path), budget=30 << 10)   # one frame fits, nobody consumes
+    import time
+    time.sleep(0.5)
+    assert not sess.finished and sess.count >= 1
+    sess.close()
+    assert sess.finished and not sess.thread.is_alive()
+
+
+@pytest.mark.gpu
+def test_video_streams_past_the_budget_on_the_gpu(tmp_path, orc, monkeypatch):
+    """the whole path with a budget of ~two frames: 10 frames x 3 views with only TWO workers, so that the third view job
+    starts after the first frames were retired and is served by a second decode -- every output still equals the oracle"""
+    import gs360_360PerspCut as cut
+    from gs360 import engine
+    clip = make_clip(tmp_path / "clip.npy", n=10, h=64, w=128)
+    monkeypatch.setattr(video, "_BUDGET_BYTES", 2 * 64 * 128 * 3 + 100)
+    res = plan_jobs(tmp_path, ["-f", "1", "--ext", "png", "--count", "3", "--size", "40"], ffmpeg=fake_ffmpeg_program(tmp_path), name="clip.npy")
+    (tmp_path / "out").mkdir()
+    cut.stop_event.clear()
+    monkeypatch.setenv("GS360_INTERP", "linear")
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        results = list(pool.map(cut.run_one, [cmd for cmd, _s, _d in res.jobs]))
+    assert results == [(0, "")] * 3, results
+    assert not engine.get_engine().videos
+    for y, tag in ((0.0, "A"), (120.0, "B"), (-120.0, "C")):
+        for n in range(10):
+            got = imageio.read_image(tmp_path / "out" / f"clip_{n:07d}_{tag}.png")
+            want = orc.equirect_views_u8(clip[n], [orc.make_view(y, 0.0, HFOV_12MM, HFOV_12MM, 40, 40)])[0]
+            assert np.array_equal(got, want), (tag, n)
