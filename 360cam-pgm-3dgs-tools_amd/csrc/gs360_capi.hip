@@ -547,7 +547,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // Views whose EQ-SPEC constants agree in everything but the integer longitude offset x0i32 -- and possibly the sign of the
     // pitch -- form a ring: the kernel evaluates a tile's coordinates once and samples it for every member (the presets'
     // yaw steps are whole texels: `yaw = i * 360 / count`, PC:794).  Float equality of the rounded constants is the criterion,
-    // so the grouping can never change a result.  The 16-bit kernel evaluates per pixel: one-view rings.
+    // so the grouping can never change a result.
     static_assert(sizeof(EqLaunch) <= 4096, "EqLaunch travels as a kernel argument");
     const bool fish = (flags & GS360_EQ_FISHEYE_OUT) != 0;
     try {
@@ -555,20 +555,15 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     for (int k = 0; k < n_views; ++k) {
         make_eq_view(views[k], W, fish, &ev[k]);
         ev[k].flip = 0;
-        if (esize == 2) {        // the 16-bit kernel walks whole rows of the full view: plain 64 x 16 tiling
-            ev[k].level = 0;
-            ev[k].blocked = 0;
-            ev[k].tiles_x = (views[k].width + kTileW - 1) / kTileW;
-            ev[k].tiles_y = (views[k].height + kTileH - 1) / kTileH;
-        }
+        if (esize == 2) ev[k].blocked = 0;   // 16-bit samples: row-per-slot lane map only
     }
     // Ring size: unlimited for the row-per-slot lane map (arithmetic-bound views: cfg3 119 -> 99 -> 95 -> 93 us per frame for
     // rings of 1 / 2 / 3 / 4-8 views).  Views on the blocked lane map are memory-bound and gain nothing from shared arithmetic,
     // while a workgroup that walks six views in a row lengthens the launch's tail (cfg2 20.3 -> 22.6 us per frame): no sharing.
-    int ring_max = esize == 2 ? 1 : GS360_MAX_VIEWS, ring_max_blocked = 1;
+    int ring_max = GS360_MAX_VIEWS, ring_max_blocked = 1;
     if (const char* e = std::getenv("GS360_RING")) {       // tests / probes: 1 = no sharing anywhere, n = at most n views per ring
         int v = std::atoi(e);
-        if (v >= 1 && esize != 2) ring_max = ring_max_blocked = v < GS360_MAX_VIEWS ? v : GS360_MAX_VIEWS;
+        if (v >= 1) ring_max = ring_max_blocked = v < GS360_MAX_VIEWS ? v : GS360_MAX_VIEWS;
     }
     std::vector<std::vector<int>> rings;
     for (int k = 0; k < n_views; ++k) {
@@ -706,37 +701,53 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     return gs360_remap_tables_u8(c, &J, 1, C, interp, border_value, slot);
 }
 
-int gs360_remap_table_u16(gs360_ctx* c, const void* src, int H, int W, int C, size_t src_stride, const float* map_x,
-                          const float* map_y, const uint8_t* valid, int h, int w, int interp,
-                          const double* border_value, int fill_value, void* dst, size_t dst_stride, int slot) {
+int gs360_remap_tables_u16(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs, int C, int interp,
+                           const double* border_value, int slot) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
-    if (!src || !map_x || !map_y || !dst) return fail(GS360_ERR_ARG, "NULL argument");
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(GS360_ERR_ARG, "bad job list");
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
-    if (H < 1 || W < 1 || H >= 32767 || W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", W, H);
-    if (h < 0 || w < 0 || h >= 32767 || w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", w, h);
     if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_NEAREST && interp != GS360_INTERP_CUBIC &&
         interp != GS360_INTERP_LANCZOS4)
         return fail(GS360_ERR_UNSUPPORTED, "interp %d not implemented (nearest=0, linear=1, cubic=2, lanczos4=4)", interp);
-    if (h == 0 || w == 0) return GS360_OK;
-    if (src_stride == 0) src_stride = (size_t)W * C * 2;
-    if (dst_stride == 0) dst_stride = (size_t)w * C * 2;
-    if (src_stride < (size_t)W * C * 2 || dst_stride < (size_t)w * C * 2) return fail(GS360_ERR_ARG, "stride smaller than a row");
-    if ((src_stride | dst_stride) & 1) return fail(GS360_ERR_ARG, "16-bit images need even strides");
-    HIP_TRY(hipSetDevice(c->device));
-    TableLaunch L;
-    std::memset(&L, 0, sizeof(L));
-    L.src = (const uint8_t*)src; L.map_x = map_x; L.map_y = map_y; L.valid = valid; L.dst = (uint8_t*)dst;
-    L.H = H; L.W = W; L.h = h; L.w = w;
-    L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
-    L.interp = interp;
-    L.fill = fill_value < 0 ? 0 : (fill_value > 65535 ? 65535 : fill_value);
     uint16_t cval[4];
     for (int k = 0; k < 4; ++k) {      // cv::saturate_cast<ushort>(double)
         long r = std::lrint(border_value ? border_value[k] : 0.0);
         cval[k] = (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
     }
-    HIP_TRY(launch_table_u16(L, C, c->d_coef1d, cval, c->stream[slot]));
+    HIP_TRY(hipSetDevice(c->device));
+    for (int j0 = 0; j0 < n_jobs; j0 += GS360_MAX_VIEWS) {
+        TableBatch B;
+        B.n_jobs = 0;
+        for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
+            const gs360_remap_job& J = jobs[j];
+            if (!J.src || !J.map_x || !J.map_y || !J.dst) return fail(GS360_ERR_ARG, "NULL argument");
+            if (J.H < 1 || J.W < 1 || J.H >= 32767 || J.W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", J.W, J.H);
+            if (J.h < 0 || J.w < 0 || J.h >= 32767 || J.w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", J.w, J.h);
+            if (J.h == 0 || J.w == 0) continue;
+            const size_t src_stride = J.src_stride ? J.src_stride : (size_t)J.W * C * 2;
+            const size_t dst_stride = J.dst_stride ? J.dst_stride : (size_t)J.w * C * 2;
+            if (src_stride < (size_t)J.W * C * 2 || dst_stride < (size_t)J.w * C * 2) return fail(GS360_ERR_ARG, "stride smaller than a row");
+            if ((src_stride | dst_stride) & 1) return fail(GS360_ERR_ARG, "16-bit images need even strides");
+            TableLaunch& L = B.job[B.n_jobs++];
+            std::memset(&L, 0, sizeof(L));
+            L.src = (const uint8_t*)J.src; L.map_x = J.map_x; L.map_y = J.map_y; L.valid = J.valid; L.dst = (uint8_t*)J.dst;
+            L.H = J.H; L.W = J.W; L.h = J.h; L.w = J.w;
+            L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
+            L.interp = interp;
+            L.fill = J.fill_value < 0 ? 0 : (J.fill_value > 65535 ? 65535 : J.fill_value);
+        }
+        if (B.n_jobs) HIP_TRY(launch_table_u16_batch(B, C, c->d_coef1d, cval, c->stream[slot]));
+    }
     return GS360_OK;
+}
+
+int gs360_remap_table_u16(gs360_ctx* c, const void* src, int H, int W, int C, size_t src_stride, const float* map_x,
+                          const float* map_y, const uint8_t* valid, int h, int w, int interp,
+                          const double* border_value, int fill_value, void* dst, size_t dst_stride, int slot) {
+    gs360_remap_job J;
+    J.src = src; J.H = H; J.W = W; J.src_stride = src_stride; J.map_x = map_x; J.map_y = map_y; J.valid = valid;
+    J.h = h; J.w = w; J.fill_value = fill_value; J.dst = dst; J.dst_stride = dst_stride;
+    return gs360_remap_tables_u16(c, &J, 1, C, interp, border_value, slot);
 }
 
 // ---- fused fisheye -> views --------------------------------------------------------------------

@@ -27,6 +27,7 @@
 
 #include "gs360_kernels.h"
 #include "gs360_eqspec.h"
+#include "gs360_rowstore.h"
 
 #ifndef GS360_EXPERIMENT
 #define GS360_EXPERIMENT 0   // 1 / 2: scratch probes used while profiling (never built into lib/)
@@ -153,22 +154,6 @@ __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s
 // row leaves as 4-byte stores (lane j writes bytes 4j..4j+3 = tail of pixel 4j/3 + head of the next one).
 // skip_first drops position 0 (the centre column of an odd-width view, which is its own mirror); the caller then
 // passes aligned4 = false and the per-lane byte path below handles it.
-// The two per-lane constants of the dword re-slicing are computed once per tile by the caller (RowPack): inside the
-// ring-member loop of eq_views_kernel they must neither be recomputed by every one of the 8 row stores of an iteration nor
-// be left to the compiler's hoisting, which drags every other invariant of the store paths along and spills.
-struct RowPack {
-    int a4;   // 4 * ((4 * lane) / 3): ds_bpermute address of the first pixel contributing to dword `lane` of the row
-    int sh;   // 8 * ((4 * lane) % 3): its bit offset
-    int lane;
-};
-__device__ __forceinline__ RowPack make_row_pack() {
-    const int lane = threadIdx.x & 63, t = lane / 3;
-    RowPack rp;
-    rp.a4 = 4 * (lane + t);
-    rp.sh = 8 * (lane - 3 * t);
-    rp.lane = lane;
-    return rp;
-}
 template <int C>
 __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4, const RowPack& rp,
                                           bool reversed = false, bool skip_first = false) {
@@ -591,6 +576,220 @@ __device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restric
     eq_store<C, MODE>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, blk, rp);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16-bit samples (16-bit stills keep their depth through the reference's ffmpeg path, PC:327-347; > 8-bit videos leave as
+// rgb48le, PC:343-347): the equirect kernel's skeleton -- mirror / horizon symmetry, yaw rings, paired row gathers, all gathers
+// of a pass in flight -- with 2-byte elements.  Same quantised coordinates and the same integer arithmetic as the 8-bit
+// sampler: bilinear (sum S a b + 512) >> 10, bicubic with the fixed-point Keys table, columns wrap, rows clamp.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t acc) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), acc, false);
+}
+__device__ __forceinline__ uint16_t ld_u16(const uint8_t* p) {
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
+
+// RGB bilinear: the two taps of a row are 12 contiguous bytes -> one dword-aligned 16-byte read per row (rows paired across
+// the wavefront halves like the 8-bit fetch), shifted into place afterwards.
+struct Eq16Taps {
+    uint32_t a[4], b[4];
+    uint32_t sh;          // (o0 & 3) | (o1 & 3) << 2
+    bool fix;
+};
+__device__ __forceinline__ Eq16Taps eq16_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, int W, int H, int sx, int sy) {
+    const int ix = sx >> 5, iy = sy >> 5;
+    const int y0 = max(iy, 0), y1 = min(iy + 1, H - 1);
+    const int ixl = min(ix, W - 3);                        // the 16-byte read of the 12 tap bytes stays inside the row
+    const uint32_t col = (uint32_t)ixl * 6u;
+    const uint32_t o0 = __umul24((uint32_t)y0, stride) + col, o1 = __umul24((uint32_t)y1, stride) + col;
+    Eq16Taps t;
+    t.fix = ix != ixl;
+    t.sh = (o0 & 3u) | ((o1 & 3u) << 2);
+    const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0 & ~3u, o1 & ~3u, false, false);
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { t.a[k] = qa[k]; t.b[k] = qb[k]; }
+    return t;
+}
+__device__ __forceinline__ void eq16_blend_rgb(const Eq16Taps& t, int sx, int sy, uint32_t (&out)[4]) {
+    uint32_t r0[4], r1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32x2 d = __builtin_amdgcn_permlane32_swap(t.a[k], t.b[k], false, false);   // .x = row y0, .y = row y1, own pixel
+        r0[k] = d.x; r1[k] = d.y;
+    }
+    const uint32_t s0 = t.sh & 3u, s1 = t.sh >> 2;
+    // halfwords of a row: R0 G0 | B0 R1 | G1 B1
+    const uint32_t d0 = __builtin_amdgcn_alignbyte(r0[1], r0[0], s0), d1 = __builtin_amdgcn_alignbyte(r0[2], r0[1], s0),
+                   d2 = __builtin_amdgcn_alignbyte(r0[3], r0[2], s0);
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(r1[1], r1[0], s1), e1 = __builtin_amdgcn_alignbyte(r1[2], r1[1], s1),
+                   e2 = __builtin_amdgcn_alignbyte(r1[3], r1[2], s1);
+    const int fx = sx & 31, fy = sy & 31;
+    const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);
+    const uint32_t wr0 = ah * (uint32_t)(32 - fy), wr1 = ah * (uint32_t)fy;       // (a0 b | a1 b << 16), a1 b <= 1024
+    // v_perm_b32 pairs the two taps of a channel (bytes 0..3 come from the second operand, 4..7 from the first), v_dot2_u32_u16
+    // multiplies both by the packed weights: sum <= 65535 * 1024 + 512 < 2^32
+    out[0] = udot2_u16(__builtin_amdgcn_perm(e1, e0, 0x07060100u), wr1, udot2_u16(__builtin_amdgcn_perm(d1, d0, 0x07060100u), wr0, 512u)) >> 10;
+    out[1] = udot2_u16(__builtin_amdgcn_perm(e2, e0, 0x05040302u), wr1, udot2_u16(__builtin_amdgcn_perm(d2, d0, 0x05040302u), wr0, 512u)) >> 10;
+    out[2] = udot2_u16(__builtin_amdgcn_perm(e2, e1, 0x07060100u), wr1, udot2_u16(__builtin_amdgcn_perm(d2, d1, 0x07060100u), wr0, 512u)) >> 10;
+}
+// any channel count, horizontal wrap: element by element (also the repair path of the RGB fast path)
+template <int C>
+__device__ __forceinline__ void eq16_sample_slow(const uint8_t* __restrict__ src, int64_t stride, int W, int H, int sx, int sy, uint32_t (&out)[4]) {
+    const int fx = sx & 31, ix = sx >> 5, fy = sy & 31, iy = sy >> 5;
+    const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
+    const uint8_t* r0 = src + (int64_t)y0 * stride;
+    const uint8_t* r1 = src + (int64_t)y1 * stride;
+    const uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
+    const int ix1 = (ix + 1 == W) ? 0 : ix + 1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const uint32_t acc = ((uint32_t)ld_u16(r0 + 2 * (ix * C + c)) * a0 + (uint32_t)ld_u16(r0 + 2 * (ix1 * C + c)) * a1) * b0 +
+                             ((uint32_t)ld_u16(r1 + 2 * (ix * C + c)) * a0 + (uint32_t)ld_u16(r1 + 2 * (ix1 * C + c)) * a1) * b1;
+        out[c] = (acc + 512u) >> 10;
+    }
+}
+
+// RGB bicubic: the four taps of a window row are 24 contiguous bytes -> seven dwords from the dword boundary below them.
+// sum w S over 16 taps needs 34 bits; with S = S' + 32768 (S' signed: one XOR per dword) it is sum w S' + 32768 * sum w, and
+// sum w = 32768 for every phase of the table (the fix-up of OpenCV's initInterTab2D; asserted in tests/test_u16.py), while
+// |sum w S'| <= 32768 * sum |w| < 2^31 (sum |w| <= 1.9 * 32768): the 16 products accumulate exactly in v_dot2_i32_i16.
+struct Eq16CubicTaps {
+    uint32_t r[4][7];
+    uint32_t sh;
+    int phase;
+    bool fix;
+};
+__device__ __forceinline__ Eq16CubicTaps eq16_cubic_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, int W, int H, int sx, int sy) {
+    const int ix = sx >> 5, iy = sy >> 5;
+    Eq16CubicTaps t;
+    const int x0 = min(max(ix - 1, 0), W - 5);              // 28-byte aligned read of 24 tap bytes stays in-row
+    t.fix = (x0 != ix - 1);
+    t.phase = (sy & 31) * 32 + (sx & 31);
+    t.sh = 0;
+    const uint32_t col = (uint32_t)x0 * 6u;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
+        const uint8_t* p = src + off;
+        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t.r[ky][k] = q[k];
+        t.sh |= o << (2 * ky);
+    }
+    return t;
+}
+// selector of v_perm_b32(a = dword of halfword e1, b = dword of halfword e0): (h_e0 | h_e1 << 16)
+#define GS360_PAIR16(e0, e1) ((uint32_t)(2 * ((e0) & 1)) | ((uint32_t)(2 * ((e0) & 1) + 1) << 8) | ((uint32_t)(4 + 2 * ((e1) & 1)) << 16) | \
+                              ((uint32_t)(5 + 2 * ((e1) & 1)) << 24))
+__device__ __forceinline__ void eq16_cubic_blend_rgb(const Eq16CubicTaps& t, const int16_t* wtab, uint32_t (&out)[4]) {
+    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
+    const uint4 wa = wq[0], wb = wq[1];
+    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint32_t o = (t.sh >> (2 * ky)) & 3u;
+        uint32_t d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = __builtin_amdgcn_alignbyte(t.r[ky][k + 1], t.r[ky][k], o) ^ 0x80008000u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                     // halfword e = 3 kx + c of the row's twelve
+            acc[c] = dot2_i16(__builtin_amdgcn_perm(d[(3 + c) >> 1], d[c >> 1], GS360_PAIR16(c, 3 + c)), wpk[2 * ky], acc[c]);
+            acc[c] = dot2_i16(__builtin_amdgcn_perm(d[(9 + c) >> 1], d[(6 + c) >> 1], GS360_PAIR16(6 + c, 9 + c)), wpk[2 * ky + 1], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int64_t v = ((int64_t)acc[c] + (1ll << 30) + (1 << 14)) >> 15;
+        out[c] = (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+    }
+}
+template <int C>
+__device__ __forceinline__ void eq16_cubic_slow(const EqSrc& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
+    const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
+    const int16_t* wt = wtab + (fy * 32 + fx) * 16;
+    int cols[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+        const int xx = ix - 1 + kx;
+        cols[kx] = xx < 0 ? xx + L.W : (xx >= L.W ? xx - L.W : xx);
+    }
+    int64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint8_t* row = src + (int64_t)min(max(iy - 1 + ky, 0), L.H - 1) * L.src_stride;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int w = wt[ky * 4 + kx];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += (int64_t)((int)ld_u16(row + 2 * (cols[kx] * C + c)) * w);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int64_t v = (acc[c] + (1 << 14)) >> 15;
+        out[c] = (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+    }
+}
+
+// one pass (see eq_pass) over the wavefront's four row slots, 16-bit samples, row-per-slot lane map
+template <int C, bool CUBIC>
+__device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restrict__ src, uint8_t* dst, int64_t dstride,
+                                          const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
+                                          const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
+                                          int col0, int n_px, bool reversed, bool aligned4, bool skip_first,
+                                          const int16_t* wtab, const RowPack& rp) {
+    uint32_t px[kRowsPerWave][4];
+    const bool wide = (C == 3) && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)L.src_stride) & 1) == 0 && L.W >= 8;
+    if constexpr (C == 3) {
+      if (wide) {
+        if constexpr (CUBIC) {
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {      // one slot at a time: 8 row reads (28 dwords) in flight
+                const Eq16CubicTaps t = eq16_cubic_issue_rgb(src, (uint32_t)L.src_stride, L.W, L.H, sxs[s], sys[s]);
+                __builtin_amdgcn_sched_barrier(0);
+                eq16_cubic_blend_rgb(t, wtab, px[s]);
+                if (__any(t.fix)) {
+                    if (t.fix) eq16_cubic_slow<C>(L, wtab, src, sxs[s], sys[s], px[s]);
+                }
+            }
+        } else {
+            Eq16Taps taps[kRowsPerWave];
+            bool any_fix = false;
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                taps[s] = eq16_issue_rgb(src, (uint32_t)L.src_stride, L.W, L.H, sxs[s], sys[s]);
+                any_fix |= taps[s].fix;
+            }
+            __builtin_amdgcn_sched_barrier(0);            // every gather of the pass is in flight before the first is consumed
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) eq16_blend_rgb(taps[s], sxs[s], sys[s], px[s]);
+            if (__any(any_fix)) {
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s)
+                    if (taps[s].fix) eq16_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
+            }
+        }
+      }
+    }
+    if (!wide) {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            if constexpr (CUBIC) eq16_cubic_slow<C>(L, wtab, src, sxs[s], sys[s], px[s]);
+            else eq16_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s)
+        if (row_ok[s]) store_row16<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * (2 * C), px[s], n_px, aligned4, rp, reversed, skip_first);
+}
+
 // equirect -> rectilinear views.  The pinhole grid is mirror-symmetric about the view's vertical axis:
 // x(w-1-i) = -x(i) exactly, so latitude (even in x) is shared by the pixel pair (i, w-1-i) and longitude only
 // changes sign before the final fma/rint.  Level views (pitch 0) are also symmetric about the horizon:
@@ -601,8 +800,8 @@ __device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restric
 // row-per-slot lane map: 3 / 4 / 6 wavefronts: 27.4 / 23.1 / 24.3; blocked lane map: 3 / 4 / 5 / 6: 22.1 / 20.8 / 20.3 /
 // 23.3 (6 spills).  5 is also the better choice for the arithmetic-bound large-view configs (cfg1/3/5).  The cubic
 // variant needs 128 VGPRs and stays at 4.
-template <int C, bool CUBIC, bool MASKED>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUBIC ? GS360_EQC_WAVES : GS360_EQ_WAVES, CUBIC ? GS360_EQC_WAVES : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
+template <int C, bool CUBIC, bool MASKED, int ES = 1>      // ES: bytes per sample (1: uint8, 2: uint16 -- row-per-slot lane map, no mask)
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES, (CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
     // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk), or -- when the launch mixes rings of
     // different sizes, whose tiles differ in cost -- runs of 2^g consecutive tiles dealt round-robin to the XCDs
     int b = blockIdx.x;
@@ -622,10 +821,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
         __syncthreads();
     }
-    constexpr bool kBlocked = (C == 3) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map, see below
+    constexpr bool kBlocked = (C == 3) && (ES == 1) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map, see below
     // LDS: the blocked store's transpose slices (256 dwords per wavefront; its read-back may touch the dword after the slice,
     // which is the next slice or the first parked dword -- never used), then the parked ring coordinates (see below)
-    constexpr int kParkN = CUBIC ? GS360_RING_PARK_CUBIC : GS360_RING_PARK;     // 0 none, 1 latitude only, 3 all three
+    constexpr int kParkN = (CUBIC && ES == 2) ? 3 : (CUBIC ? GS360_RING_PARK_CUBIC : GS360_RING_PARK);     // 0 none, 1 latitude only, 3 all three
     constexpr int kBlkDw = kBlocked ? kWaves * 256 : 0;
     constexpr int kParkDw = kParkN * kRowsPerWave * 64 * kWaves;
     __shared__ uint32_t s_lds[kBlkDw + (kParkDw ? kParkDw : 4)];
@@ -649,7 +848,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
                                                           // active for the store shuffles)
     const uint8_t* __restrict__ src = L.src[f];
     const uint8_t* __restrict__ mask = L.mask[f];
-    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
+    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C * ES;
     const float x = (float)(2 * xl + 1 - V.out_w) * V.sxu;
 
     // ---- row slots of this wavefront -------------------------------------------------------------
@@ -863,13 +1062,15 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(CUB
         }
         BlkStore bm = bs;
         if (flip) { bm.y0 = out_h - 1 - bs.y0; bm.ystep = -1; }
-        eq_pass<C, CUBIC, MODE, MASKED>(S, src, mask, dst, dstride, sx_l, sy_m, ys_m, row_ok, x0, n_px, false, base_aligned, false, s_wtab, bm, rp);
+        if constexpr (ES == 2) eq_pass16<C, CUBIC>(S, src, dst, dstride, sx_l, sy_m, ys_m, row_ok, x0, n_px, false, base_aligned && ((x0 * C * 2) & 3) == 0, false, s_wtab, rp);
+        else eq_pass<C, CUBIC, MODE, MASKED>(S, src, mask, dst, dstride, sx_l, sy_m, ys_m, row_ok, x0, n_px, false, base_aligned, false, s_wtab, bm, rp);
         // mirrored segment: columns [w - x0 - n_px, w - x0), lane l holds column w-1-x0-l.  With an odd width the
         // centre column is its own mirror and was already written: drop it from the segment.
         if (n_px > (centre_dup ? 1 : 0)) {
             const int col0 = out_w - x0 - n_px;
-            const bool m_aligned = base_aligned && (((col0 * C) & 3) == 0) && !centre_dup;
-            eq_pass<C, CUBIC, MODE, MASKED>(S, src, mask, dst, dstride, sx_m, sy_m, ys_m, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab, bm, rp);
+            const bool m_aligned = base_aligned && (((col0 * C * ES) & 3) == 0) && !centre_dup;
+            if constexpr (ES == 2) eq_pass16<C, CUBIC>(S, src, dst, dstride, sx_m, sy_m, ys_m, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab, rp);
+            else eq_pass<C, CUBIC, MODE, MASKED>(S, src, mask, dst, dstride, sx_m, sy_m, ys_m, row_ok, col0, n_px, true, m_aligned, centre_dup, s_wtab, bm, rp);
         }
     }
     };
@@ -1379,6 +1580,26 @@ hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
         case 4: if (masked) hipLaunchKernelGGL((eq_views_kernel<4, true, true>), grid, block, 0, s, L);
                 else hipLaunchKernelGGL((eq_views_kernel<4, true, false>), grid, block, 0, s, L); break;
         default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_equirect_u16(const EqLaunch& L, int C, bool cubic, hipStream_t s) {
+    dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
+    if (cubic) {
+        switch (C) {
+            case 1: hipLaunchKernelGGL((eq_views_kernel<1, true, false, 2>), grid, block, 0, s, L); break;
+            case 3: hipLaunchKernelGGL((eq_views_kernel<3, true, false, 2>), grid, block, 0, s, L); break;
+            case 4: hipLaunchKernelGGL((eq_views_kernel<4, true, false, 2>), grid, block, 0, s, L); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (C) {
+            case 1: hipLaunchKernelGGL((eq_views_kernel<1, false, false, 2>), grid, block, 0, s, L); break;
+            case 3: hipLaunchKernelGGL((eq_views_kernel<3, false, false, 2>), grid, block, 0, s, L); break;
+            case 4: hipLaunchKernelGGL((eq_views_kernel<4, false, false, 2>), grid, block, 0, s, L); break;
+            default: return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }

@@ -17,6 +17,7 @@
 // First-cut kernels: one output pixel per lane per row slot, straight-line samplers, 2-byte-element gathers.  They are
 // HBM-bound byte gathers like their 8-bit siblings but carry none of the tuned fetch paths yet.
 #include "gs360_eqspec.h"
+#include "gs360_rowstore.h"
 
 namespace gs360 {
 
@@ -29,166 +30,109 @@ __device__ __forceinline__ int cv_round_u16(float v) {
 __device__ __forceinline__ int sat_s16_u16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ uint16_t sat_u16(float v) { return (uint16_t)min(max(cv_round_u16(v), 0), 65535); }
 
-template <int C, bool CUBIC>
-__global__ __launch_bounds__(64 * kWaves) void eq_views_u16_kernel(const EqLaunch L) {
-    int b = blockIdx.x;
-    int t = (b & 7) * L.chunk + (b >> 3);
-    if (t >= L.total_tiles) return;
-    int f = t / L.tiles_per_frame;
-    int r = t - f * L.tiles_per_frame;
-    int k = 0;
-    while (k + 1 < L.n_views && r >= L.view[k + 1].tile_base) ++k;
-    const EqView& V = L.view[k];
-    r -= V.tile_base;
-    const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = tile_x * kTileW + lane;
-    if (i >= V.out_w) return;
-    const uint16_t* __restrict__ src = reinterpret_cast<const uint16_t*>(L.src[f]);
-    const size_t ss = (size_t)L.src_stride >> 1;                       // elements per source row
-    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C * 2;
-    uint8_t* dst = L.dst[f * L.n_views + k];
-    const int W = L.W, H = L.H;
-#pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s) {
-        const int j = tile_y * kTileH + wave * kRowsPerWave + s;
-        if (j >= V.out_h) break;
-        int sx, sy;
-        eq_coord_px(L, V, i, j, sx, sy);
-        const int fx = sx & 31, ix = sx >> 5, fy = sy & 31, iy = sy >> 5;
-        uint16_t* out = reinterpret_cast<uint16_t*>(dst + (int64_t)j * dstride) + (size_t)i * C;
-        if constexpr (!CUBIC) {
-            const int ix1 = (ix + 1 == W) ? 0 : ix + 1;
-            const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
-            const uint16_t* r0 = src + (size_t)y0 * ss;
-            const uint16_t* r1 = src + (size_t)y1 * ss;
-            const uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
-            if constexpr (C == 3) {
-                // the two RGB taps of a row are 12 contiguous bytes: one dword-aligned 16-byte read per row (the frame base
-                // is 4-byte aligned, device buffers carry 64 bytes of slack) shifted into place, instead of six 2-byte loads
-                if (ix1 != 0 && ix + 3 <= W && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)L.src_stride) & 3) == 0) {
-                    uint32_t d[2][3];
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const uint16_t* p = (rr ? r1 : r0) + (size_t)ix * 3;
-                        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;        // 0 or 2
-                        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const uint8_t*>(p) - o, 4));
-                        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                        d[rr][0] = __builtin_amdgcn_alignbyte(q1, q0, o);
-                        d[rr][1] = __builtin_amdgcn_alignbyte(q2, q1, o);
-                        d[rr][2] = __builtin_amdgcn_alignbyte(q3, q2, o);
-                    }
-                    // samples: R0 G0 | B0 R1 | G1 B1
-                    const uint32_t s00[3] = {d[0][0] & 0xffffu, d[0][0] >> 16, d[0][1] & 0xffffu};
-                    const uint32_t s01[3] = {d[0][1] >> 16, d[0][2] & 0xffffu, d[0][2] >> 16};
-                    const uint32_t s10[3] = {d[1][0] & 0xffffu, d[1][0] >> 16, d[1][1] & 0xffffu};
-                    const uint32_t s11[3] = {d[1][1] >> 16, d[1][2] & 0xffffu, d[1][2] >> 16};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) out[c] = (uint16_t)(((s00[c] * a0 + s01[c] * a1) * b0 + (s10[c] * a0 + s11[c] * a1) * b1 + 512u) >> 10);
-                    continue;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const uint32_t acc = ((uint32_t)r0[ix * C + c] * a0 + (uint32_t)r0[ix1 * C + c] * a1) * b0 +
-                                     ((uint32_t)r1[ix * C + c] * a0 + (uint32_t)r1[ix1 * C + c] * a1) * b1;
-                out[c] = (uint16_t)((acc + 512u) >> 10);
-            }
-        } else {
-            const int16_t* wt = L.cubic_tab + (fy * 32 + fx) * 16;
-            int cols[4];
-#pragma unroll
-            for (int kx = 0; kx < 4; ++kx) {
-                const int xx = ix - 1 + kx;
-                cols[kx] = xx < 0 ? xx + W : (xx >= W ? xx - W : xx);
-            }
-            int64_t acc[4] = {0, 0, 0, 0};
-            if constexpr (C == 3) {
-                // the four RGB taps of a window row are 24 contiguous bytes: seven dwords from the dword boundary below them
-                // (dwordx4 + dwordx3) shifted into place, instead of twelve 2-byte loads per row
-                if (ix >= 1 && ix + 4 <= W && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)L.src_stride) & 3) == 0) {
-#pragma unroll
-                    for (int ky = 0; ky < 4; ++ky) {
-                        const uint16_t* p = src + (size_t)min(max(iy - 1 + ky, 0), H - 1) * ss + (size_t)(ix - 1) * 3;
-                        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;        // 0 or 2
-                        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const uint8_t*>(p) - o, 4));
-                        uint32_t r[7];
-#pragma unroll
-                        for (int t = 0; t < 7; ++t) r[t] = q[t];
-                        uint32_t d[6];
-#pragma unroll
-                        for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(r[t + 1], r[t], o);
-#pragma unroll
-                        for (int kx = 0; kx < 4; ++kx) {
-                            const int w = wt[ky * 4 + kx];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const int e = kx * 3 + c;                                      // sample index within the row's 12
-                                const int v = (int)((e & 1) ? (d[e >> 1] >> 16) : (d[e >> 1] & 0xffffu));
-                                acc[c] += (int64_t)(v * w);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int64_t v = (acc[c] + (1 << 14)) >> 15;
-                        out[c] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
-                    }
-                    continue;
-                }
-            }
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const uint16_t* row = src + (size_t)min(max(iy - 1 + ky, 0), H - 1) * ss;
-#pragma unroll
-                for (int kx = 0; kx < 4; ++kx) {
-                    const int w = wt[ky * 4 + kx];
-#pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] += (int64_t)((int)row[(size_t)cols[kx] * C + c] * w);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int64_t v = (acc[c] + (1 << 14)) >> 15;
-                out[c] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
-            }
-        }
-    }
-}
-
 // cv2.remap(CV_16U) -- see the file header.  coef: 32 phases x (2 + 4 + 8) float32 1-D coefficients (linear, cubic, lanczos4).
+// All jobs of a call (the views of a dual-fisheye pair) in ONE launch, tiles dealt to the XCDs in contiguous chunks like the
+// 8-bit kernel: six 1750^2 launches left a fifth of the machine idle in their tails.
 template <int C>
-__global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const TableLaunch T, const float* __restrict__ coef, const uint16_t c0,
+__global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const TableBatch B, const float* __restrict__ coef, const uint16_t c0,
                                                                       const uint16_t c1, const uint16_t c2, const uint16_t c3) {
-    const int tiles_x = (T.w + kTileW - 1) / kTileW;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    int t = (blockIdx.x & 7) * B.chunk + (blockIdx.x >> 3);
+    if (t >= B.total_tiles) return;
+    int j = 0;
+    while (j + 1 < B.n_jobs && t >= B.job[j + 1].tile_base) ++j;
+    const TableLaunch& T = B.job[j];          // wave-uniform: fields are read from the kernel argument on demand
+    t -= T.tile_base;
+    const int tiles_x = T.tiles_x;
+    const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = tile_x * kTileW + lane;
-    if (x >= T.w) return;
+    const int x0t = tile_x * kTileW;
+    const int n_px = min(kTileW, T.w - x0t);
+    const int x = min(x0t + lane, T.w - 1);   // lanes past the edge redo the last column: every lane stays active for the packed stores
     const uint16_t cval[4] = {c0, c1, c2, c3};
     const uint16_t* __restrict__ src = reinterpret_cast<const uint16_t*>(T.src);
     const size_t ss = (size_t)T.src_stride >> 1;
     const int W = T.W, H = T.H, interp = T.interp;
     const int ks = interp == GS360_INTERP_LINEAR ? 2 : (interp == GS360_INTERP_CUBIC ? 4 : 8);
     const float* tab = coef + (interp == GS360_INTERP_LINEAR ? 0 : (interp == GS360_INTERP_CUBIC ? 64 : 192));
-#pragma unroll 1
-    for (int s = 0; s < kRowsPerWave; ++s) {
-        const int y = tile_y * kTileH + wave * kRowsPerWave + s;
-        if (y >= T.h) break;
-        const size_t p = (size_t)y * T.w + x;
-        uint16_t* out = reinterpret_cast<uint16_t*>(T.dst + (int64_t)y * T.dst_stride) + (size_t)x * C;
-        if (T.valid && !T.valid[p]) {
+    // the job's fields as values (read once), the maps and valid flags of the wavefront's four rows in flight together
+    const float* __restrict__ map_x = T.map_x;
+    const float* __restrict__ map_y = T.map_y;
+    const uint8_t* __restrict__ vmask = T.valid;
+    uint8_t* const dst = T.dst;
+    const int64_t dst_stride = T.dst_stride;
+    const int tw = T.w, th = T.h, fill = T.fill;
+    const int ybase = tile_y * kTileH + wave * kRowsPerWave;
+    float mxs[kRowsPerWave], mys[kRowsPerWave];
+    bool inval[kRowsPerWave], done[kRowsPerWave];
+    uint32_t px[kRowsPerWave][4];
 #pragma unroll
-            for (int c = 0; c < C; ++c) out[c] = (uint16_t)T.fill;
-            continue;
+    for (int s = 0; s < kRowsPerWave; ++s) {
+        const size_t p = (size_t)min(ybase + s, th - 1) * tw + x;
+        mxs[s] = map_x[p];
+        mys[s] = map_y[p];
+        inval[s] = vmask && !vmask[p];
+        done[s] = false;
+    }
+    if constexpr (C == 3) {
+        // bilinear, RGB, windows inside the image: the two row reads of ALL four slots (dword-aligned 16-byte reads of the 12 tap
+        // bytes) and their weight reads are issued before any is consumed; float32 blend in OpenCV's expression order
+        if (interp == GS360_INTERP_LINEAR && W >= 8 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)T.src_stride) & 1) == 0) {
+            uint32_t ra[kRowsPerWave][4], rb[kRowsPerWave][4], sh[kRowsPerWave];
+            float2 cys[kRowsPerWave], cxs[kRowsPerWave];
+            bool fast[kRowsPerWave];
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                const int sx = cv_round_u16(mxs[s] * 32.0f), sy = cv_round_u16(mys[s] * 32.0f);
+                const int ix = sat_s16_u16(sx >> 5), iy = sat_s16_u16(sy >> 5);
+                fast[s] = !inval[s] && ix >= 0 && iy >= 0 && ix + 3 <= W && iy + 2 <= H && ybase + s < th;
+                const int xa = min(max(ix, 0), W - 3), ya = min(max(iy, 0), H - 2);
+                const uint8_t* p0 = reinterpret_cast<const uint8_t*>(src) + (size_t)ya * (size_t)T.src_stride + (size_t)xa * 6;
+                const uint8_t* p1 = p0 + (size_t)T.src_stride;
+                const uint32_t o0 = (uint32_t)reinterpret_cast<uintptr_t>(p0) & 3u, o1 = (uint32_t)reinterpret_cast<uintptr_t>(p1) & 3u;
+                sh[s] = o0 | (o1 << 2);
+                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p0 - o0, 4));
+                const uint32_t* q1 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p1 - o1, 4));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ra[s][k] = q0[k]; rb[s][k] = q1[k]; }
+                cys[s] = *reinterpret_cast<const float2*>(tab + (sy & 31) * 2);
+                cxs[s] = *reinterpret_cast<const float2*>(tab + (sx & 31) * 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                if (!fast[s]) continue;
+                const uint32_t o0 = sh[s] & 3u, o1 = sh[s] >> 2;
+                const uint32_t d[2][3] = {{__builtin_amdgcn_alignbyte(ra[s][1], ra[s][0], o0), __builtin_amdgcn_alignbyte(ra[s][2], ra[s][1], o0),
+                                           __builtin_amdgcn_alignbyte(ra[s][3], ra[s][2], o0)},
+                                          {__builtin_amdgcn_alignbyte(rb[s][1], rb[s][0], o1), __builtin_amdgcn_alignbyte(rb[s][2], rb[s][1], o1),
+                                           __builtin_amdgcn_alignbyte(rb[s][3], rb[s][2], o1)}};
+                float v[2][6];
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky) {
+                    v[ky][0] = (float)(d[ky][0] & 0xffffu); v[ky][1] = (float)(d[ky][0] >> 16); v[ky][2] = (float)(d[ky][1] & 0xffffu);
+                    v[ky][3] = (float)(d[ky][1] >> 16); v[ky][4] = (float)(d[ky][2] & 0xffffu); v[ky][5] = (float)(d[ky][2] >> 16);
+                }
+                const float w00 = cys[s].x * cxs[s].x, w01 = cys[s].x * cxs[s].y, w10 = cys[s].y * cxs[s].x, w11 = cys[s].y * cxs[s].y;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[s][c] = sat_u16(v[0][c] * w00 + v[0][3 + c] * w01 + v[1][c] * w10 + v[1][3 + c] * w11);
+                done[s] = true;
+            }
         }
-        const float mx = T.map_x[p], my = T.map_y[p];
+    }
+    // one pixel, straight-line (every interpolation, borders, any channel count): the rolled loop below runs it for the slots the
+    // batched path above did not finish
+    auto sample_one = [&](float mx, float my, bool iv, uint32_t (&out)[4]) {
+        if (iv) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) out[c] = (uint32_t)fill;
+            return;
+        }
         if (interp == GS360_INTERP_NEAREST) {
             const int ix = sat_s16_u16(cv_round_u16(mx)), iy = sat_s16_u16(cv_round_u16(my));
             const bool in = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
 #pragma unroll
             for (int c = 0; c < C; ++c) out[c] = in ? src[(size_t)iy * ss + (size_t)ix * C + c] : cval[c];
-            continue;
+            return;
         }
         const int sx = cv_round_u16(mx * 32.0f), sy = cv_round_u16(my * 32.0f);
         const int fx = sx & 31, fy = sy & 31;
@@ -197,7 +141,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
         if (x0 >= W || x0 + ks <= 0 || y0 >= H || y0 + ks <= 0) {
 #pragma unroll
             for (int c = 0; c < C; ++c) out[c] = cval[c];
-            continue;
+            return;
         }
         const float* cy = tab + fy * ks;
         const float* cx = tab + fx * ks;
@@ -251,7 +195,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) out[c] = sat_u16(sum[c]);
-                continue;
+                return;
             }
         }
 #pragma unroll
@@ -288,7 +232,30 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
             }
             out[c] = sat_u16(sum);
         }
+    };
+    static_assert(kRowsPerWave == 4, "four row slots");
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        const bool dn = s == 0 ? done[0] : s == 1 ? done[1] : s == 2 ? done[2] : done[3];
+        if (dn || ybase + s >= th) continue;
+        const bool iv = s == 0 ? inval[0] : s == 1 ? inval[1] : s == 2 ? inval[2] : inval[3];
+        const float mx = s == 0 ? mxs[0] : s == 1 ? mxs[1] : s == 2 ? mxs[2] : mxs[3];
+        const float my = s == 0 ? mys[0] : s == 1 ? mys[1] : s == 2 ? mys[2] : mys[3];
+        uint32_t o[4] = {0, 0, 0, 0};
+        sample_one(mx, my, iv, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (s == k) px[k][c] = o[c];
     }
+    // rows leave as whole dwords (96 per 64 RGB pixels) instead of three 2-byte stores per lane
+    const RowPack rp = make_row_pack();
+    const bool aligned4 = ((dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (ybase + s < th)
+            store_row16<C>(dst + (int64_t)(ybase + s) * dst_stride + (int64_t)x0t * (2 * C), px[s], n_px, aligned4, rp, false, false);
 }
 
 }  // namespace
@@ -330,34 +297,22 @@ hipError_t launch_arith_selftest(uint32_t seed, int blocks, int iters, unsigned 
     return hipGetLastError();
 }
 
-hipError_t launch_equirect_u16(const EqLaunch& L, int C, bool cubic, hipStream_t s) {
-    dim3 grid((unsigned)(L.chunk * 8)), block(64 * kWaves);
-    if (cubic) {
-        switch (C) {
-            case 1: hipLaunchKernelGGL((eq_views_u16_kernel<1, true>), grid, block, 0, s, L); break;
-            case 3: hipLaunchKernelGGL((eq_views_u16_kernel<3, true>), grid, block, 0, s, L); break;
-            case 4: hipLaunchKernelGGL((eq_views_u16_kernel<4, true>), grid, block, 0, s, L); break;
-            default: return hipErrorInvalidValue;
-        }
-    } else {
-        switch (C) {
-            case 1: hipLaunchKernelGGL((eq_views_u16_kernel<1, false>), grid, block, 0, s, L); break;
-            case 3: hipLaunchKernelGGL((eq_views_u16_kernel<3, false>), grid, block, 0, s, L); break;
-            case 4: hipLaunchKernelGGL((eq_views_u16_kernel<4, false>), grid, block, 0, s, L); break;
-            default: return hipErrorInvalidValue;
-        }
+hipError_t launch_table_u16_batch(TableBatch& B, int C, const float* coef, const uint16_t cval[4], hipStream_t s) {
+    int base = 0;
+    for (int j = 0; j < B.n_jobs; ++j) {
+        TableLaunch& L = B.job[j];
+        L.tiles_x = (L.w + kTileW - 1) / kTileW;
+        L.tile_base = base;
+        base += L.tiles_x * ((L.h + kTileH - 1) / kTileH);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_table_u16(const TableLaunch& T, int C, const float* coef, const uint16_t cval[4], hipStream_t s) {
-    const int tiles = ((T.w + kTileW - 1) / kTileW) * ((T.h + kTileH - 1) / kTileH);
-    if (tiles == 0) return hipSuccess;
-    dim3 grid((unsigned)tiles), block(64 * kWaves);
+    B.total_tiles = base;
+    B.chunk = (base + 7) / 8;
+    if (base == 0) return hipSuccess;
+    dim3 grid((unsigned)(B.chunk * 8)), block(64 * kWaves);
     switch (C) {
-        case 1: hipLaunchKernelGGL((table_remap_u16_kernel<1>), grid, block, 0, s, T, coef, cval[0], cval[1], cval[2], cval[3]); break;
-        case 3: hipLaunchKernelGGL((table_remap_u16_kernel<3>), grid, block, 0, s, T, coef, cval[0], cval[1], cval[2], cval[3]); break;
-        case 4: hipLaunchKernelGGL((table_remap_u16_kernel<4>), grid, block, 0, s, T, coef, cval[0], cval[1], cval[2], cval[3]); break;
+        case 1: hipLaunchKernelGGL((table_remap_u16_kernel<1>), grid, block, 0, s, B, coef, cval[0], cval[1], cval[2], cval[3]); break;
+        case 3: hipLaunchKernelGGL((table_remap_u16_kernel<3>), grid, block, 0, s, B, coef, cval[0], cval[1], cval[2], cval[3]); break;
+        case 4: hipLaunchKernelGGL((table_remap_u16_kernel<4>), grid, block, 0, s, B, coef, cval[0], cval[1], cval[2], cval[3]); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -29,7 +29,7 @@ EXPORTS = (
     "gs360_fisheye_views_u8", "gs360_remap_tables_u8",
     "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
-    "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
+    "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_remap_tables_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
     "gs360_png_unfilter", "gs360_event_sync", "gs360_stream_wait_event",
     "gs360_color_plan16_create", "gs360_color_plan16_destroy", "gs360_color_apply_u16", "gs360_tiff_lzw_decode", "gs360_selftest_arith",
 )
@@ -116,6 +116,7 @@ def load_library(path=None):
                                                 sz, i]
         L.gs360_equirect_views_u16.argtypes = L.gs360_equirect_views_u8.argtypes
         L.gs360_remap_table_u16.argtypes = L.gs360_remap_table_u8.argtypes
+        L.gs360_remap_tables_u16.argtypes = L.gs360_remap_tables_u8.argtypes
         L.gs360_equirect_views_u16_host.argtypes = L.gs360_equirect_views_u8_host.argtypes
         L.gs360_remap_table_u16_host.argtypes = L.gs360_remap_table_u8_host.argtypes
         L.gs360_png_unfilter.argtypes = [vp, i, i, i]
@@ -329,14 +330,15 @@ class Context:
         _check(fn(self.handle, src.ptr, H, W, Cn, 0, map_x.ptr, map_y.ptr, valid.ptr if valid is not None else None, h, w, interp, bv,
                   int(fill_value), dst.ptr, 0, slot), self.L)
 
-    def remap_tables_dev(self, jobs, Cn, interp=INTERP_LINEAR, border_value=(0, 0, 0, 0), slot=0):
+    def remap_tables_dev(self, jobs, Cn, interp=INTERP_LINEAR, border_value=(0, 0, 0, 0), slot=0, dtype=np.uint8):
         """Several remaps in one launch.  jobs: iterable of (src, H, W, map_x, map_y, valid_or_None, h, w, fill_value, dst)
         with DeviceBuffer objects for src / maps / valid / dst."""
         arr = (RemapJob * len(jobs))()
         for k, (src, H, W, mx, my, valid, h, w, fill, dst) in enumerate(jobs):
             arr[k] = RemapJob(src.ptr, H, W, 0, mx.ptr, my.ptr, valid.ptr if valid is not None else None, h, w, int(fill), dst.ptr, 0)
         bv = (C.c_double * 4)(*[float(x) for x in border_value])
-        _check(self.L.gs360_remap_tables_u8(self.handle, arr, len(jobs), Cn, interp, bv, slot), self.L)
+        fn = self.L.gs360_remap_tables_u16 if np.dtype(dtype) == np.uint16 else self.L.gs360_remap_tables_u8
+        _check(fn(self.handle, arr, len(jobs), Cn, interp, bv, slot), self.L)
 
     def fisheye_views_dev(self, lens_bufs, calibs, Cn, views, lens_fov_deg, dsts, valid_outs=None,
                           interp=INTERP_LINEAR, mask_outside=True, mask_value=0, slot=0):

@@ -63,8 +63,12 @@ class PairRenderer:
     def _remap_views(self, dev, imgs, dmask, interp, border, valid_fill):
         """All views of the pair in ONE batched launch (no per-view launch tails), then the downloads.  `dmask` set:
         the per-lens mask images are the sources (DF:2031-2043), else the lens images."""
+        dtype = np.uint8
         if dmask is None and any(v.dtype == np.uint16 for v in imgs.values()):
-            return self._remap_views_u16(dev, imgs, interp, border, valid_fill)
+            if any(v.dtype != np.uint16 for v in imgs.values()):
+                raise RuntimeError("the two lens images differ in bit depth")
+            dtype = np.uint16                 # CV_16U samplers, the same batched launch (gs360_remap_tables_u16)
+        esz = np.dtype(dtype).itemsize
         jobs, shapes, bufs = [], [], []
         for spec in self.specs:
             vid = str(spec["view_id"])
@@ -76,7 +80,7 @@ class PairRenderer:
             else:
                 d_src, (H, W, C) = dev[key], imgs[key].shape
             h, w = int(spec["height"]), int(spec["width"])
-            d_dst = self.ctx.alloc(h * w * C)
+            d_dst = self.ctx.alloc(h * w * C * esz)
             bufs.append(d_dst)
             mx, my, va = self.dev_tables[vid]
             jobs.append((d_src, H, W, mx, my, va if valid_fill is not None else None, h, w,
@@ -86,23 +90,11 @@ class PairRenderer:
             channels = {s[1][2] for s in shapes}
             if len(channels) != 1:
                 raise RuntimeError("the two lens images differ in channel count")
-            self.ctx.remap_tables_dev(jobs, channels.pop(), interp=interp, border_value=border, slot=0)
-            return {vid: self.ctx.download(b, shape, slot=0) for (vid, shape), b in zip(shapes, bufs)}
+            self.ctx.remap_tables_dev(jobs, channels.pop(), interp=interp, border_value=border, slot=0, dtype=dtype)
+            return {vid: self.ctx.download(b, shape, dtype=dtype, slot=0) for (vid, shape), b in zip(shapes, bufs)}
         finally:
             for b in bufs:
                 self.ctx.free(b)
-
-    def _remap_views_u16(self, dev, imgs, interp, border, valid_fill):
-        """16-bit lens images: one CV_16U remap launch per view (the first-cut 16-bit kernel has no batched form)."""
-        if any(v.dtype != np.uint16 for v in imgs.values()):
-            raise RuntimeError("the two lens images differ in bit depth")
-        out = {}
-        for spec in self.specs:
-            vid = str(spec["view_id"])
-            key = self.tables[vid]["lens_key"]
-            out[vid] = self._remap(dev[key], imgs[key].shape, self.dev_tables[vid], (int(spec["height"]), int(spec["width"])),
-                                   interp, border, valid_fill, dtype=np.uint16)
-        return out
 
     def render_pair(self, image_x: np.ndarray, image_y: np.ndarray, sensor_id_x: str, sensor_id_y: str, *,
                     interpolation: int, mask_outside_model: bool, mask_value: int,

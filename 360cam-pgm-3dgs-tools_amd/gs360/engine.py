@@ -27,6 +27,8 @@ from .jobspec import JobSpec
 _FRAME_CACHE_BYTES = int(os.environ.get("GS360_FRAME_CACHE_MB", "4096")) << 20
 _SLOTS_PER_DEVICE = 4
 _LINGER_S = float(os.environ.get("GS360_BATCH_LINGER_MS", "3")) * 1e-3
+_PREFETCH_FRAMES = int(os.environ.get("GS360_PREFETCH_FRAMES", "8"))      # still images decoded ahead of their view jobs (0 = off)
+_PREFETCH_THREADS = int(os.environ.get("GS360_PREFETCH_THREADS", "4"))    # decoder threads of the read-ahead
 
 
 class _Batch:
@@ -100,9 +102,18 @@ class Engine:
         self._expected = {}                       # str(source path) -> view jobs that can arrive together (announce())
         self._announce_lock = threading.Lock()
         self._assigned = {}                       # str(source path) -> index into self.states (device_for)
+        self._prefetch_queue = collections.deque()   # announced still-image sources not yet decoded ahead
+        self._prefetch_threads = []
+        self._prefetch_permits = threading.Semaphore(_PREFETCH_FRAMES)
+        self._prefetch_stop = threading.Event()
+        self._ahead = set()                       # sources decoded ahead whose view jobs have not arrived yet
+        self._touched = set()                     # sources a view job has asked for
         self._load = [0] * len(self.states)       # sources assigned per device
 
     def close(self):
+        self._prefetch_stop.set()
+        for t in list(self._prefetch_threads):
+            t.join(timeout=5.0)
         with self.videos_lock:
             sessions, self.videos = list(self.videos.values()), {}
         for sess in sessions:
@@ -310,6 +321,58 @@ class Engine:
                 self._expected[k] = min(n, workers) if workers else n
         for k in counts:                          # deal the sources to the devices in job-list order (Counter keeps it)
             self.device_for(k)
+        self._start_prefetch([j.src for j in jobs if j.is_still_image])
+
+    # -- decode-ahead -----------------------------------------------------------------------------
+    def _start_prefetch(self, sources):
+        """With the whole job list known, decode + upload the next still images in the background while the view jobs of the
+        current ones render and encode.  Without it a frame's decode (70 ms for a 5.7K PNG) sits on the critical path of its 8
+        view jobs: the first job decodes, the others wait, and with `-j 16` only two frames are ever in flight.  At most
+        GS360_PREFETCH_FRAMES (8) frames run ahead of the jobs; the first job that touches a source hands its permit back."""
+        order = []
+        for src in sources:
+            k = str(src)
+            if k not in order:
+                order.append(k)
+        if len(order) < 2 or _PREFETCH_FRAMES <= 0:
+            return
+        with self._announce_lock:
+            self._prefetch_queue.extend(order)
+            need = min(_PREFETCH_THREADS, len(order)) - len(self._prefetch_threads)
+            for _ in range(max(0, need)):
+                t = threading.Thread(target=self._prefetch_loop, name="gs360-decode-ahead", daemon=True)
+                self._prefetch_threads.append(t)
+                t.start()
+
+    def _prefetch_loop(self):
+        while not self._prefetch_stop.is_set():
+            with self._announce_lock:
+                if not self._prefetch_queue:
+                    self._prefetch_threads = [t for t in self._prefetch_threads if t is not threading.current_thread()]
+                    return
+                src = self._prefetch_queue.popleft()
+                if src in self._touched:          # its view jobs are already running (they decode it themselves)
+                    continue
+            if not self._prefetch_permits.acquire(timeout=0.25):
+                with self._announce_lock:
+                    self._prefetch_queue.appendleft(src)
+                continue
+            with self._announce_lock:
+                self._ahead.add(src)
+            try:
+                st = self.states[self.device_for(src)]
+                self.release_frame(st, self.resident_frame(st, src))
+            except Exception:  # noqa: BLE001  (the view job reports the real error when it gets there)
+                self._job_touches(src)
+
+    def _job_touches(self, src):
+        """a view job (or a failed prefetch) reached `src`: whatever ran ahead for it is consumed"""
+        key = str(src)
+        with self._announce_lock:
+            self._touched.add(key)
+            if key in self._ahead:
+                self._ahead.discard(key)
+                self._prefetch_permits.release()
 
     def _expected_for(self, src) -> int:
         with self._announce_lock:
@@ -322,6 +385,7 @@ class Engine:
         interp = self._interp_for(job)
         st = self.states[self.device_for(job.src)]
         held = []
+        self._job_touches(job.src)
 
         def get_frame():
             entry = self.resident_frame(st, job.src)

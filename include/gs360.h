@@ -234,6 +234,9 @@ int gs360_remap_table_u16(gs360_ctx *ctx, const void *src, int H, int W, int C, 
                           const float *map_x, const float *map_y, const uint8_t *valid, int h, int w,
                           int interp, const double *border_value, int fill_value,
                           void *dst, size_t dst_stride, int slot);
+/* several CV_16U remaps in one launch (the views of a dual-fisheye pair), as gs360_remap_tables_u8 */
+int gs360_remap_tables_u16(gs360_ctx *ctx, const gs360_remap_job *jobs, int n_jobs, int C, int interp,
+                           const double *border_value, int slot);
 
 /*
  * The same stage for 16-bit images (DF:603-618 treat uint16 like uint8 with 65535 levels).  Nothing is tabulated on the

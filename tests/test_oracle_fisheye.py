@@ -91,6 +91,12 @@ def test_fe_spec_tracks_reference_on_valid_pixels(orc, case):
     both = sv & gv
     if both.any():
         assert np.abs(sx - gx)[both].max() <= 1e-2 and np.abs(sy - gy)[both].max() <= 1e-2
+        # in float32 ULP of the coordinate (north_star asks <= 1 ULP pre-quantisation): the MEDIAN deviation is 0-1 ULP in
+        # every golden case; the tail (up to ~80 ULP = 0.008 px at coordinates of 2000-4000) is the reference's float32
+        # acos / sin / division path, FE-SPEC itself sits within 3 ULP of the float64 evaluation (next test).  DESIGN.md
+        # section 4 carries the per-case table; table mode is the exact one.
+        ulp = np.r_[np.abs(sx - gx)[both] / np.spacing(np.abs(gx[both])), np.abs(sy - gy)[both] / np.spacing(np.abs(gy[both]))]
+        assert np.median(ulp) <= 1.0
 
 
 def test_fe_spec_against_float64_truth(orc):

@@ -64,7 +64,37 @@ def test_oracle_u16_tracks_the_8bit_sampler(orc):
             assert np.abs(b.astype(np.float64) / 257.0 - a).max() <= 1.0
 
 
+def test_cubic_table_properties_the_16bit_kernel_relies_on(orc):
+    """eq16_cubic_blend_rgb accumulates sum w (S - 32768) in 32 bits and adds 32768 * 32768 back: every phase of the fixed-point
+    Keys table must sum to 32768, and 32768 * sum |w| must stay below 2^31."""
+    t = orc.cubic_table().astype(np.int64).reshape(1024, 16)
+    assert (t.sum(axis=1) == 32768).all()
+    assert int(np.abs(t).sum(axis=1).max()) * 32768 < 2 ** 31
+    # worst cases through the oracle's 64-bit accumulation: all-0 / all-65535 images and a +-extreme checker stay in range
+    for img in (np.zeros((9, 16, 3), np.uint16), np.full((9, 16, 3), 65535, np.uint16),
+                (np.indices((9, 16)).sum(0) % 2 * 65535).astype(np.uint16)[..., None].repeat(3, 2)):
+        out = orc.equirect_views_u16(img, [orc.make_view(10.0, 5.0, 80.0, 80.0, 24, 24)], interp=2)[0]
+        assert out.dtype == np.uint16
+
+
 # ---- GPU parity -----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", [1, 2])
+def test_gpu_equirect_u16_rings_extremes_and_odd_shapes(ctx, orc, interp):
+    """the 16-bit path on the ring skeleton: level + flipped-pitch rings, odd widths (centre column, byte-store fallback),
+    0 / 65535 checkers (the cubic sampler's 32-bit accumulation at its limits), strided rows"""
+    rng = np.random.default_rng(91)
+    src = rng.integers(0, 65536, (180, 360, 3), dtype=np.uint16)
+    src[::2, ::2] = 65535
+    src[1::2, 1::2] = 0
+    specs = [(y, p, 100.0, 100.0, 75, 61) for y in (0.0, 90.0, 180.0, -90.0) for p in (30.0, -30.0)]
+    specs += [(y, 0.0, 112.62, 112.62, 80, 80) for y in (0.0, 45.0, 90.0)] + [(12.3, 77.0, 60.0, 60.0, 33, 47), (0.0, 90.0, 105.0, 105.0, 64, 64)]
+    got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], interp=interp)
+    want = orc.equirect_views_u16(src, [orc.make_view(*s) for s in specs], interp=interp)
+    for k, (g, w_) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w_), (k, specs[k], interp)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels", [1, 3, 4])
 @pytest.mark.parametrize("interp", [0, 1, 2, 4])
