@@ -1263,6 +1263,7 @@ __device__ __forceinline__ void cv_sample_lanczos4(const uint8_t* __restrict__ s
 template <int C>
 struct CvTaps {
     uint2 t0, t1;
+    RowsRaw raw;    // C == 3: the loads in flight (cv_taps_finish)
     int fx, fy;
     bool fast;
 };
@@ -1289,7 +1290,7 @@ __device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__
         t.t0 = make_uint2(a, 0);
         t.t1 = make_uint2(b, 0);
     } else if constexpr (C == 3) {
-        ld_rows_rgb(src, o0, o1, t.t0, t.t1);
+        t.raw = ld_rows_rgb_issue(src, o0, o1);
     } else {
         t.t0 = ld_u64(r0);
         t.t1 = ld_u64(r1);
@@ -1298,7 +1299,8 @@ __device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__
 }
 
 template <int C>
-__device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out)[4]) {
+__device__ __forceinline__ void cv_blend_fast(CvTaps<C>& t, uint32_t (&out)[4]) {
+    if constexpr (C == 3) ld_rows_rgb_finish(t.raw, t.t0, t.t1);
     EqTaps<C> e;
     e.t0 = t.t0;
     e.t1 = t.t1;
@@ -1312,7 +1314,9 @@ __device__ __forceinline__ void cv_blend_fast(const CvTaps<C>& t, uint32_t (&out
 __device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
                                                    const float (&mxs)[kRowsPerWave], const float (&mys)[kRowsPerWave],
                                                    const uint8_t (&cval)[4], const int16_t* __restrict__ tab,
-                                                   uint32_t (&px)[kRowsPerWave][4]) {
+                                                   const int16_t* tab_lds, uint32_t (&px)[kRowsPerWave][4]) {
+    // tab_lds: the workgroup's LDS copy of the table for the fast path (every lane reads another 32-byte entry: left in global
+    // memory the 32 KiB table competes with the source lines for the 32 KiB vector L1 and costs two more gathers per pixel)
     static_assert(kRowsPerWave == 4, "four row slots");
     bool fast[4];
 #pragma unroll
@@ -1326,8 +1330,8 @@ __device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ s
             t[u] = cubic_issue_rgb(src, (uint32_t)stride, W, H, ix, iy, sx & 31, sy & 31);
         }
         __builtin_amdgcn_sched_barrier(0);
-        eq_cubic_blend(t[0], tab, px[s0]);
-        eq_cubic_blend(t[1], tab, px[s0 + 1]);
+        eq_cubic_blend(t[0], tab_lds, px[s0]);
+        eq_cubic_blend(t[1], tab_lds, px[s0 + 1]);
     }
     if (__any(!(fast[0] && fast[1] && fast[2] && fast[3]))) {
         // border windows: ONE copy of the straight-line sampler in a rolled loop (slot picked with uniform selects), so
@@ -1370,21 +1374,40 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
     const RowPack rp = make_row_pack();
     constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
+    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
+    if constexpr (kFastCubic) {
+        if (L.pipelined) {                    // (wave-uniform; no thread has left the workgroup yet)
+            const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
+            uint4* l = reinterpret_cast<uint4*>(s_wtab);
+#pragma unroll
+            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+            __syncthreads();
+        }
+    }
     if ((INTERP == GS360_INTERP_LINEAR || INTERP == GS360_INTERP_NEAREST || kFastCubic) && L.pipelined) {
         // maps of the wavefront's 4 rows -> all gathers in flight -> blend -> border/valid fix-ups -> packed stores
         const int ybase = tile_y * kTileH + wave * kRowsPerWave;
         float mxs[kRowsPerWave], mys[kRowsPerWave];
         bool inval[kRowsPerWave];
+        // the twelve map / valid reads of the four row slots go out together: behind a run-time `if (L.valid)` the compiler waits
+        // for each valid byte (and with it for the slot's map reads) before it issues the next slot's -- four serial round trips
+        // per tile.  Without a valid map the byte is read from the map itself (h * w readable bytes) and ignored.
+        const uint8_t* __restrict__ vptr = L.valid ? L.valid : reinterpret_cast<const uint8_t*>(L.map_x);
+        const bool has_valid = L.valid != nullptr;
+        uint8_t vbyte[kRowsPerWave];
 #pragma unroll
         for (int rr = 0; rr < kRowsPerWave; ++rr) {
             const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
             mxs[rr] = L.map_x[o];         // (non-temporal map loads were measured: no difference)
             mys[rr] = L.map_y[o];
-            inval[rr] = L.valid && !L.valid[o];
+            vbyte[rr] = vptr[o];
         }
+        __builtin_amdgcn_sched_barrier(0);    // all twelve in flight before anything else is scheduled
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) inval[rr] = has_valid & (vbyte[rr] == 0);
         uint32_t px[kRowsPerWave][4];
         if constexpr (kFastCubic) {
-            cv_cubic_slots_rgb(L.src, L.src_stride, L.W, L.H, mxs, mys, L.cval, L.cubic_tab, px);
+            cv_cubic_slots_rgb(L.src, L.src_stride, L.W, L.H, mxs, mys, L.cval, L.cubic_tab, s_wtab, px);
         } else if constexpr (INTERP == GS360_INTERP_NEAREST) {   // mask cutting (DF:2031-2043): the 4 slots' reads in flight together
 #pragma unroll
             for (int rr = 0; rr < kRowsPerWave; ++rr) cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
@@ -1396,6 +1419,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
                 taps[rr] = cv_fetch_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr]);
                 any_slow |= !taps[rr].fast;
             }
+            __builtin_amdgcn_sched_barrier(0);    // every gather of the wavefront's four rows in flight before the first is consumed
 #pragma unroll
             for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
             if (__any(any_slow)) {
@@ -1458,6 +1482,17 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
     const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(V.dst) & 3) == 0);
     const RowPack rp = make_row_pack();
     const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
+    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
+    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
+    if constexpr (kFastCubic) {
+        if (L.pipelined) {                    // the weight table into LDS, as in the table kernel
+            const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
+            uint4* l = reinterpret_cast<uint4*>(s_wtab);
+#pragma unroll
+            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+            __syncthreads();
+        }
+    }
 
     const int ybase = tile_y * kTileH + wave * kRowsPerWave;
     const bool pipelined = (INTERP == GS360_INTERP_LINEAR) && L.pipelined;
@@ -1496,7 +1531,7 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
     }
     uint32_t px[kRowsPerWave][4];
     if ((INTERP == GS360_INTERP_CUBIC) && (C == 3) && L.pipelined) {
-        if constexpr (C == 3) cv_cubic_slots_rgb(V.src, L.src_stride, V.W, V.H, mxs, mys, L.cval, L.cubic_tab, px);
+        if constexpr (C == 3) cv_cubic_slots_rgb(V.src, L.src_stride, V.W, V.H, mxs, mys, L.cval, L.cubic_tab, s_wtab, px);
     } else if (pipelined) {
         CvTaps<C> taps[kRowsPerWave];
         bool any_slow = false;
@@ -1505,6 +1540,7 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
             taps[rr] = cv_fetch_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr]);
             any_slow |= !taps[rr].fast;
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
         if (__any(any_slow)) {

@@ -65,14 +65,21 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
     float mxs[kRowsPerWave], mys[kRowsPerWave];
     bool inval[kRowsPerWave], done[kRowsPerWave];
     uint32_t px[kRowsPerWave][4];
+    // (branch-free: without a valid map the byte is read from the map itself and ignored -- see table_remap_kernel)
+    const uint8_t* __restrict__ vptr = vmask ? vmask : reinterpret_cast<const uint8_t*>(map_x);
+    const bool has_valid = vmask != nullptr;
+    uint8_t vbyte[kRowsPerWave];
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s) {
         const size_t p = (size_t)min(ybase + s, th - 1) * tw + x;
         mxs[s] = map_x[p];
         mys[s] = map_y[p];
-        inval[s] = vmask && !vmask[p];
+        vbyte[s] = vptr[p];
         done[s] = false;
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) inval[s] = has_valid & (vbyte[s] == 0);
     if constexpr (C == 3) {
         // bilinear, RGB, windows inside the image: the two row reads of ALL four slots (dword-aligned 16-byte reads of the 12 tap
         // bytes) and their weight reads are issued before any is consumed; float32 blend in OpenCV's expression order
