@@ -378,8 +378,21 @@ __device__ __forceinline__ EqCubicTaps cubic_issue_rgb(const uint8_t* __restrict
     t.fix = (x0 != ix - 1);
     t.phase = fy * 32 + fx;
     const uint32_t col = (uint32_t)x0 * 3u;
-    // rows start at multiples of the stride from a 4-byte aligned base; with a stride that is a multiple of 4 every row of the
-    // window has the same misalignment, otherwise it is taken per row (folded into the address, see below)
+    // Common case (wave-uniform test): no window of the wavefront touches the first or the last image row and the stride is a
+    // multiple of 4 -- the four rows are off0 + k * stride with ONE misalignment: 8 address instructions instead of 26 (the
+    // kernel is arithmetic-bound).
+    if ((stride & 3u) == 0 && !__any(iy < 1 || iy > H - 3)) {
+        const uint32_t off0 = __umul24((uint32_t)(iy - 1), stride) + col;
+        const uint32_t o = (uint32_t)(reinterpret_cast<uintptr_t>(src) + off0) & 3u;
+        t.sh = o * 0x55u;
+        const uint8_t* p0 = src + (off0 - o);
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p0 + (size_t)ky * stride, 4));
+            t.raw[ky][0] = q[0]; t.raw[ky][1] = q[1]; t.raw[ky][2] = q[2]; t.raw[ky][3] = q[3];
+        }
+        return t;
+    }
     t.sh = 0;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
