@@ -165,7 +165,7 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
             const int la4 = reversed ? 4 * (n_px - 1) - rp.a4 : rp.a4, lb4 = reversed ? la4 - 4 : la4 + 4;
             const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(la4 & 252, (int)packed);
             const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)packed);
-            const uint32_t dw = (pa >> rp.sh) | (pb << (24 - rp.sh));
+            const uint32_t dw = __builtin_amdgcn_perm(pb, pa, rp.sel);   // = (pa >> sh) | (pb << (24 - sh)) on 24-bit pixels, one instruction
             int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
             if (lane < full) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
             if (lane == full && rem)

@@ -11,6 +11,7 @@ namespace gs360 {
 struct RowPack {
     int a4;   // 4 * ((4 * lane) / 3): ds_bpermute address of the first pixel contributing to dword `lane` of the row
     int sh;   // 8 * ((4 * lane) % 3): its bit offset
+    uint32_t sel;   // v_perm_b32 selector that cuts dword `lane` out of the two 24-bit pixels (pa in bytes 0..3, pb in 4..7)
     int lane;
 };
 __device__ __forceinline__ RowPack make_row_pack() {
@@ -18,6 +19,7 @@ __device__ __forceinline__ RowPack make_row_pack() {
     RowPack rp;
     rp.a4 = 4 * (lane + t);
     rp.sh = 8 * (lane - 3 * t);
+    rp.sel = rp.sh == 0 ? 0x04020100u : (rp.sh == 8 ? 0x05040201u : 0x06050402u);
     rp.lane = lane;
     return rp;
 }
