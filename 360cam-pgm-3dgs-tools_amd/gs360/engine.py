@@ -346,24 +346,29 @@ class Engine:
 
     def _prefetch_loop(self):
         while not self._prefetch_stop.is_set():
-            with self._announce_lock:
-                if not self._prefetch_queue:
-                    self._prefetch_threads = [t for t in self._prefetch_threads if t is not threading.current_thread()]
-                    return
-                src = self._prefetch_queue.popleft()
-                if src in self._touched:          # its view jobs are already running (they decode it themselves)
-                    continue
-            if not self._prefetch_permits.acquire(timeout=0.25):
+            if not self._prefetch_permits.acquire(timeout=0.25):      # a permit first, then the NEXT source: strict job-list order
                 with self._announce_lock:
-                    self._prefetch_queue.appendleft(src)
+                    if not self._prefetch_queue:
+                        break
                 continue
+            src = None
             with self._announce_lock:
-                self._ahead.add(src)
+                while self._prefetch_queue:
+                    cand = self._prefetch_queue.popleft()
+                    if cand not in self._touched:     # else its view jobs are already running (they decode it themselves)
+                        src = cand
+                        self._ahead.add(src)
+                        break
+            if src is None:
+                self._prefetch_permits.release()
+                break
             try:
                 st = self.states[self.device_for(src)]
                 self.release_frame(st, self.resident_frame(st, src))
             except Exception:  # noqa: BLE001  (the view job reports the real error when it gets there)
                 self._job_touches(src)
+        with self._announce_lock:
+            self._prefetch_threads = [t for t in self._prefetch_threads if t is not threading.current_thread()]
 
     def _job_touches(self, src):
         """a view job (or a failed prefetch) reached `src`: whatever ran ahead for it is consumed"""

@@ -131,3 +131,47 @@ def test_cancelled_follower_does_not_strand_its_pinned_block(monkeypatch):
     assert res == {0: 0} and list(errs) == [60] and "cancelled" in str(errs[60])
     assert len(launches) == 1 and len(launches[0]) == 2
     assert sorted(b[1] for b in st.given_back) == [0.0, 60.0]     # the leader's own block and the abandoned one both came back
+
+
+def test_decode_ahead_runs_at_most_its_permits_ahead_and_hands_them_back(monkeypatch):
+    """Engine._start_prefetch / _job_touches (host logic, no GPU): announced sources are decoded in order by the background
+    threads, never more than GS360_PREFETCH_FRAMES beyond what the view jobs have reached; a job touching a source frees its permit."""
+    import collections as c
+    eng = engine.Engine.__new__(engine.Engine)
+    eng.states = [object(), object()]
+    eng._announce_lock = threading.Lock()
+    eng._assigned, eng._load = {}, [0, 0]
+    eng._prefetch_queue, eng._prefetch_threads = c.deque(), []
+    monkeypatch.setattr(engine, "_PREFETCH_FRAMES", 3)
+    monkeypatch.setattr(engine, "_PREFETCH_THREADS", 2)
+    eng._prefetch_permits = threading.Semaphore(3)
+    eng._prefetch_stop = threading.Event()
+    eng._ahead, eng._touched = set(), set()
+    decoded, lock = [], threading.Lock()
+
+    def fake_resident(st, src):
+        with lock:
+            decoded.append(src)
+        return [None, 0, 0, 0, 1, None]
+    monkeypatch.setattr(eng, "resident_frame", fake_resident, raising=False)
+    monkeypatch.setattr(eng, "release_frame", lambda st, entry: None, raising=False)
+    srcs = [f"/p/{k}.png" for k in range(8)]
+    eng._start_prefetch(srcs + srcs[:3])                      # duplicates (several views per source) collapse
+    deadline = time.monotonic() + 2.0
+    while len(decoded) < 3 and time.monotonic() < deadline:
+        time.sleep(0.01)
+    time.sleep(0.3)
+    assert sorted(decoded) == srcs[:3]                        # three permits: three frames ahead, in order, no more
+    assert [eng.device_for(s) for s in srcs[:4]] == [0, 1, 0, 1] or len({eng.device_for(s) for s in srcs}) == 2
+    eng._job_touches(srcs[0])                                 # the first view job arrives: one permit comes back
+    deadline = time.monotonic() + 2.0
+    while len(decoded) < 4 and time.monotonic() < deadline:
+        time.sleep(0.01)
+    assert sorted(decoded) == srcs[:4]
+    for s in srcs[1:]:
+        eng._job_touches(s)                                   # jobs overtake the read-ahead: touched sources are skipped
+    time.sleep(0.6)
+    assert len(decoded) <= 8 and len(set(decoded)) == len(decoded)
+    eng._prefetch_stop.set()
+    for t in list(eng._prefetch_threads):
+        t.join(2.0)
