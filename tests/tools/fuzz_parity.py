@@ -224,6 +224,18 @@ def fuzz_u16(ctx, rng, case):
         src = rng.integers(0, 65536, (H, W, c), dtype=np.uint16)
         specs = [(float(rng.uniform(-400, 400)), 0.0 if rng.random() < 0.4 else float(rng.uniform(-95, 95)), float(rng.uniform(5, 179)),
                   float(rng.uniform(5, 179)), int(rng.integers(1, 160)), int(rng.integers(1, 100))) for _ in range(int(rng.integers(1, 4)))]
+        if rng.random() < 0.5:   # yaw rings (whole-texel yaw steps, flipped pitch) and extreme samples for the 32-bit cubic accumulation
+            if rng.random() < 0.5:
+                W = int(rng.choice([8, 24, 48, 96, 240, 360]))
+                src = rng.integers(0, 65536, (H, W, c), dtype=np.uint16)
+            count = int(rng.choice([2, 3, 4, 6, 8]))
+            base = specs[0]
+            pitch = 0.0 if rng.random() < 0.35 else float(rng.choice([30.0, -30.0, 90.0, float(rng.uniform(-95, 95))]))
+            specs = [((i % count) * 360.0 / count + (float(rng.uniform(-3, 3)) if rng.random() < 0.1 else 0.0),
+                      (-pitch if rng.random() < 0.4 else pitch), base[2], base[3], base[4], base[5]) for i in range(int(rng.integers(2, 19)))]
+            if rng.random() < 0.5:
+                src[rng.random(src.shape[:2]) < 0.3] = 65535
+                src[rng.random(src.shape[:2]) < 0.3] = 0
         interp = int(rng.choice([1, 2]))
         fish = rng.random() < 0.25
         got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], interp=interp, flags=gs360.EQ_FISHEYE_OUT if fish else 0)
