@@ -1,10 +1,6 @@
-// gs360_u16.hip -- 16-bit (uint16) variants of the two samplers.
+// gs360_u16.hip -- cv2.remap on CV_16U sources and the arithmetic self-test.
+// (The 16-bit EQUIRECT sampler lives in gs360_kernels.hip: eq_views_kernel<..., ES = 2>, the 8-bit kernel's skeleton on 2-byte samples.)
 //
-//   eq_views_u16_kernel      EQ-SPEC v1 on 16-bit equirect sources: 16-bit stills keep their depth through the reference's
-//                            ffmpeg path (PC:327-347 sets no -pix_fmt for PNG/TIFF stills) and > 8-bit videos leave as
-//                            rgb48le (PC:343-347).  Same quantised coordinates as the 8-bit kernel, evaluated per pixel
-//                            (eq_coord_px); bilinear (sum S a b + 512) >> 10, bicubic with the fixed-point Keys table in
-//                            64-bit, columns wrap, rows clamp.
 //   table_remap_u16_kernel   cv2.remap on CV_16U sources (DF:735 keeps 16-bit inputs at native depth; DF:2001-2014):
 //                            OpenCV routes ushort to its FLOAT-weight samplers -- 2-D weight = cy[k1] * cx[k2] in float32
 //                            from the 1-D phase tables, float32 accumulation in OpenCV's expression order, cvRound +
@@ -14,8 +10,10 @@
 //                            outside taps by the border value, bicubic / lanczos4 start from the border value cv and add
 //                            (S - cv) w for every in-image tap in row-major order.
 //
-// First-cut kernels: one output pixel per lane per row slot, straight-line samplers, 2-byte-element gathers.  They are
-// HBM-bound byte gathers like their 8-bit siblings but carry none of the tuned fetch paths yet.
+// All jobs of a call (the views of a pair) share one launch; the maps / valid flags of a wavefront's four rows go out together;
+// bilinear RGB windows inside the image take a pipelined path (all eight row reads in flight, then the float32 blend); everything
+// else -- bicubic, Lanczos, borders, other channel counts -- runs the straight-line sampler one row slot at a time; rows leave as
+// whole dwords (gs360_rowstore.h).
 #include "gs360_eqspec.h"
 #include "gs360_rowstore.h"
 

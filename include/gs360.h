@@ -220,7 +220,8 @@ int gs360_color_apply_u8(gs360_ctx *ctx, const gs360_color_plan *plan, const voi
  * native depth: cv2.imread(IMREAD_UNCHANGED) in the dual-fisheye tool (DF:735) and 16-bit PNG/TIFF stills / > 8-bit
  * videos (rgb48le) in 360PerspCut (gs360_360PerspCut.py:327-347).
  *   gs360_equirect_views_u16  EQ-SPEC v1 coordinates; bilinear (sum S a b + 512) >> 10, bicubic with the fixed-point
- *                             Keys table accumulated in 64 bits, clamped to [0, 65535].  No fused keep-mask.
+ *                             Keys table, exact integer sum (the value a 64-bit accumulation gives), clamped to
+ *                             [0, 65535].  No fused keep-mask.
  *   gs360_remap_table_u16     cv2.remap on CV_16U: OpenCV's float-weight samplers (weights cy[k1]*cx[k2] in float32,
  *                             float32 accumulation in OpenCV's expression order, cvRound + saturate), all four
  *                             interpolations; border_value saturates to [0, 65535]; fill_value is written as uint16.
