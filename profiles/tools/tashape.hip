@@ -46,7 +46,7 @@ void run(const unsigned* buf, unsigned* out, int lpr, int S, int RS, unsigned ma
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double instr_per_cu = (double)iters * 8 * 16;
     printf("ndw %d lanes/row %2d stride %2d rowstride %4d align %2d : %.3f ms  cycles/instr/CU@2.4GHz = %5.1f   (wave-instr in the timed dispatch: %d)\n",
-           NDW, lpr, S, RS, (mask & 12) ? 4 : 16, ms, ms * 1e-3 * 2.4e9 / instr_per_cu, iters * 8 * blocks * 4);
+           NDW, lpr, S, RS, (mask & 1) ? 1 : ((mask & 2) ? 2 : ((mask & 12) ? 4 : 16)), ms, ms * 1e-3 * 2.4e9 / instr_per_cu, iters * 8 * blocks * 4);
 }
 int main() {
     unsigned *buf, *out; CK(hipMalloc(&buf, 1 << 16)); CK(hipMemset(buf, 1, 1 << 16)); CK(hipMalloc(&out, 256 * 4 * 256 * 4));
@@ -61,6 +61,13 @@ int main() {
             run<4>(buf, out, lpr, S, 1092, 0x3ffcu);
             run<4>(buf, out, lpr, S, 1092, 0x3ff0u);
         }
+    // byte-misaligned lanes (mask keeps every byte offset): what an unaligned tap read would cost
+    for (int S : {6, 14}) {
+        run<2>(buf, out, 64, S, 1092, 0x3fffu);
+        run<3>(buf, out, 64, S, 1092, 0x3fffu);
+        run<2>(buf, out, 16, S, 1092, 0x3fffu);
+        run<2>(buf, out, 64, S, 1092, 0x3ffeu);
+    }
     // perfectly coalesced references
     run<1>(buf, out, 64, 4, 0, 0x3ffcu);
     run<4>(buf, out, 64, 16, 0, 0x3ff0u);
