@@ -405,6 +405,14 @@ int gs360_dev_memset(gs360_ctx* c, void* dst_dev, int value, size_t bytes, int s
     HIP_TRY(hipMemsetAsync(dst_dev, value, bytes, c->stream[slot]));
     return GS360_OK;
 }
+int gs360_dev_bswap16(gs360_ctx* c, void* buf_dev, size_t n_samples, int slot) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!buf_dev || ((uintptr_t)buf_dev & 1)) return fail(GS360_ERR_ARG, "NULL or odd buffer address");
+    if (n_samples == 0) return GS360_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_bswap16((uint16_t*)buf_dev, n_samples, c->stream[slot]));
+    return GS360_OK;
+}
 int gs360_sync(gs360_ctx* c, int slot) {
     if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));

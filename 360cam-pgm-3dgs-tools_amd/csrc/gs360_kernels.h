@@ -170,6 +170,7 @@ void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 void build_coef1d(float* out);             // host: the float32 1-D phase tables (linear, cubic, lanczos4) of the CV_16U samplers, 448
 hipError_t launch_equirect_u16(const EqLaunch& L, int C, bool cubic, hipStream_t s);                       // gs360_u16.hip
+hipError_t launch_bswap16(uint16_t* buf, size_t n, hipStream_t s);            // gs360_u16.hip: in-place byte swap of 16-bit samples
 hipError_t launch_arith_selftest(uint32_t seed, int blocks, int iters, unsigned long long* d_bad, hipStream_t s);
 hipError_t launch_table_u16_batch(TableBatch& B, int C, const float* coef, const uint16_t cval[4], hipStream_t s);   // all jobs share interp
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s);

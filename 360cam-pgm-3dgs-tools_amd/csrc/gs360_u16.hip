@@ -297,6 +297,32 @@ __global__ __launch_bounds__(256) void arith_selftest_kernel(uint32_t seed, int 
 }
 }  // namespace
 
+namespace {
+// 16-bit PPM frames arrive big-endian (video decode pipe, gs360/video.py): swapped in place on the device after the upload, on the
+// upload stream -- a 177 MB rgb48 8K frame is 60 us here against a 35 ms pass over pinned memory on the reader thread.
+// Grid-stride over dwords (two samples each: v_perm), the odd head / tail sample by one lane each.
+__global__ __launch_bounds__(256) void bswap16_kernel(uint16_t* buf, size_t n) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(buf);
+    const size_t head = (a & 2) ? 1 : 0;                         // samples before the first dword boundary
+    const size_t nd = (n - (n < head ? n : head)) / 2;             // whole dwords after the head
+    uint32_t* d = reinterpret_cast<uint32_t*>(buf + head);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < nd; i += step) d[i] = __builtin_amdgcn_perm(0u, d[i], 0x02030001u);
+    if (tid == 0) {
+        if (head && n) buf[0] = (uint16_t)((buf[0] >> 8) | (buf[0] << 8));
+        const size_t tail = head + 2 * nd;
+        if (tail < n) buf[tail] = (uint16_t)((buf[tail] >> 8) | (buf[tail] << 8));
+    }
+}
+}  // namespace
+
+hipError_t launch_bswap16(uint16_t* buf, size_t n, hipStream_t s) {
+    const size_t nd = n / 2 + 1;
+    unsigned blocks = (unsigned)((nd + 255) / 256 < 256 * 16 ? (nd + 255) / 256 : 256 * 16);
+    hipLaunchKernelGGL(bswap16_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, buf, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_arith_selftest(uint32_t seed, int blocks, int iters, unsigned long long* d_bad, hipStream_t s) {
     hipLaunchKernelGGL(arith_selftest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, seed, iters, d_bad);
     return hipGetLastError();

@@ -24,7 +24,7 @@ MAX_FRAMES = 16
 EXPORTS = (
     "gs360_abi_version", "gs360_device_count", "gs360_last_error", "gs360_ctx_create", "gs360_ctx_destroy",
     "gs360_device_info", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
-    "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_sync", "gs360_event_record",
+    "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_dev_bswap16", "gs360_sync", "gs360_event_record",
     "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_equirect_views_masked_u8", "gs360_remap_table_u8",
     "gs360_fisheye_views_u8", "gs360_remap_tables_u8",
     "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
@@ -99,6 +99,7 @@ def load_library(path=None):
         L.gs360_upload.argtypes = [vp, vp, vp, sz, i]
         L.gs360_download.argtypes = [vp, vp, vp, sz, i]
         L.gs360_dev_memset.argtypes = [vp, vp, i, sz, i]
+        L.gs360_dev_bswap16.argtypes = [vp, vp, sz, i]
         L.gs360_sync.argtypes = [vp, i]
         L.gs360_event_record.argtypes = [vp, i, i]
         L.gs360_event_elapsed_ms.argtypes = [vp, i, i, i, C.POINTER(C.c_float)]
@@ -262,6 +263,10 @@ class Context:
 
     def memset(self, buf, value, slot=0):
         _check(self.L.gs360_dev_memset(self.handle, buf.ptr, int(value), buf.nbytes, slot), self.L)
+
+    def bswap16(self, buf, n_samples, slot=0):
+        """in-place byte swap of 16-bit samples on the device (asynchronous on `slot`)"""
+        _check(self.L.gs360_dev_bswap16(self.handle, buf.ptr, int(n_samples), slot), self.L)
 
     def sync(self, slot=-1):
         _check(self.L.gs360_sync(self.handle, slot), self.L)

@@ -257,8 +257,6 @@ class VideoSession:
                 stage = pair[which]
                 host = np.frombuffer(stage.view, dtype=np.uint8, count=nbytes)      # the pinned block as an array
                 read_exact_into(out, memoryview(host))
-                if fdtype == np.uint16:
-                    host.view(np.uint16).byteswap(inplace=True)       # PPM samples are big-endian
                 if pending is not None:           # frame k-1 has had this whole pipe read to land
                     pst, pev, pargs = pending
                     pst.ctx.event_sync(pst.upload_slot, pev)
@@ -270,6 +268,8 @@ class VideoSession:
                 ev = _EVENT_BASE + which
                 with st.upload_lock:              # the engine's still-image uploads share this stream (engine.resident_frame)
                     st.ctx.upload(buf, host, slot=st.upload_slot, sync=False)
+                    if fdtype == np.uint16:               # PPM samples are big-endian: swapped on the device, behind the copy
+                        st.ctx.bswap16(buf, nbytes // 2, slot=st.upload_slot)
                     st.ctx.event_record(st.upload_slot, ev)
                 pending = (st, ev, (st, buf, h, w, fdtype, nbytes))
                 k += 1

@@ -101,6 +101,9 @@ int gs360_host_free(gs360_ctx *ctx, void *hptr);
 int gs360_upload(gs360_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, int slot);
 int gs360_download(gs360_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, int slot);
 int gs360_dev_memset(gs360_ctx *ctx, void *dst_dev, int value, size_t bytes, int slot);
+/* in-place byte swap of n_samples 16-bit samples on the device (16-bit PPM frames of the video decode pipe are big-endian:
+ * cli_tools/gs360_360PerspCut.py:343-347 keeps > 8-bit videos at 16 bits); asynchronous on `slot` */
+int gs360_dev_bswap16(gs360_ctx *ctx, void *buf_dev, size_t n_samples, int slot);
 int gs360_sync(gs360_ctx *ctx, int slot); /* slot < 0: every slot */
 
 /* ---- timing: HIP events recorded on the slot's own stream (8 events per slot) -------------- */

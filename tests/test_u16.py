@@ -142,3 +142,16 @@ def test_gpu_equirect_u16_full_size_8k(ctx, orc):
     want = orc.equirect_views_u16(src, [orc.make_view(*s) for s in specs], threads=0)
     for k, (g, w_) in enumerate(zip(got, want)):
         assert np.array_equal(g, w_), k
+
+
+@pytest.mark.gpu
+def test_gpu_bswap16_in_place(ctx):
+    """gs360_dev_bswap16 (big-endian 16-bit PPM frames of the video pipe are swapped on the device): every size parity"""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 64, 1001, 3 * 7680 * 5 + 1):
+        a = rng.integers(0, 65536, n, dtype=np.uint16)
+        d = ctx.to_device(a)
+        ctx.bswap16(d, n, slot=0)
+        got = ctx.download(d, (n,), dtype=np.uint16)
+        assert np.array_equal(got, a.byteswap()), n
+        ctx.free(d)
