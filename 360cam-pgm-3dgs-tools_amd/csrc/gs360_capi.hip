@@ -574,19 +574,36 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         if (v >= 1) ring_max = ring_max_blocked = v < GS360_MAX_VIEWS ? v : GS360_MAX_VIEWS;
     }
     std::vector<std::vector<int>> rings;
-    for (int k = 0; k < n_views; ++k) {
-        const EqView& b = ev[k];
-        int hit = -1;
-        for (size_t r = 0; r < rings.size() && hit < 0; ++r) {
-            const EqView& a = ev[rings[r][0]];
-            if ((int)rings[r].size() < (b.blocked ? ring_max_blocked : ring_max) && a.sxu == b.sxu && a.syv == b.syv && a.cp == b.cp && (a.sp == b.sp || a.sp == -b.sp) &&
-                a.x0f32 == b.x0f32 && a.out_w == b.out_w && a.out_h == b.out_h && a.level == b.level && a.fish == b.fish &&
-                a.blocked == b.blocked)
-                hit = (int)r;
+    const bool ring_forced = std::getenv("GS360_RING") != nullptr;
+    for (;;) {
+        rings.clear();
+        for (int k = 0; k < n_views; ++k) {
+            const EqView& b = ev[k];
+            int hit = -1;
+            for (size_t r = 0; r < rings.size() && hit < 0; ++r) {
+                const EqView& a = ev[rings[r][0]];
+                if ((int)rings[r].size() < (b.blocked ? ring_max_blocked : ring_max) && a.sxu == b.sxu && a.syv == b.syv && a.cp == b.cp && (a.sp == b.sp || a.sp == -b.sp) &&
+                    a.x0f32 == b.x0f32 && a.out_w == b.out_w && a.out_h == b.out_h && a.level == b.level && a.fish == b.fish &&
+                    a.blocked == b.blocked)
+                    hit = (int)r;
+            }
+            if (hit < 0) { rings.emplace_back(); hit = (int)rings.size() - 1; }
+            rings[hit].push_back(k);
+            ev[k].flip = ev[rings[hit][0]].sp != b.sp ? 1 : 0;
         }
-        if (hit < 0) { rings.emplace_back(); hit = (int)rings.size() - 1; }
-        rings[hit].push_back(k);
-        ev[k].flip = ev[rings[hit][0]].sp != b.sp ? 1 : 0;
+        // A ring's workgroup walks all its members, so a SMALL job in long rings is too few workgroups to fill the chip twice over
+        // (one 5.7K frame -> `default`: one ring of 8 = 1300 workgroups for 1280 resident slots: 61 us against 56 us as two rings of
+        // 4; the engine's product path launches one frame at a time).  Halve the ring cap until the job has two rounds of workgroups.
+        size_t longest = 1;
+        long long wgs = 0;
+        for (const auto& r : rings) {
+            longest = r.size() > longest ? r.size() : longest;
+            wgs += (long long)ev[r[0]].tiles_x * ev[r[0]].tiles_y;
+        }
+        wgs *= n_frames < GS360_MAX_FRAMES ? n_frames : GS360_MAX_FRAMES;
+        const long long two_rounds = 2ll * c->prop.multiProcessorCount * 5;
+        if (ring_forced || wgs >= two_rounds || longest <= 2 || ring_max <= 2) break;
+        ring_max = (int)((longest + 1) / 2);
     }
 
     size_t r0 = 0;
