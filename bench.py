@@ -15,6 +15,8 @@ The timed job is FIXED: `--steps` x `--frames` frame renders.  With N ranks the 
 (gs360/sharding.py, the partition the engine uses), every rank renders its share from its own HBM-resident frames in
 launches of `--frames`, and `value` = the job's pixels / the slowest rank's time: strong scaling of a resident job
 (`"scaling": "strong"`; at N = 1 it is exactly the headline run).  Per-rank times travel in `config.per_rank_seconds`.
+Before the W warm-up steps every rank runs the same launches untimed for `--settle-ms` (150 ms): the device's clocks ramp over
+the first ~100 ms of load, and a 20-step run behind 5 warm-up steps (8 ms in all) otherwise measures the ramp, not the kernel.
 
     python bench.py --gpus 1 --steps 400 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -298,6 +300,8 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--frames", type=int, default=16, help="distinct HBM-resident frames per step (one launch; <= 16)")
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed launches before the warm-up steps until the device has been busy this long (clock ramp); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -411,6 +415,14 @@ def main():
     step_rem = (ctx.make_equirect_call(d_frames[:rem], W, H, C, views, d_out[:rem * N_VIEWS], slot=0,
                                        src_stride=stride if args.stride_pad else 0) if rem else None)
 
+    # settle: the same launches, untimed, until the device has been busy for --settle-ms (clocks ramp over the first ~100 ms of
+    # load: with 5 warm-up steps = 1.6 ms alone the 20 timed steps that follow run 6 % slower than in steady state), then the
+    # caller's W warm-up steps
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(8):
+            step()
+        ctx.sync(0)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -483,7 +495,7 @@ def main():
                        "frames_per_step": nf, "views": N_VIEWS, "out_px_per_step": px_per_step,
                        "device": info["name"], "parallelism": f"frames sharded x{world}, no collective",
                        "job": f"{args.steps} steps x {nf} frames = {args.steps * nf} frame renders, dealt round-robin to {world} rank(s)",
-                       "frames_rank0": n_mine, "per_rank_seconds": per_rank,
+                       "frames_rank0": n_mine, "per_rank_seconds": per_rank, "settle_ms": args.settle_ms,
                        "parity_vs_oracle": parity},
             "roofline": None if not baseline_shape else {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
