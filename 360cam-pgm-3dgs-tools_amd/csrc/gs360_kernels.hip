@@ -683,8 +683,21 @@ __device__ __forceinline__ Eq16CubicTaps eq16_cubic_issue_rgb(const uint8_t* __r
     const int x0 = min(max(ix - 1, 0), W - 5);              // 28-byte aligned read of 24 tap bytes stays in-row
     t.fix = (x0 != ix - 1);
     t.phase = (sy & 31) * 32 + (sx & 31);
-    t.sh = 0;
     const uint32_t col = (uint32_t)x0 * 6u;
+    if ((stride & 3u) == 0 && !__any(iy < 1 || iy > H - 3)) {     // common case, as in cubic_issue_rgb: rows off0 + k * stride, one misalignment
+        const uint32_t off0 = __umul24((uint32_t)(iy - 1), stride) + col;
+        const uint32_t o = (uint32_t)(reinterpret_cast<uintptr_t>(src) + off0) & 3u;
+        t.sh = o * 0x55u;
+        const uint8_t* p0 = src + (off0 - o);
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p0 + (size_t)ky * stride, 4));
+#pragma unroll
+            for (int k = 0; k < 7; ++k) t.r[ky][k] = q[k];
+        }
+        return t;
+    }
+    t.sh = 0;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
         const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
