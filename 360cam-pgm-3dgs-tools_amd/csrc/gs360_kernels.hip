@@ -1360,23 +1360,35 @@ __device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ s
         eq_cubic_blend(t[1], tab_lds, px[s0 + 1]);
     }
     if (__any(!(fast[0] && fast[1] && fast[2] && fast[3]))) {
-        // border windows: ONE copy of the straight-line sampler in a rolled loop (slot picked with uniform selects), so
-        // that its 48 byte loads do not set the register budget of the path above
+        // border windows: ONE copy of the straight-line sampler in a rolled loop, so that its 48 byte loads do not set the
+        // register budget of the path above.  The loop always works on slot 0 and ROTATES the four slots after every turn (plain
+        // register moves, back in place after four turns): picking the slot with `rr == k ? a[k] : ...` made the compiler keep the
+        // coordinate arrays in scratch memory and store them there on the hot path of every tile (+4 B/px of writes, measured as
+        // WRITE_SIZE 54 -> 108 MB per cfg4 launch).
+        float x0 = mxs[0], x1 = mxs[1], x2 = mxs[2], x3 = mxs[3], y0 = mys[0], y1 = mys[1], y2 = mys[2], y3 = mys[3];
+        bool f0 = fast[0], f1 = fast[1], f2 = fast[2], f3 = fast[3];
+        uint32_t p0[3] = {px[0][0], px[0][1], px[0][2]}, p1[3] = {px[1][0], px[1][1], px[1][2]},
+                 p2[3] = {px[2][0], px[2][1], px[2][2]}, p3[3] = {px[3][0], px[3][1], px[3][2]};
 #pragma unroll 1
         for (int rr = 0; rr < 4; ++rr) {
-            const float mx = rr == 0 ? mxs[0] : rr == 1 ? mxs[1] : rr == 2 ? mxs[2] : mxs[3];
-            const float my = rr == 0 ? mys[0] : rr == 1 ? mys[1] : rr == 2 ? mys[2] : mys[3];
-            const bool f = rr == 0 ? fast[0] : rr == 1 ? fast[1] : rr == 2 ? fast[2] : fast[3];
-            if (!f) {
+            if (!f0) {
                 uint32_t o[4];
-                cv_sample_cubic<3>(src, stride, W, H, mx, my, cval, tab, o);
+                cv_sample_cubic<3>(src, stride, W, H, x0, y0, cval, tab, o);
+                p0[0] = o[0]; p0[1] = o[1]; p0[2] = o[2];
+            }
+            const float tx = x0, ty = y0;
+            const bool tf = f0;
+            x0 = x1; x1 = x2; x2 = x3; x3 = tx;
+            y0 = y1; y1 = y2; y2 = y3; y3 = ty;
+            f0 = f1; f1 = f2; f2 = f3; f3 = tf;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        if (rr == k) px[k][c] = o[c];
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t t = p0[c];
+                p0[c] = p1[c]; p1[c] = p2[c]; p2[c] = p3[c]; p3[c] = t;
             }
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { px[0][c] = p0[c]; px[1][c] = p1[c]; px[2][c] = p2[c]; px[3][c] = p3[c]; }
     }
 }
 
