@@ -31,7 +31,7 @@ __device__ __forceinline__ uint16_t sat_u16(float v) { return (uint16_t)min(max(
 // cv2.remap(CV_16U) -- see the file header.  coef: 32 phases x (2 + 4 + 8) float32 1-D coefficients (linear, cubic, lanczos4).
 // All jobs of a call (the views of a dual-fisheye pair) in ONE launch, tiles dealt to the XCDs in contiguous chunks like the
 // 8-bit kernel: six 1750^2 launches left a fifth of the machine idle in their tails.
-template <int C>
+template <int C, int INTERP>
 __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const TableBatch B, const float* __restrict__ coef, const uint16_t c0,
                                                                       const uint16_t c1, const uint16_t c2, const uint16_t c3) {
     int t = (blockIdx.x & 7) * B.chunk + (blockIdx.x >> 3);
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
     const uint16_t cval[4] = {c0, c1, c2, c3};
     const uint16_t* __restrict__ src = reinterpret_cast<const uint16_t*>(T.src);
     const size_t ss = (size_t)T.src_stride >> 1;
-    const int W = T.W, H = T.H, interp = T.interp;
+    const int W = T.W, H = T.H;
+    constexpr int interp = INTERP;            // one interpolation per call (gs360_remap_tables_u16): a compile-time constant
     const int ks = interp == GS360_INTERP_LINEAR ? 2 : (interp == GS360_INTERP_CUBIC ? 4 : 8);
     const float* tab = coef + (interp == GS360_INTERP_LINEAR ? 0 : (interp == GS360_INTERP_CUBIC ? 64 : 192));
     // the job's fields as values (read once), the maps and valid flags of the wavefront's four rows in flight together
@@ -238,21 +239,26 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
             out[c] = sat_u16(sum);
         }
     };
+    // The rolled loop always works on slot 0 and rotates the four slots through the registers (back in place after four turns):
+    // picking the slot with `s == k ? a[k] : ...` made the compiler keep the arrays in scratch.
     static_assert(kRowsPerWave == 4, "four row slots");
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
-        const bool dn = s == 0 ? done[0] : s == 1 ? done[1] : s == 2 ? done[2] : done[3];
-        if (dn || ybase + s >= th) continue;
-        const bool iv = s == 0 ? inval[0] : s == 1 ? inval[1] : s == 2 ? inval[2] : inval[3];
-        const float mx = s == 0 ? mxs[0] : s == 1 ? mxs[1] : s == 2 ? mxs[2] : mxs[3];
-        const float my = s == 0 ? mys[0] : s == 1 ? mys[1] : s == 2 ? mys[2] : mys[3];
-        uint32_t o[4] = {0, 0, 0, 0};
-        sample_one(mx, my, iv, o);
+        if (!done[0] && ybase + s < th) sample_one(mxs[0], mys[0], inval[0], px[0]);
+        const float tx = mxs[0], ty = mys[0];
+        const bool ti = inval[0], td = done[0];
+        uint32_t tp[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 4; ++c) tp[c] = px[0][c];
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-                if (s == k) px[k][c] = o[c];
+        for (int k = 0; k < 3; ++k) {
+            mxs[k] = mxs[k + 1]; mys[k] = mys[k + 1]; inval[k] = inval[k + 1]; done[k] = done[k + 1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) px[k][c] = px[k + 1][c];
+        }
+        mxs[3] = tx; mys[3] = ty; inval[3] = ti; done[3] = td;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) px[3][c] = tp[c];
     }
     // rows leave as whole dwords (96 per 64 RGB pixels) instead of three 2-byte stores per lane
     const RowPack rp = make_row_pack();
@@ -340,12 +346,24 @@ hipError_t launch_table_u16_batch(TableBatch& B, int C, const float* coef, const
     B.chunk = (base + 7) / 8;
     if (base == 0) return hipSuccess;
     dim3 grid((unsigned)(B.chunk * 8)), block(64 * kWaves);
+    const int interp = B.job[0].interp;       // the same for every job of a call
+#define GS360_T16(CC, II) hipLaunchKernelGGL((table_remap_u16_kernel<CC, II>), grid, block, 0, s, B, coef, cval[0], cval[1], cval[2], cval[3])
+#define GS360_T16_C(CC)                                                             \
+    switch (interp) {                                                               \
+        case GS360_INTERP_NEAREST: GS360_T16(CC, GS360_INTERP_NEAREST); break;      \
+        case GS360_INTERP_LINEAR: GS360_T16(CC, GS360_INTERP_LINEAR); break;        \
+        case GS360_INTERP_CUBIC: GS360_T16(CC, GS360_INTERP_CUBIC); break;          \
+        case GS360_INTERP_LANCZOS4: GS360_T16(CC, GS360_INTERP_LANCZOS4); break;    \
+        default: return hipErrorInvalidValue;                                       \
+    }
     switch (C) {
-        case 1: hipLaunchKernelGGL((table_remap_u16_kernel<1>), grid, block, 0, s, B, coef, cval[0], cval[1], cval[2], cval[3]); break;
-        case 3: hipLaunchKernelGGL((table_remap_u16_kernel<3>), grid, block, 0, s, B, coef, cval[0], cval[1], cval[2], cval[3]); break;
-        case 4: hipLaunchKernelGGL((table_remap_u16_kernel<4>), grid, block, 0, s, B, coef, cval[0], cval[1], cval[2], cval[3]); break;
+        case 1: GS360_T16_C(1) break;
+        case 3: GS360_T16_C(3) break;
+        case 4: GS360_T16_C(4) break;
         default: return hipErrorInvalidValue;
     }
+#undef GS360_T16_C
+#undef GS360_T16
     return hipGetLastError();
 }
 
