@@ -637,6 +637,13 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
                 int v = std::atoi(e);
                 if (v >= -1 && v <= 12) L.xcd_group_log2 = v;
             }
+            // Persistent workgroups for the cubic variants (one LDS weight-table fill per workgroup instead of per tile) are OFF:
+            // an equirect tile already spreads the fill over its mirrored halves and ring members (2048-32768 pixels), and the
+            // static walk costs more in balance than the fill saves (cfg2 / cfg1 / cfg3 cubic: 33.4 / 86.5 / 161.5 us per frame
+            // with one tile per workgroup, 35.5 / 90.2 / 177.5 with 2048 persistent ones; profiles/r03/persistent_cubic_ab.txt).
+            // The cv2 table kernel, 1024 pixels per tile, gains 12 % from it (launch_table_batch).
+            L.persist_blocks = 0;
+            if (const char* e = std::getenv("GS360_EQ_PERSIST")) L.persist_blocks = std::atoi(e);   // probes: grid cap
             for (int f = 0; f < nf; ++f) {
                 L.src[f] = (const uint8_t*)src_frames[f0 + f];
                 L.mask[f] = mask_frames ? (const uint8_t*)mask_frames[f0 + f] : nullptr;
@@ -707,6 +714,8 @@ int gs360_remap_tables_u8(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs,
     for (int j0 = 0; j0 < n_jobs; j0 += GS360_MAX_VIEWS) {
         TableBatch B;
         B.n_jobs = 0;
+        B.persist_blocks = c->prop.multiProcessorCount * 8;      // two rounds of the four workgroups a CU holds (bicubic RGB)
+        if (const char* e = std::getenv("GS360_TABLE_PERSIST")) B.persist_blocks = std::atoi(e);   // probes: 0 = one tile per workgroup
         for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
             if (jobs[j].h == 0 || jobs[j].w == 0) continue;
             if (int rc = fill_table_job(c, jobs[j], C, interp, border_value, &B.job[B.n_jobs])) return rc;
@@ -743,6 +752,7 @@ int gs360_remap_tables_u16(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs
     for (int j0 = 0; j0 < n_jobs; j0 += GS360_MAX_VIEWS) {
         TableBatch B;
         B.n_jobs = 0;
+        B.persist_blocks = 0;
         for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
             const gs360_remap_job& J = jobs[j];
             if (!J.src || !J.map_x || !J.map_y || !J.dst) return fail(GS360_ERR_ARG, "NULL argument");
@@ -826,6 +836,8 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
         for (int k = 0; k < nv; ++k)
             if (calibs[v0 + k].width < 8 || (uint64_t)L.src_stride * (uint64_t)calibs[v0 + k].height >= ((uint64_t)1 << 32)) L.pipelined = 0;
         if ((uint64_t)L.src_stride >= ((uint64_t)1 << 24)) L.pipelined = 0;
+        L.persist_blocks = c->prop.multiProcessorCount * 8;
+        if (const char* e = std::getenv("GS360_TABLE_PERSIST")) L.persist_blocks = std::atoi(e);
         HIP_TRY(launch_fisheye(L, C, c->stream[slot]));
     }
     return GS360_OK;

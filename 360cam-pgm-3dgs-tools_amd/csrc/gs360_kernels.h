@@ -66,6 +66,9 @@ struct EqLaunch {
                               // contiguous chunks would hand whole rings to single XCDs); -1: contiguous chunks (`chunk`)
     int32_t ring_first[GS360_MAX_VIEWS];   // 32-bit on purpose: sub-dword fields of the kernel argument are fetched with VECTOR loads
     int32_t ring_count[GS360_MAX_VIEWS];   // (a memory round trip per wavefront), dwords with scalar loads
+    // The cubic variants run persistent workgroups (one LDS weight table per workgroup): the caller sets `persist_blocks` (grid
+    // cap, 0 = one tile per workgroup); the launcher fills `grid_total` (positions of the tile order to walk).
+    int32_t persist_blocks, grid_total;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -92,6 +95,7 @@ struct TableLaunch {
 struct TableBatch {
     TableLaunch job[GS360_MAX_VIEWS];
     int32_t n_jobs, total_tiles, chunk;
+    int32_t persist_blocks;   // grid cap for kernels whose workgroups walk several tiles (0: one tile per workgroup); set by the caller
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -116,6 +120,7 @@ struct FeCommon {          // per-launch constants of fe_views_kernel
     uint8_t cval[4];
     const int16_t* cubic_tab;
     int32_t pipelined;
+    int32_t grid_total;      // positions of the tile order (the persistent bicubic RGB variant walks them with stride gridDim.x)
 };
 
 struct FeBatch {           // kernel argument: all views of one launch + the common block
@@ -131,6 +136,7 @@ struct FeLaunch {          // host-side batch description
     uint8_t cval[4];
     const int16_t* cubic_tab;
     int32_t pipelined;
+    int32_t persist_blocks;  // grid cap of the persistent bicubic RGB variant (0: one tile per workgroup)
 };
 
 // ------------------------------------------------------------------------------------------------

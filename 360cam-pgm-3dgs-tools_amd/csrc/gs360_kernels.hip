@@ -826,34 +826,33 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
 // row-per-slot lane map: 3 / 4 / 6 wavefronts: 27.4 / 23.1 / 24.3; blocked lane map: 3 / 4 / 5 / 6: 22.1 / 20.8 / 20.3 /
 // 23.3 (6 spills).  5 is also the better choice for the arithmetic-bound large-view configs (cfg1/3/5).  The cubic
 // variant needs 128 VGPRs and stays at 4.
-template <int C, bool CUBIC, bool MASKED, int ES = 1>      // ES: bytes per sample (1: uint8, 2: uint16 -- row-per-slot lane map, no mask)
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES, (CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
-    // XCD-aware tile order: XCD x (= blockIdx % 8) walks tiles [x*chunk, (x+1)*chunk), or -- when the launch mixes rings of
+// LDS of a workgroup besides the cubic weight table: the blocked store's transpose slices (256 dwords per wavefront; its read-back
+// may touch the dword after the slice, which is the next slice or the first parked dword -- never used), then the parked ring
+// coordinates (see the member loop).  Every thread / wavefront only ever touches its own part: no barrier.
+template <int C, bool CUBIC, int ES>
+struct EqLds {
+    static constexpr bool kBlocked = (C == 3) && (ES == 1) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map available
+    static constexpr int kParkN = (CUBIC && ES == 2) ? 3 : (CUBIC ? GS360_RING_PARK_CUBIC : GS360_RING_PARK);     // 0 none, 1 latitude only, 3 all three
+    static constexpr int kBlkDw = kBlocked ? kWaves * 256 : 0;
+    static constexpr int kParkDw = kParkN * kRowsPerWave * 64 * kWaves;
+    static constexpr int kDwords = kBlkDw + (kParkDw ? kParkDw : 4);
+};
+
+// One tile of a ring (all its members, both halves) -- the body of eq_views_kernel.  `b` is the workgroup's position in the
+// tile order (blockIdx.x, or the persistent walk of the cubic variants).
+template <int C, bool CUBIC, bool MASKED, int ES>
+__device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, const int16_t* s_wtab, uint32_t* const s_lds) {
+    // XCD-aware tile order: XCD x (= b % 8) walks tiles [x*chunk, (x+1)*chunk), or -- when the launch mixes rings of
     // different sizes, whose tiles differ in cost -- runs of 2^g consecutive tiles dealt round-robin to the XCDs
-    int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
     if (L.xcd_group_log2 >= 0) {
         const int q = b >> 3, g = L.xcd_group_log2;
         t = ((((q >> g) << 3) + (b & 7)) << g) + (q & ((1 << g) - 1));
     }
     if (t >= L.total_tiles) return;
-    // cubic: the 32 KiB weight table would otherwise occupy the whole vector L1 and every lane reads a different
-    // 32-byte entry of it; one coalesced copy per workgroup into LDS keeps the L1 for source lines
-    __shared__ __attribute__((aligned(16))) int16_t s_wtab[CUBIC ? 32 * 32 * 16 : 8];
-    if constexpr (CUBIC) {
-        const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
-        uint4* l = reinterpret_cast<uint4*>(s_wtab);
-#pragma unroll
-        for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
-        __syncthreads();
-    }
-    constexpr bool kBlocked = (C == 3) && (ES == 1) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map, see below
-    // LDS: the blocked store's transpose slices (256 dwords per wavefront; its read-back may touch the dword after the slice,
-    // which is the next slice or the first parked dword -- never used), then the parked ring coordinates (see below)
-    constexpr int kParkN = (CUBIC && ES == 2) ? 3 : (CUBIC ? GS360_RING_PARK_CUBIC : GS360_RING_PARK);     // 0 none, 1 latitude only, 3 all three
-    constexpr int kBlkDw = kBlocked ? kWaves * 256 : 0;
-    constexpr int kParkDw = kParkN * kRowsPerWave * 64 * kWaves;
-    __shared__ uint32_t s_lds[kBlkDw + (kParkDw ? kParkDw : 4)];
+    constexpr bool kBlocked = EqLds<C, CUBIC, ES>::kBlocked;
+    constexpr int kParkN = EqLds<C, CUBIC, ES>::kParkN;
+    constexpr int kBlkDw = EqLds<C, CUBIC, ES>::kBlkDw;
     uint32_t* const s_blk = s_lds;
     int* const s_park = reinterpret_cast<int*>(s_lds + kBlkDw);
     int f = t / L.tiles_per_frame;
@@ -866,7 +865,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CU
     const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
 
     // the wavefront index as a scalar: everything derived from it (row slots, patch origins) then lives in SGPRs
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (the lane index behind an optimisation barrier in the persistent variants: nothing derived from it is hoisted out of the walk)
+    const int lane = CUBIC ? lane_here() : (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half_w = (V.out_w + 1) >> 1;               // columns [0, half_w) are computed, the rest mirrored
     const int x0 = tile_x * kTileW;
     const int n_px = min(kTileW, half_w - x0);
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CU
         sxm[s] = eq_lon_norm(sxm[s], W32);
     }
     const bool centre_dup = (V.out_w & 1) && (x0 + n_px == half_w);
-    const RowPack rp = make_row_pack();
+    const RowPack rp = make_row_pack(lane);
     // The 12 shared coordinates of a lane would stay live across the whole member loop on top of the sampler's own peak
     // (bilinear: 123 registers against the 96 of 5 wavefronts per SIMD).  Each thread parks its own values in LDS and takes
     // them back at the top of every iteration -- no barrier, a thread only ever reads what it wrote.
@@ -1108,6 +1108,28 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CU
         }
     }
     members(std::integral_constant<int, 0>{});
+}
+
+// The cubic variants keep a 32 KiB LDS copy of the weight table (left in global memory it would occupy the whole vector L1,
+// every lane reading another 32-byte entry), filled once per workgroup.  Their workgroups CAN be persistent -- a capped grid whose
+// workgroups walk positions b, b + gridDim.x, ... of the tile order (the stride is a multiple of 8: a workgroup stays on its
+// XCD's tiles) -- but the C ABI leaves that off (`persist_blocks` = 0 -> grid_total == gridDim.x, one turn of the loop): measured
+// slower than one tile per workgroup, see equirect_views_impl.
+template <int C, bool CUBIC, bool MASKED, int ES = 1>      // ES: bytes per sample (1: uint8, 2: uint16 -- row-per-slot lane map, no mask)
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES, (CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
+    __shared__ __attribute__((aligned(16))) int16_t s_wtab[CUBIC ? 32 * 32 * 16 : 8];
+    __shared__ uint32_t s_lds[EqLds<C, CUBIC, ES>::kDwords];
+    if constexpr (CUBIC) {
+        const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
+        uint4* l = reinterpret_cast<uint4*>(s_wtab);
+#pragma unroll
+        for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+        __syncthreads();
+#pragma unroll 1
+        for (int b = blockIdx.x; b < L.grid_total; b += gridDim.x) eq_views_tile<C, CUBIC, MASKED, ES>(L, b, s_wtab, s_lds);
+    } else {
+        eq_views_tile<C, CUBIC, MASKED, ES>(L, blockIdx.x, s_wtab, s_lds);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1395,8 +1417,7 @@ __device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ s
 // One instantiation per interpolation: the 8x8 Lanczos window would otherwise set the register budget (and with it the
 // occupancy) of the bilinear path.
 template <int C, int INTERP>
-__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBatch B) {
-    int b = blockIdx.x;
+__device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int b, const int16_t* s_wtab) {
     int t = (b & 7) * B.chunk + (b >> 3);
     if (t >= B.total_tiles) return;
     int j = 0;
@@ -1405,23 +1426,15 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
     t -= L.tile_base;
     const int tiles_x = L.tiles_x;
     int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (behind an optimisation barrier: in the persistent variant the lane-derived constants would otherwise be hoisted out of the
+    // tile loop and cost the kernel its fourth wavefront per SIMD)
+    const int lane = lane_here(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const RowPack rp = make_row_pack(lane);
     const int x0 = tile_x * kTileW;
     const int n_px = min(kTileW, L.w - x0);
     const int xc = min(x0 + lane, L.w - 1);
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
-    const RowPack rp = make_row_pack();
     constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
-    if constexpr (kFastCubic) {
-        if (L.pipelined) {                    // (wave-uniform; no thread has left the workgroup yet)
-            const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
-            uint4* l = reinterpret_cast<uint4*>(s_wtab);
-#pragma unroll
-            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
-            __syncthreads();
-        }
-    }
     if ((INTERP == GS360_INTERP_LINEAR || INTERP == GS360_INTERP_NEAREST || kFastCubic) && L.pipelined) {
         // maps of the wavefront's 4 rows -> all gathers in flight -> blend -> border/valid fix-ups -> packed stores
         const int ybase = tile_y * kTileH + wave * kRowsPerWave;
@@ -1495,6 +1508,30 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
     }
 }
 
+// Bicubic RGB keeps a 32 KiB LDS copy of the weight table: filled once per workgroup, so its workgroups are PERSISTENT (the
+// launcher caps the grid at a few workgroups per CU and each walks tiles b, b + gridDim.x, ... -- the stride is a multiple of 8,
+// so a workgroup stays inside its XCD's chunk of tiles).  One 64 x 16 tile per workgroup meant 32 bytes of table fill per
+// output pixel: as many bytes as the pixel's own weight entry, eight more 1 KiB loads per wavefront next to its sixteen row
+// gathers, and a load -> LDS -> barrier bubble in front of every tile.
+template <int C, int INTERP>
+__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBatch B) {
+    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
+    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
+    if constexpr (kFastCubic) {
+        if (B.job[0].cubic_tab) {             // (the context's table: the same pointer in every job)
+            const uint4* g = reinterpret_cast<const uint4*>(B.job[0].cubic_tab);
+            uint4* l = reinterpret_cast<uint4*>(s_wtab);
+#pragma unroll
+            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int b = blockIdx.x; b < B.chunk * 8; b += gridDim.x) table_remap_tile<C, INTERP>(B, b, s_wtab);
+    } else {
+        table_remap_tile<C, INTERP>(B, blockIdx.x, s_wtab);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // FE-SPEC v1: fused fisheye -> perspective
 // ------------------------------------------------------------------------------------------------
@@ -1502,9 +1539,8 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
 // (scalar loads on demand): copying a dynamically indexed 148-byte block into a local made the compiler spill the whole
 // argument array to scratch (2368 B/lane, 13x slower).
 template <int C, int INTERP>
-__global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) {
+__device__ __forceinline__ void fe_views_tile(const FeBatch& B, const int b, const int16_t* s_wtab) {
     const FeCommon& L = B.common;
-    int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
     if (t >= L.total_tiles) return;
     int j = 0;
@@ -1512,25 +1548,16 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
     const FeView& V = B.view[j];              // a reference: fields are fetched from the kernel argument on demand
     t -= V.tile_base;
     int tile_y = t / V.tiles_x, tile_x = t - tile_y * V.tiles_x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
+    // (persistent variant: lane-derived constants stay inside the tile, see table_remap_tile)
+    const int lane = kFastCubic ? lane_here() : (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = tile_x * kTileW;
     const int n_px = min(kTileW, V.out_w - x0);
     const int xc = min(x0 + lane, V.out_w - 1);
     const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
     const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(V.dst) & 3) == 0);
-    const RowPack rp = make_row_pack();
+    const RowPack rp = make_row_pack(lane);
     const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
-    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
-    if constexpr (kFastCubic) {
-        if (L.pipelined) {                    // the weight table into LDS, as in the table kernel
-            const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
-            uint4* l = reinterpret_cast<uint4*>(s_wtab);
-#pragma unroll
-            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
-            __syncthreads();
-        }
-    }
 
     const int ybase = tile_y * kTileH + wave * kRowsPerWave;
     const bool pipelined = (INTERP == GS360_INTERP_LINEAR) && L.pipelined;
@@ -1619,6 +1646,27 @@ __global__ __launch_bounds__(64 * kWaves) void fe_views_kernel(const FeBatch B) 
     }
 }
 
+// (bicubic RGB: persistent workgroups around one LDS weight-table fill, as in table_remap_kernel)
+template <int C, int INTERP>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((INTERP == GS360_INTERP_CUBIC && C == 3) ? 4 : 1, 8)))
+void fe_views_kernel(const FeBatch B) {
+    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
+    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
+    if constexpr (kFastCubic) {
+        if (B.common.pipelined) {
+            const uint4* g = reinterpret_cast<const uint4*>(B.common.cubic_tab);
+            uint4* l = reinterpret_cast<uint4*>(s_wtab);
+#pragma unroll
+            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int b = blockIdx.x; b < B.common.grid_total; b += gridDim.x) fe_views_tile<C, INTERP>(B, b, s_wtab);
+    } else {
+        fe_views_tile<C, INTERP>(B, blockIdx.x, s_wtab);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1643,8 +1691,17 @@ hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
-    dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
+// persistent grid of the cubic variants: at most `persist_blocks` workgroups (rounded to the XCD count) walk the tile order
+static EqLaunch eq_persistent(const EqLaunch& L0, dim3& grid) {
+    EqLaunch L = L0;
+    L.grid_total = (int32_t)grid.x;
+    if (L.persist_blocks > 0 && (unsigned)L.persist_blocks < grid.x) grid.x = (unsigned)(L.persist_blocks + 7) & ~7u;
+    return L;
+}
+
+hipError_t launch_equirect_cubic(const EqLaunch& L0, int C, hipStream_t s) {
+    dim3 grid(eq_grid_blocks(L0)), block(64 * kWaves);
+    const EqLaunch L = eq_persistent(L0, grid);
     const bool masked = L.mask[0] != nullptr;
     switch (C) {
         case 1: if (masked) hipLaunchKernelGGL((eq_views_kernel<1, true, true>), grid, block, 0, s, L);
@@ -1658,8 +1715,9 @@ hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_equirect_u16(const EqLaunch& L, int C, bool cubic, hipStream_t s) {
-    dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
+hipError_t launch_equirect_u16(const EqLaunch& L0, int C, bool cubic, hipStream_t s) {
+    dim3 grid(eq_grid_blocks(L0)), block(64 * kWaves);
+    const EqLaunch L = cubic ? eq_persistent(L0, grid) : L0;
     if (cubic) {
         switch (C) {
             case 1: hipLaunchKernelGGL((eq_views_kernel<1, true, false, 2>), grid, block, 0, s, L); break;
@@ -1714,6 +1772,9 @@ hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s) {
     B.chunk = (base + 7) / 8;
     if (base == 0) return hipSuccess;
     dim3 grid((unsigned)(B.chunk * 8)), block(64 * kWaves);
+    // persistent workgroups for the kernel with a per-workgroup LDS table (see table_remap_kernel)
+    if (C == 3 && B.job[0].interp == GS360_INTERP_CUBIC && B.persist_blocks > 0 && (unsigned)B.persist_blocks < grid.x)
+        grid.x = (unsigned)(B.persist_blocks + 7) & ~7u;
     switch (C) {
         case 1: launch_table_c<1>(B, grid, block, s); break;
         case 3: launch_table_c<3>(B, grid, block, s); break;
@@ -1727,6 +1788,7 @@ hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
     TableBatch B;
     B.job[0] = L;
     B.n_jobs = 1;
+    B.persist_blocks = 0;
     return launch_table_batch(B, C, s);
 }
 
@@ -1749,6 +1811,9 @@ hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s) {
     K.pipelined = L.pipelined;
     if (base == 0) return hipSuccess;
     dim3 grid((unsigned)(K.chunk * 8)), block(64 * kWaves);
+    K.grid_total = (int32_t)grid.x;
+    if (C == 3 && L.interp == GS360_INTERP_CUBIC && L.persist_blocks > 0 && (unsigned)L.persist_blocks < grid.x)
+        grid.x = (unsigned)(L.persist_blocks + 7) & ~7u;
     switch (C) {
         case 1: launch_fisheye_c<1>(B, grid, block, s); break;
         case 3: launch_fisheye_c<3>(B, grid, block, s); break;

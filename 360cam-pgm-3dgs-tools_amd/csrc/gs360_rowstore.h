@@ -14,8 +14,8 @@ struct RowPack {
     uint32_t sel;   // v_perm_b32 selector that cuts dword `lane` out of the two 24-bit pixels (pa in bytes 0..3, pb in 4..7)
     int lane;
 };
-__device__ __forceinline__ RowPack make_row_pack() {
-    const int lane = threadIdx.x & 63, t = lane / 3;
+__device__ __forceinline__ RowPack make_row_pack(const int lane) {
+    const int t = lane / 3;
     RowPack rp;
     rp.a4 = 4 * (lane + t);
     rp.sh = 8 * (lane - 3 * t);
@@ -23,6 +23,7 @@ __device__ __forceinline__ RowPack make_row_pack() {
     rp.lane = lane;
     return rp;
 }
+__device__ __forceinline__ RowPack make_row_pack() { return make_row_pack((int)(threadIdx.x & 63)); }
 // Row store of 16-bit pixels.  RGB: lane l holds pixel l (or n_px-1-l) as A = c0 | c1 << 16, B = c2; the row's dword stream
 // takes dword 3m from A[2m], 3m+1 from B[2m] | A[2m+1] << 16, 3m+2 from A[2m+1] >> 16 | B[2m+1] << 16: two cross-lane reads per
 // dword, 96 dwords per 64 pixels = one and a half store instructions of whole dwords.
