@@ -60,6 +60,16 @@ __device__ __forceinline__ int uniform_here(int v) {
     return v;
 }
 
+// "some lane": the comparison's lane mask tested directly.  (__any() goes through an int -- v_cndmask 0/1 + v_cmp_ne per call --
+// and these tests sit in the arithmetic-bound inner loops.)
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// min(max(x, 0), hi) for a wave-uniform hi >= 0 as ONE v_med3_i32 (the compiler only fuses the pair when both bounds are constants)
+__device__ __forceinline__ int clamp0_uniform(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+
 // 8 bytes starting at the (unaligned) address p, fetched as ONE dword-aligned 12-byte access and shifted into
 // place with v_alignbyte.  The texture-address path merges dword-aligned lane accesses of a quad into cache-line
 // requests; byte-misaligned ones are looked up lane by lane (measured: 96 tag lookups per 64-lane instruction).
@@ -314,6 +324,13 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot2_i16(uint32_t taps, uint32_t weights, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, taps), __builtin_bit_cast(s16x2, weights), acc, false);
 }
+// First multiply-add of a chain: the start value (rounding constant) rides in a SCALAR register as the VOP3P form's third operand.
+// Left to the compiler a constant start becomes v_mov + the accumulate-in-place VOP2 form -- one more vector instruction per chain.
+__device__ __forceinline__ int dot2_i16_from(uint32_t taps, uint32_t weights, int start_uniform) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(taps), "v"(weights), "s"(start_uniform));
+    return r;
+}
 // v_perm_b32(a, b, sel) selector: result = (0, hi, 0, lo) where lo / hi index the bytes of {a (4..7), b (0..3)}
 #define GS360_PAIR(lo, hi) (0x0c000c00u | ((uint32_t)(hi) << 16) | (uint32_t)(lo))
 
@@ -326,19 +343,19 @@ __device__ __forceinline__ void eq_blend(const EqTaps<C>& t, int sx, int sy, uin
     const uint32_t wr0 = ah * (uint32_t)(32 - fy), wr1 = ah * (uint32_t)fy;
     if constexpr (C == 3) {          // row bytes: r0 g0 b0 r1 | g1 b1 . .
         out[0] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.x, t.t1.x, GS360_PAIR(0, 3)), wr1,
-                                    dot2_i16(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 3)), wr0, 512)) >> 10;
+                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 3)), wr0, 512)) >> 10;
         out[1] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(1, 4)), wr1,
-                                    dot2_i16(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(1, 4)), wr0, 512)) >> 10;
+                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(1, 4)), wr0, 512)) >> 10;
         out[2] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(2, 5)), wr1,
-                                    dot2_i16(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(2, 5)), wr0, 512)) >> 10;
+                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(2, 5)), wr0, 512)) >> 10;
     } else if constexpr (C == 4) {   // row bytes: r0 g0 b0 a0 | r1 g1 b1 a1
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             out[c] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(c, 4 + c)), wr1,
-                                        dot2_i16(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(c, 4 + c)), wr0, 512)) >> 10;
+                                        dot2_i16_from(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(c, 4 + c)), wr0, 512)) >> 10;
     } else {                         // row bytes: v0 v1
         out[0] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.x, t.t1.x, GS360_PAIR(0, 1)), wr1,
-                                    dot2_i16(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 1)), wr0, 512)) >> 10;
+                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 1)), wr0, 512)) >> 10;
     }
 }
 
@@ -370,38 +387,46 @@ struct EqCubicTaps {
     bool fix;
 };
 
-// window anchored at texel (ix, iy) with phase (fx, fy); `fix` = the window's columns could not be read in place
-__device__ __forceinline__ EqCubicTaps cubic_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, int W, int H,
+// window anchored at texel (ix, iy) with phase (fx, fy); `fix` = the window's columns could not be read in place.
+// `stride4` (wave-uniform): the row stride is a multiple of 4, so all four rows start at the same misalignment (`sh` = that one
+// value; otherwise four 2-bit fields).  Every read is src + a 32-bit lane offset: scalar base + vector offset addressing, no
+// 64-bit vector adds.
+__device__ __forceinline__ EqCubicTaps cubic_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, bool stride4, int W, int H,
                                                        int ix, int iy, int fx, int fy) {
     EqCubicTaps t;
-    const int x0 = min(max(ix - 1, 0), W - 6);              // 16-byte aligned read of 12 tap bytes stays in-row
+    const int x0 = clamp0_uniform(ix - 1, W - 6);           // 16-byte aligned read of 12 tap bytes stays in-row
     t.fix = (x0 != ix - 1);
     t.phase = fy * 32 + fx;
     const uint32_t col = (uint32_t)x0 * 3u;
-    // Common case (wave-uniform test): no window of the wavefront touches the first or the last image row and the stride is a
-    // multiple of 4 -- the four rows are off0 + k * stride with ONE misalignment: 8 address instructions instead of 26 (the
-    // kernel is arithmetic-bound).
-    if ((stride & 3u) == 0 && !__any(iy < 1 || iy > H - 3)) {
-        const uint32_t off0 = __umul24((uint32_t)(iy - 1), stride) + col;
-        const uint32_t o = (uint32_t)(reinterpret_cast<uintptr_t>(src) + off0) & 3u;
-        t.sh = o * 0x55u;
-        const uint8_t* p0 = src + (off0 - o);
+    uint32_t offs[4];                                       // the branches meet on 32-bit offsets, not on pointers
+    if (stride4) {
+        const uint32_t o = ((uint32_t)reinterpret_cast<uintptr_t>(src) + col) & 3u;
+        t.sh = o;
+        const uint32_t cb = col - o;
+        // Common case (wave-uniform test): no window of the wavefront touches the first or the last image row -- the four rows
+        // are off0 + k * stride (the kernel is arithmetic-bound).
+        if (!any_lane(iy < 1 || iy > H - 3)) {
+            offs[0] = __umul24((uint32_t)(iy - 1), stride) + cb;
+#pragma unroll
+            for (int ky = 1; ky < 4; ++ky) offs[ky] = offs[ky - 1] + stride;
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) offs[ky] = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + cb;
+        }
+    } else {
+        t.sh = 0;
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p0 + (size_t)ky * stride, 4));
-            t.raw[ky][0] = q[0]; t.raw[ky][1] = q[1]; t.raw[ky][2] = q[2]; t.raw[ky][3] = q[3];
+            const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
+            const uint32_t o = ((uint32_t)reinterpret_cast<uintptr_t>(src) + off) & 3u;
+            offs[ky] = off - o;
+            t.sh |= o << (2 * ky);
         }
-        return t;
     }
-    t.sh = 0;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
-        const uint8_t* p = src + off;
-        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (size_t)offs[ky], 4));
         t.raw[ky][0] = q[0]; t.raw[ky][1] = q[1]; t.raw[ky][2] = q[2]; t.raw[ky][3] = q[3];
-        t.sh |= o << (2 * ky);
     }
     return t;
 }
@@ -411,38 +436,54 @@ __device__ __forceinline__ EqCubicTaps cubic_issue_rgb(const uint8_t* __restrict
 struct EqSrc {
     int W, H;
     int64_t src_stride, mask_stride;
+    bool stride4;        // src_stride % 4 == 0
 };
 
 __device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqSrc& L, const uint8_t* __restrict__ src, int sx, int sy) {
-    return cubic_issue_rgb(src, (uint32_t)L.src_stride, L.W, L.H, sx >> 5, sy >> 5, sx & 31, sy & 31);
+    return cubic_issue_rgb(src, (uint32_t)L.src_stride, L.stride4, L.W, L.H, sx >> 5, sy >> 5, sx & 31, sy & 31);
 }
 
 // 48 multiply-adds per pixel as 24 v_dot2_i32_i16 (see eq_blend): constant selectors -- the 12 tap bytes of a row are
 // b0..b11, channel c owns b[c], b[3+c], b[6+c], b[9+c] -- and the table already stores the weights as int16 pairs.
 // `wtab` is the LDS copy in the equirect kernel and the global table in the cv2 kernels.
 
-__device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, const int16_t* wtab, uint32_t (&out)[4]) {
-    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
-    const uint4 wa = wq[0], wb = wq[1];
-    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-    int acc[3] = {0, 0, 0};
+template <bool ONE_SHIFT>
+__device__ __forceinline__ void eq_cubic_rows(const EqCubicTaps& t, const uint32_t (&wpk)[8], int (&acc)[3]) {
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t o = (t.sh >> (2 * ky)) & 3u;
+        const uint32_t o = ONE_SHIFT ? t.sh : ((t.sh >> (2 * ky)) & 3u);
         const uint32_t d0 = __builtin_amdgcn_alignbyte(t.raw[ky][1], t.raw[ky][0], o);
         const uint32_t d1 = __builtin_amdgcn_alignbyte(t.raw[ky][2], t.raw[ky][1], o);
         const uint32_t d2 = __builtin_amdgcn_alignbyte(t.raw[ky][3], t.raw[ky][2], o);
         const uint32_t w01 = wpk[2 * ky], w23 = wpk[2 * ky + 1];
-        // perm(a, b, sel): bytes 0..3 come from b, 4..7 from a
-        acc[0] = dot2_i16(__builtin_amdgcn_perm(d0, d0, GS360_PAIR(0, 3)), w01, acc[0]);            // b0, b3
+        // perm(a, b, sel): bytes 0..3 come from b, 4..7 from a.  Row 0 starts the three chains from the rounding constant.
+        const uint32_t p0 = __builtin_amdgcn_perm(d0, d0, GS360_PAIR(0, 3));             // b0, b3
+        const uint32_t p1 = __builtin_amdgcn_perm(d1, d0, GS360_PAIR(1, 4));             // b1 = d0.1, b4 = d1.0
+        const uint32_t p2 = __builtin_amdgcn_perm(d1, d0, GS360_PAIR(2, 5));             // b2 = d0.2, b5 = d1.1
+        if (ky == 0) {
+            acc[0] = dot2_i16_from(p0, w01, 1 << 14);
+            acc[1] = dot2_i16_from(p1, w01, 1 << 14);
+            acc[2] = dot2_i16_from(p2, w01, 1 << 14);
+        } else {
+            acc[0] = dot2_i16(p0, w01, acc[0]);
+            acc[1] = dot2_i16(p1, w01, acc[1]);
+            acc[2] = dot2_i16(p2, w01, acc[2]);
+        }
         acc[0] = dot2_i16(__builtin_amdgcn_perm(d2, d1, GS360_PAIR(2, 5)), w23, acc[0]);            // b6 = d1.2, b9 = d2.1
-        acc[1] = dot2_i16(__builtin_amdgcn_perm(d1, d0, GS360_PAIR(1, 4)), w01, acc[1]);            // b1 = d0.1, b4 = d1.0
         acc[1] = dot2_i16(__builtin_amdgcn_perm(d2, d1, GS360_PAIR(3, 6)), w23, acc[1]);            // b7 = d1.3, b10 = d2.2
-        acc[2] = dot2_i16(__builtin_amdgcn_perm(d1, d0, GS360_PAIR(2, 5)), w01, acc[2]);            // b2 = d0.2, b5 = d1.1
         acc[2] = dot2_i16(__builtin_amdgcn_perm(d2, d2, GS360_PAIR(0, 3)), w23, acc[2]);            // b8 = d2.0, b11 = d2.3
     }
+}
+
+__device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, const int16_t* wtab, bool stride4, uint32_t (&out)[4]) {
+    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
+    const uint4 wa = wq[0], wb = wq[1];
+    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    int acc[3];                                           // (sum + 2^14) >> 15: the chains start at 2^14
+    if (stride4) eq_cubic_rows<true>(t, wpk, acc);        // wave-uniform
+    else eq_cubic_rows<false>(t, wpk, acc);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((acc[c] + (1 << 14)) >> 15, 0), 255);
+    for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max(acc[c] >> 15, 0), 255);
 }
 
 // generic cubic sample: columns wrap, rows clamp (any channel count; also the repair path of the RGB fast path)
@@ -536,9 +577,9 @@ __device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restric
                 EqCubicTaps ta = eq_cubic_fetch(L, src, sxs[s0], sys[s0]);
                 EqCubicTaps tb = eq_cubic_fetch(L, src, sxs[s0 + 1], sys[s0 + 1]);
                 __builtin_amdgcn_sched_barrier(0);        // all 8 row reads in flight before the first result is touched
-                eq_cubic_blend(ta, wtab, px[s0]);
-                eq_cubic_blend(tb, wtab, px[s0 + 1]);
-                if (__any(ta.fix | tb.fix)) {
+                eq_cubic_blend(ta, wtab, L.stride4, px[s0]);
+                eq_cubic_blend(tb, wtab, L.stride4, px[s0 + 1]);
+                if (any_lane(ta.fix | tb.fix)) {
                     if (ta.fix) eq_cubic_slow<C>(L, wtab, src, sxs[s0], sys[s0], px[s0]);
                     if (tb.fix) eq_cubic_slow<C>(L, wtab, src, sxs[s0 + 1], sys[s0 + 1], px[s0 + 1]);
                 }
@@ -576,7 +617,7 @@ __device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restric
         eq_taps_finish<C>(taps[s]);
         eq_blend<C>(taps[s], sxs[s], sys[s], px[s]);
     }
-    if (__any(any_fix)) {
+    if (any_lane(any_fix)) {
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s)
             if (taps[s].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
@@ -684,7 +725,7 @@ __device__ __forceinline__ Eq16CubicTaps eq16_cubic_issue_rgb(const uint8_t* __r
     t.fix = (x0 != ix - 1);
     t.phase = (sy & 31) * 32 + (sx & 31);
     const uint32_t col = (uint32_t)x0 * 6u;
-    if ((stride & 3u) == 0 && !__any(iy < 1 || iy > H - 3)) {     // common case, as in cubic_issue_rgb: rows off0 + k * stride, one misalignment
+    if ((stride & 3u) == 0 && !any_lane(iy < 1 || iy > H - 3)) {     // common case, as in cubic_issue_rgb: rows off0 + k * stride, one misalignment
         const uint32_t off0 = __umul24((uint32_t)(iy - 1), stride) + col;
         const uint32_t o = (uint32_t)(reinterpret_cast<uintptr_t>(src) + off0) & 3u;
         t.sh = o * 0x55u;
@@ -781,7 +822,7 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
                 const Eq16CubicTaps t = eq16_cubic_issue_rgb(src, (uint32_t)L.src_stride, L.W, L.H, sxs[s], sys[s]);
                 __builtin_amdgcn_sched_barrier(0);
                 eq16_cubic_blend_rgb(t, wtab, px[s]);
-                if (__any(t.fix)) {
+                if (any_lane(t.fix)) {
                     if (t.fix) eq16_cubic_slow<C>(L, wtab, src, sxs[s], sys[s], px[s]);
                 }
             }
@@ -796,7 +837,7 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
             __builtin_amdgcn_sched_barrier(0);            // every gather of the pass is in flight before the first is consumed
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s) eq16_blend_rgb(taps[s], sxs[s], sys[s], px[s]);
-            if (__any(any_fix)) {
+            if (any_lane(any_fix)) {
 #pragma unroll
                 for (int s = 0; s < kRowsPerWave; ++s)
                     if (taps[s].fix) eq16_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
@@ -1047,6 +1088,7 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
     S.H = uniform_here(L.H);
     S.src_stride = (int64_t)(uint32_t)uniform_here((int)L.src_stride);          // < 2^24 (checked by the host)
     S.mask_stride = (int64_t)(uint32_t)uniform_here((int)L.mask_stride);        // H * mask_stride < 2^32
+    S.stride4 = uniform_here((int)(L.src_stride & 3)) == 0;
     const int out_h = uniform_here(V.out_h), out_w = uniform_here(V.out_w);
     const int y0x2 = uniform_here(2 * L.y0i32);
     const int dst_base = uniform_here(f * L.n_views + k0);
@@ -1079,11 +1121,15 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
         }
         const bool base_aligned = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
         int sx_l[kRowsPerWave], sx_m[kRowsPerWave], sy_m[kRowsPerWave], ys_m[kRowsPerWave];
+        // latitude of a flipped member, y0x2 - sys, and of the others, sys, as ONE multiply-add: sys * (+-1) + (y0x2 | 0)
+        const int y_sign = flip ? -1 : 1;
+        int y_off = flip ? y0x2 : 0;
+        asm volatile("" : "+v"(y_off));                   // (a vector register: the instruction takes one scalar operand)
 #pragma unroll
         for (int s = 0; s < kRowsPerWave; ++s) {
             sx_l[s] = eq_lon_member(sxl[s], x0i, W32);
             sx_m[s] = eq_lon_member(sxm[s], x0i, W32);
-            sy_m[s] = flip ? y0x2 - sys[s] : sys[s];
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(sy_m[s]) : "v"(sys[s]), "s"(y_sign), "v"(y_off));    // |sys| < 2^23 (32 H < 2^21)
             ys_m[s] = flip ? out_h - 1 - ys[s] : ys[s];
         }
         BlkStore bm = bs;
@@ -1366,6 +1412,7 @@ __device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ s
     // tab_lds: the workgroup's LDS copy of the table for the fast path (every lane reads another 32-byte entry: left in global
     // memory the 32 KiB table competes with the source lines for the 32 KiB vector L1 and costs two more gathers per pixel)
     static_assert(kRowsPerWave == 4, "four row slots");
+    const bool stride4 = uniform_here((int)(stride & 3)) == 0;
     bool fast[4];
 #pragma unroll
     for (int s0 = 0; s0 < 4; s0 += 2) {                   // two slots at a time: 8 row reads in flight, 24 tap dwords live
@@ -1375,13 +1422,13 @@ __device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ s
             const int sx = cv_round(mxs[s0 + u] * 32.0f), sy = cv_round(mys[s0 + u] * 32.0f);
             const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
             fast[s0 + u] = ix >= 1 && iy >= 1 && ix <= W - 5 && iy <= H - 3;
-            t[u] = cubic_issue_rgb(src, (uint32_t)stride, W, H, ix, iy, sx & 31, sy & 31);
+            t[u] = cubic_issue_rgb(src, (uint32_t)stride, stride4, W, H, ix, iy, sx & 31, sy & 31);
         }
         __builtin_amdgcn_sched_barrier(0);
-        eq_cubic_blend(t[0], tab_lds, px[s0]);
-        eq_cubic_blend(t[1], tab_lds, px[s0 + 1]);
+        eq_cubic_blend(t[0], tab_lds, stride4, px[s0]);
+        eq_cubic_blend(t[1], tab_lds, stride4, px[s0 + 1]);
     }
-    if (__any(!(fast[0] && fast[1] && fast[2] && fast[3]))) {
+    if (any_lane(!(fast[0] && fast[1] && fast[2] && fast[3]))) {
         // border windows: ONE copy of the straight-line sampler in a rolled loop, so that its 48 byte loads do not set the
         // register budget of the path above.  The loop always works on slot 0 and ROTATES the four slots after every turn (plain
         // register moves, back in place after four turns): picking the slot with `rr == k ? a[k] : ...` made the compiler keep the
@@ -1473,7 +1520,7 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
             __builtin_amdgcn_sched_barrier(0);    // every gather of the wavefront's four rows in flight before the first is consumed
 #pragma unroll
             for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
-            if (__any(any_slow)) {
+            if (any_lane(any_slow)) {
 #pragma unroll
                 for (int rr = 0; rr < kRowsPerWave; ++rr)
                     if (!taps[rr].fast) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
@@ -1608,7 +1655,7 @@ __device__ __forceinline__ void fe_views_tile(const FeBatch& B, const int b, con
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
-        if (__any(any_slow)) {
+        if (any_lane(any_slow)) {
 #pragma unroll
             for (int rr = 0; rr < kRowsPerWave; ++rr)
                 if (!taps[rr].fast) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
