@@ -640,6 +640,11 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t acc) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), acc, false);
 }
+__device__ __forceinline__ uint32_t udot2_u16_from(uint32_t a, uint32_t b, uint32_t start_uniform) {   // see dot2_i16_from
+    uint32_t r;
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(start_uniform));
+    return r;
+}
 __device__ __forceinline__ uint16_t ld_u16(const uint8_t* p) {
     uint16_t v;
     __builtin_memcpy(&v, p, 2);
@@ -687,9 +692,9 @@ __device__ __forceinline__ void eq16_blend_rgb(const Eq16Taps& t, int sx, int sy
     const uint32_t wr0 = ah * (uint32_t)(32 - fy), wr1 = ah * (uint32_t)fy;       // (a0 b | a1 b << 16), a1 b <= 1024
     // v_perm_b32 pairs the two taps of a channel (bytes 0..3 come from the second operand, 4..7 from the first), v_dot2_u32_u16
     // multiplies both by the packed weights: sum <= 65535 * 1024 + 512 < 2^32
-    out[0] = udot2_u16(__builtin_amdgcn_perm(e1, e0, 0x07060100u), wr1, udot2_u16(__builtin_amdgcn_perm(d1, d0, 0x07060100u), wr0, 512u)) >> 10;
-    out[1] = udot2_u16(__builtin_amdgcn_perm(e2, e0, 0x05040302u), wr1, udot2_u16(__builtin_amdgcn_perm(d2, d0, 0x05040302u), wr0, 512u)) >> 10;
-    out[2] = udot2_u16(__builtin_amdgcn_perm(e2, e1, 0x07060100u), wr1, udot2_u16(__builtin_amdgcn_perm(d2, d1, 0x07060100u), wr0, 512u)) >> 10;
+    out[0] = udot2_u16(__builtin_amdgcn_perm(e1, e0, 0x07060100u), wr1, udot2_u16_from(__builtin_amdgcn_perm(d1, d0, 0x07060100u), wr0, 512u)) >> 10;
+    out[1] = udot2_u16(__builtin_amdgcn_perm(e2, e0, 0x05040302u), wr1, udot2_u16_from(__builtin_amdgcn_perm(d2, d0, 0x05040302u), wr0, 512u)) >> 10;
+    out[2] = udot2_u16(__builtin_amdgcn_perm(e2, e1, 0x07060100u), wr1, udot2_u16_from(__builtin_amdgcn_perm(d2, d1, 0x07060100u), wr0, 512u)) >> 10;
 }
 // any channel count, horizontal wrap: element by element (also the repair path of the RGB fast path)
 template <int C>
@@ -718,64 +723,74 @@ struct Eq16CubicTaps {
     int phase;
     bool fix;
 };
-__device__ __forceinline__ Eq16CubicTaps eq16_cubic_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, int W, int H, int sx, int sy) {
+__device__ __forceinline__ Eq16CubicTaps eq16_cubic_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, bool stride4, int W, int H, int sx, int sy) {
     const int ix = sx >> 5, iy = sy >> 5;
     Eq16CubicTaps t;
-    const int x0 = min(max(ix - 1, 0), W - 5);              // 28-byte aligned read of 24 tap bytes stays in-row
+    const int x0 = clamp0_uniform(ix - 1, W - 5);           // 28-byte aligned read of 24 tap bytes stays in-row
     t.fix = (x0 != ix - 1);
     t.phase = (sy & 31) * 32 + (sx & 31);
     const uint32_t col = (uint32_t)x0 * 6u;
-    if ((stride & 3u) == 0 && !any_lane(iy < 1 || iy > H - 3)) {     // common case, as in cubic_issue_rgb: rows off0 + k * stride, one misalignment
-        const uint32_t off0 = __umul24((uint32_t)(iy - 1), stride) + col;
-        const uint32_t o = (uint32_t)(reinterpret_cast<uintptr_t>(src) + off0) & 3u;
-        t.sh = o * 0x55u;
-        const uint8_t* p0 = src + (off0 - o);
+    uint32_t offs[4];                                       // as in cubic_issue_rgb: 32-bit offsets from the scalar base
+    if (stride4) {                                          // one misalignment (0 or 2) for all four rows
+        const uint32_t o = ((uint32_t)reinterpret_cast<uintptr_t>(src) + col) & 3u;
+        t.sh = o;
+        const uint32_t cb = col - o;
+        if (!any_lane(iy < 1 || iy > H - 3)) {              // common case: rows off0 + k * stride
+            offs[0] = __umul24((uint32_t)(iy - 1), stride) + cb;
+#pragma unroll
+            for (int ky = 1; ky < 4; ++ky) offs[ky] = offs[ky - 1] + stride;
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) offs[ky] = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + cb;
+        }
+    } else {
+        t.sh = 0;
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p0 + (size_t)ky * stride, 4));
-#pragma unroll
-            for (int k = 0; k < 7; ++k) t.r[ky][k] = q[k];
+            const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
+            const uint32_t o = ((uint32_t)reinterpret_cast<uintptr_t>(src) + off) & 3u;
+            offs[ky] = off - o;
+            t.sh |= o << (2 * ky);
         }
-        return t;
     }
-    t.sh = 0;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
-        const uint8_t* p = src + off;
-        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (size_t)offs[ky], 4));
 #pragma unroll
         for (int k = 0; k < 7; ++k) t.r[ky][k] = q[k];
-        t.sh |= o << (2 * ky);
     }
     return t;
 }
 // selector of v_perm_b32(a = dword of halfword e1, b = dword of halfword e0): (h_e0 | h_e1 << 16)
 #define GS360_PAIR16(e0, e1) ((uint32_t)(2 * ((e0) & 1)) | ((uint32_t)(2 * ((e0) & 1) + 1) << 8) | ((uint32_t)(4 + 2 * ((e1) & 1)) << 16) | \
                               ((uint32_t)(5 + 2 * ((e1) & 1)) << 24))
-__device__ __forceinline__ void eq16_cubic_blend_rgb(const Eq16CubicTaps& t, const int16_t* wtab, uint32_t (&out)[4]) {
-    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
-    const uint4 wa = wq[0], wb = wq[1];
-    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-    int acc[3] = {0, 0, 0};
+template <bool ONE_SHIFT>
+__device__ __forceinline__ void eq16_cubic_rows(const Eq16CubicTaps& t, const uint32_t (&wpk)[8], int (&acc)[3]) {
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t o = (t.sh >> (2 * ky)) & 3u;
+        const uint32_t o = ONE_SHIFT ? t.sh : ((t.sh >> (2 * ky)) & 3u);
         uint32_t d[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[k] = __builtin_amdgcn_alignbyte(t.r[ky][k + 1], t.r[ky][k], o) ^ 0x80008000u;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {                     // halfword e = 3 kx + c of the row's twelve
-            acc[c] = dot2_i16(__builtin_amdgcn_perm(d[(3 + c) >> 1], d[c >> 1], GS360_PAIR16(c, 3 + c)), wpk[2 * ky], acc[c]);
+            const uint32_t p = __builtin_amdgcn_perm(d[(3 + c) >> 1], d[c >> 1], GS360_PAIR16(c, 3 + c));
+            acc[c] = ky == 0 ? dot2_i16_from(p, wpk[0], 1 << 14) : dot2_i16(p, wpk[2 * ky], acc[c]);
             acc[c] = dot2_i16(__builtin_amdgcn_perm(d[(9 + c) >> 1], d[(6 + c) >> 1], GS360_PAIR16(6 + c, 9 + c)), wpk[2 * ky + 1], acc[c]);
         }
     }
+}
+__device__ __forceinline__ void eq16_cubic_blend_rgb(const Eq16CubicTaps& t, const int16_t* wtab, bool stride4, uint32_t (&out)[4]) {
+    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
+    const uint4 wa = wq[0], wb = wq[1];
+    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    // (sum w S' + 2^30 + 2^14) >> 15 in 32 bits: the chains start at 2^14 -- |sum w S'| + 2^14 <= 32768 * 1.9 * 32768 + 2^14 < 2^31
+    // (the bound asserted on the table in tests/test_u16.py) -- and 2^30 >> 15 = 32768 is added after the shift, exactly
+    int acc[3];
+    if (stride4) eq16_cubic_rows<true>(t, wpk, acc);
+    else eq16_cubic_rows<false>(t, wpk, acc);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int64_t v = ((int64_t)acc[c] + (1ll << 30) + (1 << 14)) >> 15;
-        out[c] = (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
-    }
+    for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((acc[c] >> 15) + 32768, 0), 65535);
 }
 template <int C>
 __device__ __forceinline__ void eq16_cubic_slow(const EqSrc& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
@@ -819,9 +834,9 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
         if constexpr (CUBIC) {
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s) {      // one slot at a time: 8 row reads (28 dwords) in flight
-                const Eq16CubicTaps t = eq16_cubic_issue_rgb(src, (uint32_t)L.src_stride, L.W, L.H, sxs[s], sys[s]);
+                const Eq16CubicTaps t = eq16_cubic_issue_rgb(src, (uint32_t)L.src_stride, L.stride4, L.W, L.H, sxs[s], sys[s]);
                 __builtin_amdgcn_sched_barrier(0);
-                eq16_cubic_blend_rgb(t, wtab, px[s]);
+                eq16_cubic_blend_rgb(t, wtab, L.stride4, px[s]);
                 if (any_lane(t.fix)) {
                     if (t.fix) eq16_cubic_slow<C>(L, wtab, src, sxs[s], sys[s], px[s]);
                 }
