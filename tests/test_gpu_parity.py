@@ -189,6 +189,21 @@ def test_equirect_cubic(ctx, orc, channels, lanemap):
     _assert_same(got, want, f"equirect cubic C={channels}")
 
 
+def test_equirect_cubic_persistent_walk_probe(ctx, orc, monkeypatch):
+    """GS360_EQ_PERSIST (a probe: the C ABI ships the cubic equirect kernels with one tile per workgroup): a capped
+    grid whose workgroups walk the tile order must render the same bytes, 8- and 16-bit."""
+    monkeypatch.setenv("GS360_EQ_PERSIST", "8")
+    src = rand_image(193, 386, c=3, seed=72)
+    specs = [(0, 0, 110, 110, 330, 170), (90, 0, 110, 110, 330, 170), (-75.5, 33, 90, 120, 167, 229), (10, -89, 60, 60, 133, 131)]
+    got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], interp=gs360.INTERP_CUBIC)
+    want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], interp=2)
+    _assert_same(got, want, "equirect cubic, persistent probe")
+    src16 = (np.random.default_rng(73).integers(0, 65536, size=(97, 194, 3))).astype(np.uint16)
+    got16 = ctx.equirect_views(src16, [gs360.View.make(*s) for s in specs[:2]], interp=gs360.INTERP_CUBIC)
+    want16 = orc.equirect_views_u16(src16, [orc.make_view(*s) for s in specs[:2]], interp=2)
+    _assert_same(got16, want16, "equirect cubic u16, persistent probe")
+
+
 # ---- table remap (cv2.remap semantics) ----------------------------------------------------------
 def _rand_maps(h, w, H, W, seed, spread=12.0):
     rng = np.random.default_rng(seed)
@@ -216,6 +231,47 @@ def test_table_remap_random_maps(ctx, orc, channels, interp):
     want = orc.remap_u8(src, mx, my, interp=interp, border_value=bv)
     want = orc.valid_fill(want.copy(), valid, 200)
     _assert_same([got.reshape(h, w, channels)], [want.reshape(h, w, channels)], f"table C={channels} interp={interp}")
+
+
+@pytest.mark.parametrize("persist", ["0", "8", "24"])
+def test_bicubic_persistent_workgroups_walk_every_tile(ctx, orc, persist, monkeypatch):
+    """The bicubic RGB kernels (table + fused fisheye) cap their grid and let each workgroup walk tiles b, b + gridDim.x, ...;
+    GS360_TABLE_PERSIST forces the cap (0 = one tile per workgroup, 8 / 24 = 13-40 tiles per workgroup here)."""
+    monkeypatch.setenv("GS360_TABLE_PERSIST", persist)
+    H, W, h, w = 211, 300, 150, 333                      # 6 x 10 tiles per job
+    src = rand_image(H, W, c=3, seed=71)
+    d_src = ctx.to_device(src)
+    jobs, want, keep = [], [], []
+    for k in range(5):
+        mx, my = _rand_maps(h - 7 * k, w - 11 * k, H, W, seed=72 + k)
+        d = (ctx.to_device(mx), ctx.to_device(my), ctx.alloc(mx.size * 3))
+        keep.append(d)
+        jobs.append((d_src, H, W, d[0], d[1], None, mx.shape[0], mx.shape[1], 0, d[2]))
+        want.append(orc.remap_u8(src, mx, my, interp=2, border_value=(5, 0, 0, 0)))
+    ctx.remap_tables_dev(jobs, 3, interp=2, border_value=(5, 0, 0, 0))
+    for k, (job, w_) in enumerate(zip(jobs, want)):
+        assert np.array_equal(ctx.download(job[9], w_.shape), w_), f"table job {k} persist={persist}"
+    for d in keep:
+        for b in d:
+            ctx.free(b)
+    ctx.free(d_src)
+    # the fused kernel shares the switch
+    kw = dict(TEMPLATE_CALIB)
+    kw.update(width=480, height=480, f=kw["f"] / 8)
+    ocal, gcal = orc.make_calib(**kw), gs360.Calib.make(**kw)
+    fsrc = rand_image(480, 480, seed=77)
+    specs = [(0, 0, HFOV_14MM, HFOV_14MM, 200, 170), (40, 10, HFOV_14MM, HFOV_14MM, 130, 250), (-72.5, 33.25, 75.0, 110.0, 190, 66)]
+    dsrc = ctx.to_device(fsrc)
+    dsts = [ctx.alloc(s[4] * s[5] * 3) for s in specs]
+    ctx.fisheye_views_dev([dsrc] * len(specs), [gcal] * len(specs), 3, [gs360.View.make(*s) for s in specs], 190.0, dsts,
+                          interp=2, mask_outside=True, mask_value=9)
+    ctx.sync(0)
+    for k, s_ in enumerate(specs):
+        mx, my, valid = orc.fisheye_spec_map(ocal, s_[0], s_[1], s_[2], s_[3], s_[4], s_[5], 190.0)
+        want_f = orc.valid_fill(orc.remap_u8(fsrc, mx, my, interp=2, border_value=9.0), valid, 9)
+        _assert_same([ctx.download(dsts[k], (s_[5], s_[4], 3))], [want_f], f"fused view {k} persist={persist}")
+    for b in [dsrc] + dsts:
+        ctx.free(b)
 
 
 def test_table_remap_batched_jobs(ctx, orc):
