@@ -266,11 +266,15 @@ class VideoSession:
                     self._make_room(nbytes)
                 buf = st.ctx.alloc(nbytes)
                 ev = _EVENT_BASE + which
-                with st.upload_lock:              # the engine's still-image uploads share this stream (engine.resident_frame)
-                    st.ctx.upload(buf, host, slot=st.upload_slot, sync=False)
-                    if fdtype == np.uint16:               # PPM samples are big-endian: swapped on the device, behind the copy
-                        st.ctx.bswap16(buf, nbytes // 2, slot=st.upload_slot)
-                    st.ctx.event_record(st.upload_slot, ev)
+                try:
+                    with st.upload_lock:          # the engine's still-image uploads share this stream (engine.resident_frame)
+                        st.ctx.upload(buf, host, slot=st.upload_slot, sync=False)
+                        if fdtype == np.uint16:           # PPM samples are big-endian: swapped on the device, behind the copy
+                            st.ctx.bswap16(buf, nbytes // 2, slot=st.upload_slot)
+                        st.ctx.event_record(st.upload_slot, ev)
+                except Exception:
+                    st.ctx.free(buf)              # not published, not pending: nobody else would release it
+                    raise
                 pending = (st, ev, (st, buf, h, w, fdtype, nbytes))
                 k += 1
             if pending is not None:
