@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""cfg4 (2 x 4000^2 fisheye -> 6 x 1750^2, table mode, one batched launch) for every cv2 interpolation: ms per pair.  Informational."""
+"""cfg4 (2 x 4000^2 fisheye -> 6 x 1750^2, table mode, one batched launch) for every cv2 interpolation, 8- and 16-bit: ms per pair.  Informational."""
 import sys, pathlib, numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent.parent; sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT/'360cam-pgm-3dgs-tools_amd')); sys.path.insert(0, str(ROOT/'tests')); sys.path.insert(0, str(ROOT/'tests'/'tools'))
 import gs360
@@ -19,4 +19,11 @@ jobs = [(dev[tables[s["view_id"]]["lens_key"]], 4000, 4000) + tuple(d_tab[s["vie
 for interp in (0, 1, 2, 4):
     ms = time_steps(ctx, lambda: ctx.remap_tables_dev(jobs, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0), 20)
     print("interp", interp, "ms_per_pair", round(ms, 4))
+# the same pair as 16-bit lens images (CV_16U samplers, gs360_remap_tables_u16)
+dev16 = {k: ctx.to_device((v.astype(np.uint16) * 257) ^ np.uint16(3)) for k, v in imgs.items()}
+d_out16 = {v: ctx.alloc(1750 * 1750 * 6) for v in tables}
+jobs16 = [(dev16[tables[s["view_id"]]["lens_key"]], 4000, 4000) + tuple(d_tab[s["view_id"]]) + (1750, 1750, 0, d_out16[s["view_id"]]) for s in specs]
+for interp in (0, 1, 2, 4):
+    ms = time_steps(ctx, lambda: ctx.remap_tables_dev(jobs16, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0, dtype=np.uint16), 10)
+    print("u16 interp", interp, "ms_per_pair", round(ms, 4))
 ctx.close()
