@@ -1339,6 +1339,11 @@ __device__ __forceinline__ void cv_sample_lanczos4(const uint8_t* __restrict__ s
             return;
         }
     }
+    if (outside) {                                        // the whole window outside the image: the border value, no taps
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] = (uint32_t)cval[c];
+        return;
+    }
     int acc[4] = {0, 0, 0, 0};
 #pragma unroll 2
     for (int ky = 0; ky < 8; ++ky) {
@@ -1558,11 +1563,15 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
         int64_t o = (int64_t)y * L.w + xc;
         float mx = L.map_x[o], my = L.map_y[o];      // 256 B per wavefront row, coalesced
         uint32_t px[4];
+        const bool inval = L.valid && !L.valid[o];
         if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
         else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
-        else if constexpr (INTERP == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
-        else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
-        if (L.valid && !L.valid[o]) {
+        else if constexpr (INTERP == GS360_INTERP_LANCZOS4) {
+            // 64 taps: pixels the valid map rules out are not sampled at all.  (The same test in front of the cheaper samplers
+            // made the compiler index the RGBA bicubic accumulators through scratch memory.)
+            if (!inval) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
+        } else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
+        if (inval) {
 #pragma unroll
             for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.fill;
         }

@@ -98,3 +98,51 @@ def test_run_one_reports_engine_failure_as_rc_and_text(tmp_path):
     rc, text = cut.run_one(argv)
     assert rc == 1 and "gs360" in text
     assert not (tmp_path / "pano_A.png").exists()
+
+
+def _kernel_resources():
+    """{demangled-ish kernel name: {"vgpr", "scratch", "occupancy", "vgpr_spill"}} from the compiler report the build keeps next to
+    the library (csrc/Makefile); None when the library was built some other way."""
+    report = pathlib.Path(gs360.capi.LIB_PATH).with_name("kernel_resources.txt")
+    if not report.exists():
+        return None
+    out, cur = {}, None
+    for line in report.read_text().splitlines():
+        m = re.search(r"remark:\s+(Function Name|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill): (\S+)", line)
+        if not m:
+            continue
+        key, val = m.groups()
+        if key == "Function Name":
+            cur = out.setdefault(val, {})
+        elif cur is not None:
+            cur[{"VGPRs": "vgpr", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+                 "VGPRs Spill": "vgpr_spill"}[key]] = int(val)
+    return out
+
+
+def test_kernels_keep_their_register_budgets():
+    """The hot kernels were tuned against occupancy steps (96 / 128 registers) and must not touch scratch memory; a source change
+    that tips one over still passes every parity test, so the compiler's own report is checked."""
+    res = _kernel_resources()
+    if not res:
+        pytest.skip("no kernel_resources.txt next to the library (built without csrc/Makefile)")
+    assert len(res) > 60
+    for name, r in res.items():
+        # (SGPR spills into vector lanes show up as a few dozen bytes of reserved scratch without any scratch instruction)
+        assert r["scratch"] <= 64 and r["vgpr_spill"] == 0, (name, r)
+    want = {  # mangled-name fragment -> minimum wavefronts per SIMD
+        "eq_views_kernelILi3ELb0ELb0ELi1E": 5,      # u8 RGB bilinear
+        "eq_views_kernelILi3ELb0ELb1ELi1E": 5,      # + keep-mask
+        "eq_views_kernelILi3ELb1ELb0ELi1E": 4,      # u8 RGB bicubic
+        "eq_views_kernelILi3ELb0ELb0ELi2E": 4,      # u16 RGB bilinear
+        "eq_views_kernelILi3ELb1ELb0ELi2E": 3,      # u16 RGB bicubic
+        "table_remap_kernelILi3ELi1E": 5,           # cv2 bilinear
+        "table_remap_kernelILi3ELi2E": 4,           # cv2 bicubic (persistent)
+        "fe_views_kernelILi3ELi2E": 4,
+        "table_remap_u16_kernelILi3ELi1E": 6,
+        "table_remap_u16_kernelILi3ELi2E": 4,
+    }
+    for frag, occ in want.items():
+        hits = [r for n, r in res.items() if frag in n]
+        assert len(hits) == 1, frag
+        assert hits[0]["occupancy"] >= occ, (frag, hits[0])
