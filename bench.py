@@ -13,7 +13,9 @@ last partial round of workgroups weighs twice as much).  `value` = output pixels
 
 The timed job is FIXED: `--steps` x `--frames` frame renders.  With N ranks the frames of that job are dealt round-robin
 (gs360/sharding.py, the partition the engine uses), every rank renders its share from its own HBM-resident frames in
-launches of `--frames`, and `value` = the job's pixels / the slowest rank's time: strong scaling of a resident job
+launches of `--frames`, and `value` = the job's pixels / the slowest rank's time (common start after barrier + synchronize, each
+rank's clock stops when its own work is synchronised, MAX over ranks; the closing barrier follows and the time including it is
+reported as `config.seconds_incl_closing_barrier`): strong scaling of a resident job
 (`"scaling": "strong"`; at N = 1 it is exactly the headline run).  Per-rank times travel in `config.per_rank_seconds`.
 Before the W warm-up steps every rank runs the same launches untimed for `--settle-ms` (150 ms): the device's clocks ramp over
 the first ~100 ms of load, and a 20-step run behind 5 warm-up steps (8 ms in all) otherwise measures the ramp, not the kernel.
@@ -191,11 +193,7 @@ def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
     ctx.sync(-1)
     local = time.perf_counter() - t0
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, _with_barrier = job_seconds(local, time.perf_counter() - t0, args, dist, torch)
     parity = None
     if rank == 0 and not args.no_cpu_baseline and last is not None:
         from oracle import orc
@@ -223,6 +221,18 @@ def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
             "roofline": None, "cpu_baseline": None,
         }
         emit(line)
+
+
+def job_seconds(local, incl_barrier, args, dist, torch):
+    """The job's time = the slowest rank's time from the common start (barrier + synchronize on every rank) to that rank's OWN
+    completion (its last launch synchronised): MAX over ranks of `local`.  The closing barrier + synchronize follow immediately;
+    the time including them (also MAX over ranks) is reported beside it -- on one rank the two are the same number, on N ranks
+    they differ by the latency of one RCCL barrier, which is not part of the job (a 20-step job is 0.8 ms per rank at N = 8)."""
+    if dist is None:
+        return local, incl_barrier
+    t = torch.tensor([local, incl_barrier], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0].item()), float(t[1].item())
 
 
 FULL360 = [(0, 0), (45, 30), (45, -30), (90, 0), (135, 30), (135, -30), (180, 0), (-135, 30), (-135, -30), (-90, 0), (-45, 30), (-45, -30)]
@@ -260,11 +270,9 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
     elapsed = time.perf_counter() - t0
     kernel_ms = ctx.event_elapsed_ms(0, 0, 1) if calls else 0.0
     per_rank = [round(local, 6)]
+    elapsed, with_barrier = job_seconds(local, elapsed, args, dist, torch)
     if dist is not None:
         dev = "cuda" if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         mine_t = torch.tensor([local], dtype=torch.float64, device=dev)
         all_t = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(all_t, mine_t)
@@ -289,6 +297,7 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
                        "resident_GB_rank0": round(len(mine) * W * H * C / 1e9, 1), "upload_s_rank0": round(t_up, 1),
                        "parallelism": f"frames sharded x{world}, no collective", "parity_vs_oracle": parity,
                        "frames_per_s": round(args.job_frames / elapsed, 1), "per_rank_seconds": per_rank,
+                       "seconds_incl_closing_barrier": round(with_barrier, 6),
                        "rank0_kernel_us_per_frame": round(kernel_ms * 1e3 / max(1, len(mine)), 2)},
             "roofline": None, "cpu_baseline": None,
         })
@@ -440,11 +449,9 @@ def main():
     kernel_ms_total = ctx.event_elapsed_ms(0, 0, 1)                  # HIP events on the launch stream
     kernel_ms = kernel_ms_total * nf / max(1, n_mine)                # per full launch of nf frames
     per_rank = [round(local, 6)]
+    elapsed, with_barrier = job_seconds(local, elapsed, args, dist if use_dist else None, torch)
     if use_dist:
         dev = "cuda" if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         mine_t = torch.tensor([local], dtype=torch.float64, device=dev)
         all_t = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(all_t, mine_t)
@@ -495,7 +502,8 @@ def main():
                        "frames_per_step": nf, "views": N_VIEWS, "out_px_per_step": px_per_step,
                        "device": info["name"], "parallelism": f"frames sharded x{world}, no collective",
                        "job": f"{args.steps} steps x {nf} frames = {args.steps * nf} frame renders, dealt round-robin to {world} rank(s)",
-                       "frames_rank0": n_mine, "per_rank_seconds": per_rank, "settle_ms": args.settle_ms,
+                       "frames_rank0": n_mine, "per_rank_seconds": per_rank, "seconds_incl_closing_barrier": round(with_barrier, 6),
+                       "settle_ms": args.settle_ms,
                        "parity_vs_oracle": parity},
             "roofline": None if not baseline_shape else {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
