@@ -57,6 +57,8 @@ struct gs360_ctx {
     int16_t* d_cubic = nullptr;   // 32*32*16 int16 cubic weight table, uploaded at context creation
     int16_t* d_lanczos = nullptr; // 32*32*64 int16 Lanczos4 weight table
     float* d_coef1d = nullptr;    // 448 float32 1-D phase coefficients for the 16-bit (float-weight) samplers
+    uint32_t* d_lz_cen = nullptr; // 1024 x 2 dwords: the patched block of every Lanczos4 2-D phase (TableLaunch::lz_cen)
+    bool lz_rebuild = false;      // the per-pixel weight rebuild reproduces d_lanczos (checked at context creation)
 };
 
 namespace {
@@ -314,6 +316,37 @@ int gs360_ctx_create(int device, int n_slots, gs360_ctx** out) {
             build_lanczos4_table(tab.data());
             e = hipMalloc((void**)&c->d_lanczos, tab.size() * sizeof(int16_t));
             if (e == hipSuccess) e = hipMemcpy(c->d_lanczos, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+            // the Lanczos kernel rebuilds the 2-D weights per pixel from the 1-D table: w = low 16 bits of the float
+            // (cy * (cx * 2^15)) + 1.5 * 2^23 (round-to-nearest-even into the mantissa).  That reproduces every table entry except
+            // the block [4,5] x [4,5] the sum fix-up patches (shipped per phase: `cen`) and the one saturated entry of phase 0
+            // (handled in the kernel) -- verified here for all 1024 phases; on any mismatch the kernel keeps reading the table.
+            std::vector<uint32_t> cen(1024 * 2);
+            float c1[32 * 8];
+            lanczos4_coef1d(c1);
+            bool rebuilt_ok = true;
+            for (int p = 0; p < 1024; ++p) {
+                const int16_t* k = tab.data() + p * 64;
+                cen[2 * p] = (uint32_t)(uint16_t)k[4 * 8 + 4] | ((uint32_t)(uint16_t)k[4 * 8 + 5] << 16);
+                cen[2 * p + 1] = (uint32_t)(uint16_t)k[5 * 8 + 4] | ((uint32_t)(uint16_t)k[5 * 8 + 5] << 16);
+                const float* cy = c1 + (p >> 5) * 8;
+                const float* cx = c1 + (p & 31) * 8;
+                for (int a = 0; a < 8; ++a)
+                    for (int b = 0; b < 8; ++b) {
+                        if ((a == 4 || a == 5) && (b == 4 || b == 5)) continue;
+                        volatile float cx32 = cx[b] * 32768.0f;
+                        volatile float m = cy[a] * cx32;
+                        volatile float t = m + 12582912.0f;
+                        const float tf = t;
+                        uint32_t bits;
+                        std::memcpy(&bits, &tf, 4);
+                        int16_t w = (int16_t)(uint16_t)(bits & 0xffffu);
+                        if (p == 0 && a == 3 && b == 3) w = 32767;          // the kernel's phase-0 rule
+                        if (w != k[a * 8 + b]) rebuilt_ok = false;
+                    }
+            }
+            c->lz_rebuild = rebuilt_ok;
+            if (e == hipSuccess) e = hipMalloc((void**)&c->d_lz_cen, cen.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(c->d_lz_cen, cen.data(), cen.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         }
         if (e == hipSuccess) {
             float coef[448];
@@ -346,6 +379,7 @@ int gs360_ctx_destroy(gs360_ctx* c) {
     if (c->d_cubic) (void)hipFree(c->d_cubic);
     if (c->d_lanczos) (void)hipFree(c->d_lanczos);
     if (c->d_coef1d) (void)hipFree(c->d_coef1d);
+    if (c->d_lz_cen) (void)hipFree(c->d_lz_cen);
     delete c;
     return GS360_OK;
 }
@@ -696,6 +730,10 @@ int fill_table_job(gs360_ctx* c, const gs360_remap_job& J, int C, int interp, co
     L->fill = J.fill_value < 0 ? 0 : (J.fill_value > 255 ? 255 : J.fill_value);
     for (int k = 0; k < 4; ++k) L->cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
     L->cubic_tab = interp == GS360_INTERP_LANCZOS4 ? c->d_lanczos : c->d_cubic;
+    if (interp == GS360_INTERP_LANCZOS4 && c->lz_rebuild && !std::getenv("GS360_LANCZOS_TABLE")) {   // (env: probes / A-B runs)
+        L->lz_c1 = c->d_coef1d + 192;
+        L->lz_cen = c->d_lz_cen;
+    }
     L->pipelined = (J.W >= 8 && src_stride < ((size_t)1 << 24) && (uint64_t)src_stride * (uint64_t)J.H < ((uint64_t)1 << 32)) ? 1 : 0;
     return 0;
 }

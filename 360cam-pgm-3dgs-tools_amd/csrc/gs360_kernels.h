@@ -89,6 +89,12 @@ struct TableLaunch {
     int32_t pipelined;   // W >= 8 and 32-bit tap offsets: split fetch/blend path allowed
     int32_t tiles_x;     // filled by launch_table_batch
     int32_t tile_base;   // first tile of this job inside the batched launch
+    // Lanczos-4, RGB: the 1-D phase table (32 x 8 float32, the floats the 2-D table was built from) and, per 2-D phase, the weight
+    // pairs (taps 4, 5) of window rows 4 and 5 of the 2-D table as two dwords -- the block its sum fix-up patches.  With both
+    // present the kernel rebuilds the other weights per pixel (same float32 product, same rounding) instead of reading 128 B of
+    // the 128 KiB table; null = read the table.  (gs360_ctx_create checks the rebuilt weights against the table, all phases.)
+    const float* lz_c1;
+    const uint32_t* lz_cen;
 };
 
 // One launch for several remaps (e.g. the views of a dual-fisheye pair): no per-view launch tails.

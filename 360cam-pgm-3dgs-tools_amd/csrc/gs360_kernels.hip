@@ -1370,6 +1370,61 @@ __device__ __forceinline__ void cv_sample_lanczos4(const uint8_t* __restrict__ s
     }
 }
 
+// cv2 Lanczos-4 for an RGB window inside the image with the 2-D weights REBUILT per pixel (TableLaunch::lz_c1 / lz_cen; `lds` = the
+// workgroup's copy: 256 floats of 1-D coefficients, then 2048 dwords of patched pairs).  OpenCV's table entry is
+// saturate_cast<short>(cvRound((cy * cx) * 2^15)): the float32 product cy * (cx * 2^15) is the same float (a power of two scales
+// exactly), and adding 1.5 * 2^23 rounds it to nearest-even into the low mantissa bits, whose low 16 are the int16 weight.  Only
+// the block the table's sum fix-up patches (rows 4-5, taps 4-5: shipped per phase) and phase 0's one saturated entry differ.
+// 128 B of a 128 KiB table per pixel through a 32 KiB L1 was what bounded this sampler, not its 64 taps.
+// Returns false (nothing written) when the window is not inside: the caller falls back to cv_sample_lanczos4.
+__device__ __forceinline__ bool cv_lanczos4_rgb_rebuilt(const uint8_t* __restrict__ src, int64_t stride, int W, int H, float mx, float my,
+                                                        const float* lds, uint32_t (&out)[4]) {
+    const int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
+    const int fx = sx & 31, fy = sy & 31;
+    const int x0 = sat_s16(sx >> 5) - 3, y0 = sat_s16(sy >> 5) - 3;
+    if (!(x0 >= 0 && y0 >= 0 && x0 + 10 <= W && y0 + 8 <= H && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0)) return false;
+    const float4* cyq = reinterpret_cast<const float4*>(lds + fy * 8);
+    const float4* cxq = reinterpret_cast<const float4*>(lds + fx * 8);
+    const float4 cya = cyq[0], cyb = cyq[1], cxa = cxq[0], cxb = cxq[1];
+    const float cy[8] = {cya.x, cya.y, cya.z, cya.w, cyb.x, cyb.y, cyb.z, cyb.w};
+    const float cx32[8] = {cxa.x * 32768.0f, cxa.y * 32768.0f, cxa.z * 32768.0f, cxa.w * 32768.0f,
+                           cxb.x * 32768.0f, cxb.y * 32768.0f, cxb.z * 32768.0f, cxb.w * 32768.0f};
+    const int phase = fy * 32 + fx;
+    const uint2 cen = reinterpret_cast<const uint2*>(lds + 256)[phase];
+    int a3[3] = {0, 0, 0};
+#pragma unroll 2
+    for (int ky = 0; ky < 8; ++ky) {
+        uint32_t wpk[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float t0 = cy[ky] * cx32[2 * m] + 12582912.0f;          // (contraction is off: product and sum round separately)
+            const float t1 = cy[ky] * cx32[2 * m + 1] + 12582912.0f;
+            wpk[m] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, t1), __builtin_bit_cast(uint32_t, t0), 0x05040100u);
+        }
+        if (ky == 3) wpk[1] = phase == 0 ? 0x7fff0000u : wpk[1];          // cy = cx = 1: 2^15 saturates to 32767 in the table
+        if (ky == 4) wpk[2] = cen.x;
+        if (ky == 5) wpk[2] = cen.y;
+        const uint8_t* p = src + (int64_t)(y0 + ky) * stride + (int64_t)x0 * 3;
+        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
+        uint32_t r[7], d[6];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) r[t] = q[t];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(r[t + 1], r[t], o);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int p0 = 6 * m + c, p1 = p0 + 3;                    // bytes of taps 2m and 2m+1, channel c
+                a3[c] = dot2_i16(__builtin_amdgcn_perm(d[p1 >> 2], d[p0 >> 2], GS360_PAIR(p0 & 3, 4 + (p1 & 3))), wpk[m], a3[c]);
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((a3[c] + (1 << 14)) >> 15, 0), 255);
+    return true;
+}
+
 // Split bilinear fetch for cv2 semantics (same idea as eq_fetch): the two row reads are issued unconditionally from
 // a clamped, always-valid position so that a wavefront keeps all its gathers in flight; `fast` says the 2x2
 // footprint was fully inside the image and the wide read stayed in-row, otherwise the pixel is redone afterwards by
@@ -1569,7 +1624,13 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
         else if constexpr (INTERP == GS360_INTERP_LANCZOS4) {
             // 64 taps: pixels the valid map rules out are not sampled at all.  (The same test in front of the cheaper samplers
             // made the compiler index the RGBA bicubic accumulators through scratch memory.)
-            if (!inval) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
+            if (!inval) {
+                bool done = false;
+                if constexpr (C == 3) {
+                    if (L.lz_c1) done = cv_lanczos4_rgb_rebuilt(L.src, L.src_stride, L.W, L.H, mx, my, reinterpret_cast<const float*>(s_wtab), px);
+                }
+                if (!done) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
+            }
         } else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
         if (inval) {
 #pragma unroll
@@ -1587,13 +1648,24 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
 template <int C, int INTERP>
 __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBatch B) {
     constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
+    constexpr bool kLanczosRgb = (INTERP == GS360_INTERP_LANCZOS4) && (C == 3);   // 256 floats + 2048 dwords (cv_lanczos4_rgb_rebuilt)
+    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : (kLanczosRgb ? (256 + 2048) * 2 : 8)];
     if constexpr (kFastCubic) {
         if (B.job[0].cubic_tab) {             // (the context's table: the same pointer in every job)
             const uint4* g = reinterpret_cast<const uint4*>(B.job[0].cubic_tab);
             uint4* l = reinterpret_cast<uint4*>(s_wtab);
 #pragma unroll
             for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int b = blockIdx.x; b < B.chunk * 8; b += gridDim.x) table_remap_tile<C, INTERP>(B, b, s_wtab);
+    } else if constexpr (kLanczosRgb) {
+        if (B.job[0].lz_c1) {                 // (wave-uniform; the context's tables, the same in every job)
+            uint32_t* l = reinterpret_cast<uint32_t*>(s_wtab);
+            l[threadIdx.x] = reinterpret_cast<const uint32_t*>(B.job[0].lz_c1)[threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < 2048 / (64 * kWaves); ++i) l[256 + i * 64 * kWaves + threadIdx.x] = B.job[0].lz_cen[i * 64 * kWaves + threadIdx.x];
             __syncthreads();
         }
 #pragma unroll 1
@@ -1844,7 +1916,8 @@ hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s) {
     if (base == 0) return hipSuccess;
     dim3 grid((unsigned)(B.chunk * 8)), block(64 * kWaves);
     // persistent workgroups for the kernel with a per-workgroup LDS table (see table_remap_kernel)
-    if (C == 3 && B.job[0].interp == GS360_INTERP_CUBIC && B.persist_blocks > 0 && (unsigned)B.persist_blocks < grid.x)
+    if (C == 3 && (B.job[0].interp == GS360_INTERP_CUBIC || B.job[0].interp == GS360_INTERP_LANCZOS4) && B.persist_blocks > 0 &&
+        (unsigned)B.persist_blocks < grid.x)
         grid.x = (unsigned)(B.persist_blocks + 7) & ~7u;
     switch (C) {
         case 1: launch_table_c<1>(B, grid, block, s); break;

@@ -138,6 +138,7 @@ def test_kernels_keep_their_register_budgets():
         "eq_views_kernelILi3ELb1ELb0ELi2E": 3,      # u16 RGB bicubic
         "table_remap_kernelILi3ELi1E": 5,           # cv2 bilinear
         "table_remap_kernelILi3ELi2E": 4,           # cv2 bicubic (persistent)
+        "table_remap_kernelILi3ELi4E": 4,           # cv2 Lanczos-4 (weights rebuilt per pixel)
         "fe_views_kernelILi3ELi2E": 4,
         "table_remap_u16_kernelILi3ELi1E": 6,
         "table_remap_u16_kernelILi3ELi2E": 4,

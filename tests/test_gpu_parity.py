@@ -327,6 +327,32 @@ def test_table_remap_identity_and_shifts(ctx):
     assert np.array_equal(half[:, -1], (src[:, -1].astype(int) + 1) >> 1)             # right tap = border 0
 
 
+@pytest.mark.parametrize("interp", [2, 4])
+def test_table_remap_every_phase_and_integer_grid(ctx, orc, interp, monkeypatch):
+    """bicubic / Lanczos-4 RGB on windows inside the image: every one of the 32 x 32 sub-pixel phases (the Lanczos kernel rebuilds
+    its 2-D weights per pixel from the 1-D table; phase 0 and the patched block of each phase are its special cases), the integer
+    grid (phase 0 everywhere: identity), and the same through the table-reading path (GS360_LANCZOS_TABLE)."""
+    H, W = 96, 131
+    src = rand_image(H, W, c=3, seed=91)
+    fy, fx = np.meshgrid(np.arange(32, dtype=np.float32), np.arange(32, dtype=np.float32), indexing="ij")
+    reps = 5                                              # 160 x 160 pixels: five anchors per phase
+    ay = np.tile(np.repeat(np.arange(reps), 32), (reps * 32, 1)).T.astype(np.float32)
+    ax = np.tile(np.repeat(np.arange(reps), 32), (reps * 32, 1)).astype(np.float32)
+    mx = (10.0 + 17.0 * ax + np.tile(fx, (reps, reps)) / 32.0).astype(np.float32)
+    my = (9.0 + 13.0 * ay + np.tile(fy, (reps, reps)) / 32.0).astype(np.float32)
+    want = orc.remap_u8(src, mx, my, interp=interp, border_value=(3, 0, 0, 0))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    ident = orc.remap_u8(src, xx, yy, interp=interp, border_value=(3, 0, 0, 0))
+    inner = (slice(4, H - 5), slice(4, W - 7))
+    assert np.array_equal(ident[inner], src[inner])       # OpenCV's table keeps integer positions exact
+    for table_path in ("", "1"):
+        if table_path:
+            monkeypatch.setenv("GS360_LANCZOS_TABLE", table_path)
+        got = ctx.remap(src, mx, my, interpolation=interp, border_value=(3, 0, 0, 0))
+        _assert_same([got], [want], f"all phases interp={interp} table_path={table_path!r}")
+        assert np.array_equal(ctx.remap(src, xx, yy, interpolation=interp, border_value=(3, 0, 0, 0)), ident)
+
+
 def test_table_remap_fisheye_maps_from_oracle(ctx, orc):
     """cfg4-shaped: template calibration, oracle-built DF maps, 3 SFM10 views at reduced size"""
     cal = orc.make_calib(**{**TEMPLATE_CALIB, "width": 960, "height": 960, "f": TEMPLATE_CALIB["f"] / 4})
