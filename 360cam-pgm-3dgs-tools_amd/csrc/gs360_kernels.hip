@@ -1252,10 +1252,27 @@ __device__ __forceinline__ void cv_sample_nearest(const uint8_t* __restrict__ sr
     bool inside = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
     int xa = min(max(ix, 0), W - 1), ya = min(max(iy, 0), H - 1);
     const uint8_t* s = src + (int64_t)ya * stride + (int64_t)xa * C;
+    if constexpr (C == 3) {
+        // one gather instead of three: the pixel's 3 bytes lie in the 8 bytes that start at its dword -- inside the row for every
+        // column but the last two, which keep the byte reads.  (Single exit: an early return here put the callers' pixel arrays
+        // into scratch memory, 81 us -> 2 ms per cfg4 pair; tests/test_capi_load.py now watches the compiler's report.)
+        uint32_t v;
+        if (xa <= W - 3) {
+            const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(s) & 3u;
+            const uint2 q = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(s - o, 4));
+            v = __builtin_amdgcn_alignbyte(q.y, q.x, o);
+        } else {
+            v = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+        }
+        out[0] = inside ? (v & 0xffu) : (uint32_t)cval[0];
+        out[1] = inside ? ((v >> 8) & 0xffu) : (uint32_t)cval[1];
+        out[2] = inside ? ((v >> 16) & 0xffu) : (uint32_t)cval[2];
+    } else {
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        uint32_t v = s[c];
-        out[c] = inside ? v : (uint32_t)cval[c];
+        for (int c = 0; c < C; ++c) {
+            uint32_t v = s[c];
+            out[c] = inside ? v : (uint32_t)cval[c];
+        }
     }
 }
 
