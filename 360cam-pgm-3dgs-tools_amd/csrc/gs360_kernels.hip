@@ -29,10 +29,6 @@
 #include "gs360_eqspec.h"
 #include "gs360_rowstore.h"
 
-#ifndef GS360_EXPERIMENT
-#define GS360_EXPERIMENT 0   // 1 / 2: scratch probes used while profiling (never built into lib/)
-#endif
-
 namespace gs360 {
 
 // ------------------------------------------------------------------------------------------------
@@ -227,12 +223,7 @@ __device__ __forceinline__ void store_patch_rgb(uint8_t* dst, int64_t dstride, u
             const int idx = live ? rr * 64 + a : 0;
             const uint32_t pa = lds[idx], pb = lds[idx + 1];
             const uint32_t dw = (pa >> sh) | (pb << (24 - sh));
-#if GS360_EXPERIMENT == 1
-            if (live && dw == 0x12345678u)
-#else
-            if (live)
-#endif
-            {
+            if (live) {
                 uint32_t* q = reinterpret_cast<uint32_t*>(dst + (int64_t)(y0 + ystep * rr) * dstride + (int64_t)col0 * 3) + k;
                 // 4-slot patches leave as whole 192-byte row segments: streamed past the caches.  The 96-byte halves of a
                 // level view's row segment come from two wavefronts: regular stores let L2 merge them into full lines
@@ -288,13 +279,8 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
     // one full-rate v_mad_u32_u24 per row instead of 64-bit multiply/add chains, and the load can use the
     // SGPR-base + VGPR-offset addressing form.
     const uint32_t col = (uint32_t)ixl * C;
-#if GS360_EXPERIMENT == 2   // VALU-only probe: every lane reads the same two lines
-    const uint32_t o0 = (__umul24((uint32_t)y0, (uint32_t)stride) + col) & 63u;
-    const uint32_t o1 = 64u + ((__umul24((uint32_t)y1, (uint32_t)stride) + col) & 63u);
-#else
     const uint32_t o0 = __umul24((uint32_t)y0, (uint32_t)stride) + col;
     const uint32_t o1 = __umul24((uint32_t)y1, (uint32_t)stride) + col;
-#endif
     const uint8_t* r0 = src + o0;
     const uint8_t* r1 = src + o1;
     EqTaps<C> t;
@@ -554,11 +540,7 @@ __device__ __forceinline__ void eq_store(uint8_t* dst, int64_t dstride, const ui
     }
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s)
-#if GS360_EXPERIMENT == 1   // load-path probe: only one lane-row in a million is written
-        if (row_ok[s] && px[s][0] == 0x12345u) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, rp, reversed, skip_first);
-#else
         if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, rp, reversed, skip_first);
-#endif
 }
 
 template <int C, bool CUBIC, int MODE, bool MASKED>
