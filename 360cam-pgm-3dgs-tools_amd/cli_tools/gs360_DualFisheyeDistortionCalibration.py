@@ -62,7 +62,7 @@ _OPTIONS = (
     (("--sensor-id-y",), dict(default=None, help="force this sensor id for the Y lens")),
     (("--interpolation",), dict(choices=tuple(INTERPOLATION_MAP.keys()), default="cubic",
                                 help="resampling kernel (GPU cost per pair of 6 x 1750^2 views on 8-bit RGB: nearest / linear ~0.08 ms, "
-                                     "cubic ~0.2 ms, lanczos4 ~0.75 ms)")),
+                                     "cubic ~0.11 ms, lanczos4 ~0.36 ms)")),
     (("--undistort-zoom",), dict(default="auto", help="zoom of the undistorted fisheye output: a positive number or 'auto'")),
     (("--mask-outside-model",), dict(dest="mask_outside_model", action="store_true", help="paint pixels outside the lens model with --mask-value")),
     (("--no-mask-outside-model",), dict(dest="mask_outside_model", action="store_false", help="leave pixels outside the lens model as sampled")),
