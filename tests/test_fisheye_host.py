@@ -8,6 +8,7 @@ import pytest
 
 from conftest import GOLDEN
 from gs360 import fisheye as fe
+from util import TEMPLATE_CALIB
 
 G = np.load(GOLDEN / "df_goldens.npz")
 M = json.loads((GOLDEN / "df_goldens.json").read_text())
@@ -119,3 +120,20 @@ def test_undistort_tables_and_auto_zoom():
     assert np.array_equal(t.map_x[::4, ::4], G["undist_full_auto_mx"]) and np.array_equal(t.valid_mask[::4, ::4], G["undist_full_auto_valid"])
     with pytest.raises(ValueError):
         fe.undistort_tables(fe.SensorCalibration("s", "frame", 8, 8, 10.0), 1.0, 190.0)
+
+
+def test_lens_table_builds_are_the_same_on_the_thread_pool(monkeypatch):
+    """choose_lens_tables runs its 2 x len(specs) independent builds on a thread pool: same tables, same lens choice, same order
+    as one after the other (GS360_TABLE_BUILD_THREADS=1, the reference's loop DF:1857-1907)."""
+    c = fe.SensorCalibration("0", "equisolid_fisheye", 480, 480, TEMPLATE_CALIB["f"] / 8, TEMPLATE_CALIB["cx"], TEMPLATE_CALIB["cy"],
+                             TEMPLATE_CALIB["k1"], TEMPLATE_CALIB["k2"], TEMPLATE_CALIB["k3"])
+    specs = fe.sfm10_specs(97, 14.0, "36 36", 40.0, 40.0)
+    monkeypatch.setattr(fe, "_TABLE_BUILD_THREADS", 6)
+    a = fe.choose_lens_tables({"0": c}, "0", "0", specs, 0.0, 180.0, 190.0)
+    monkeypatch.setattr(fe, "_TABLE_BUILD_THREADS", 1)
+    b = fe.choose_lens_tables({"0": c}, "0", "0", specs, 0.0, 180.0, 190.0)
+    assert list(a) == list(b) == [s["view_id"] for s in specs]
+    for k in a:
+        assert a[k]["lens_key"] == b[k]["lens_key"] and a[k]["yaw_rel_deg"] == b[k]["yaw_rel_deg"]
+        for f in ("map_x", "map_y", "valid"):
+            assert a[k][f].tobytes() == b[k][f].tobytes(), (k, f)
