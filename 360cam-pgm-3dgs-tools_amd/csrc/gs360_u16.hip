@@ -21,6 +21,8 @@ namespace gs360 {
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int cv_round_u16(float v) {
     if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (int)0x80000000;
     return (int)__builtin_rintf(v);
@@ -122,6 +124,79 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[s][c] = sat_u16(v[0][c] * w00 + v[0][3 + c] * w01 + v[1][c] * w10 + v[1][3 + c] * w11);
                 done[s] = true;
+            }
+        }
+    }
+    if constexpr (C == 3 && interp == GS360_INTERP_CUBIC) {
+        // bicubic, RGB, windows inside the image: software pipeline over the four row slots -- the four row reads (7 aligned dwords
+        // each) of slot s + 1 are issued before slot s is blended, so a wavefront always has a slot's reads in flight while it
+        // computes (one slot at a time the vector ALU was 53 % busy).  Reads go to a clamped, always-valid window; `fast` says
+        // whether the result is the pixel's (otherwise the straight-line sampler below redoes it).  Float32 sums in OpenCV's order.
+        if (W >= 8 && H >= 4 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)T.src_stride) & 3) == 0) {
+            uint32_t raw[2][4][7];
+            uint32_t sh[kRowsPerWave];
+            int fxs[kRowsPerWave], fys[kRowsPerWave];
+            bool fast[kRowsPerWave];
+            auto issue = [&](int sl, uint32_t (&buf)[4][7]) {
+                const int sx = cv_round_u16(mxs[sl] * 32.0f), sy = cv_round_u16(mys[sl] * 32.0f);
+                const int x0 = sat_s16_u16(sx >> 5) - 1, y0 = sat_s16_u16(sy >> 5) - 1;
+                fxs[sl] = sx & 31;
+                fys[sl] = sy & 31;
+                fast[sl] = !inval[sl] && x0 >= 0 && y0 >= 0 && x0 + 6 <= W && y0 + 4 <= H && ybase + sl < th;
+                const int xa = min(max(x0, 0), W - 6), ya = min(max(y0, 0), H - 4);
+                const uint8_t* p0 = reinterpret_cast<const uint8_t*>(src) + (size_t)ya * (size_t)T.src_stride + (size_t)xa * 6;
+                const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p0) & 3u;      // the stride is a multiple of 4: one shift
+                sh[sl] = o;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p0 - o + (size_t)ky * (size_t)T.src_stride, 4));
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) buf[ky][t] = q[t];
+                }
+            };
+            // (channels 0 and 1 ride in one packed-float32 register pair: v_pk_mul_f32 / v_pk_add_f32 are two IEEE operations per
+            // instruction -- the same roundings, in the same order, as the scalar form)
+            auto finish = [&](int sl, const uint32_t (&buf)[4][7]) {
+                const float* cy = tab + fys[sl] * 4;
+                const float* cx = tab + fxs[sl] * 4;
+                f32x2 sum01 = {0.f, 0.f};
+                float sum2 = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    uint32_t d[6];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(buf[ky][t + 1], buf[ky][t], sh[sl]);
+                    const float cyk = cy[ky];
+                    f32x2 rs01 = {0.f, 0.f};
+                    float rs2 = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int e = kx * 3;                               // halfwords e, e + 1, e + 2 = the tap's three channels
+                        auto hw = [&](int h) { return (float)((h & 1) ? (d[h >> 1] >> 16) : (d[h >> 1] & 0xffffu)); };
+                        const float w = cyk * cx[kx];
+                        const f32x2 v01 = {hw(e), hw(e + 1)};
+                        const f32x2 w01 = {w, w};
+                        const f32x2 t01 = v01 * w01;
+                        const float t2 = hw(e + 2) * w;
+                        rs01 = kx == 0 ? t01 : rs01 + t01;
+                        rs2 = kx == 0 ? t2 : rs2 + t2;
+                    }
+                    sum01 = ky == 0 ? rs01 : sum01 + rs01;
+                    sum2 = ky == 0 ? rs2 : sum2 + rs2;
+                }
+                if (fast[sl]) {
+                    px[sl][0] = sat_u16(sum01.x);
+                    px[sl][1] = sat_u16(sum01.y);
+                    px[sl][2] = sat_u16(sum2);
+                    done[sl] = true;
+                }
+            };
+            issue(0, raw[0]);
+#pragma unroll
+            for (int sl = 0; sl < kRowsPerWave; ++sl) {
+                if (sl + 1 < kRowsPerWave) issue(sl + 1, raw[(sl + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(sl, raw[sl & 1]);
             }
         }
     }
