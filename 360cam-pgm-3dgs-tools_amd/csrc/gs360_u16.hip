@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
     const int x0t = tile_x * kTileW;
     const int n_px = min(kTileW, T.w - x0t);
     const int x = min(x0t + lane, T.w - 1);   // lanes past the edge redo the last column: every lane stays active for the packed stores
-    const uint16_t cval[4] = {c0, c1, c2, c3};
+    const uint32_t cval[4] = {c0, c1, c2, c3};   // (as dwords: a uint16_t[4] local ended up in scratch memory in the nearest instantiation)
     const uint16_t* __restrict__ src = reinterpret_cast<const uint16_t*>(T.src);
     const size_t ss = (size_t)T.src_stride >> 1;
     const int W = T.W, H = T.H;
