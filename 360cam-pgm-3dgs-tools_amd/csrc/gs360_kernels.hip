@@ -862,7 +862,8 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
 // Occupancy is pinned (GS360_EQ_WAVES wavefronts per SIMD): with more resident wavefronts their gathers evict each
 // other's lines from the 32 KiB vector L1, with fewer the miss queue runs dry.  Measured on cfg2, us per frame --
 // row-per-slot lane map: 3 / 4 / 6 wavefronts: 27.4 / 23.1 / 24.3; blocked lane map: 3 / 4 / 5 / 6: 22.1 / 20.8 / 20.3 /
-// 23.3 (6 spills).  5 is also the better choice for the arithmetic-bound large-view configs (cfg1/3/5).  The cubic
+// 23.3 (6 spills).  5 is also the better choice for the arithmetic-bound large-view configs (cfg1/3/5; re-measured on the
+// round-3 kernel, 88 registers: 6 wavefronts = 80 registers + 6 spills run cfg1/2/3/5 6-10 % slower).  The cubic
 // variant needs 128 VGPRs and stays at 4.
 // LDS of a workgroup besides the cubic weight table: the blocked store's transpose slices (256 dwords per wavefront; its read-back
 // may touch the dword after the slice, which is the next slice or the first parked dword -- never used), then the parked ring
