@@ -460,11 +460,12 @@ def main() -> None:
                     mask_count += len(specs)
             processed += 2
     else:
-        from gs360 import capi, imageio
+        from gs360 import capi, hostmem, imageio
         from gs360.dualfisheye import PairRenderer
         n_dev = capi.device_count()
         if n_dev <= 0:
             _die("[ERR] no MI355X visible: the gs360 engine has no CPU fallback", 2)
+        hostmem.tune_malloc()                     # the worker threads' large short-lived image buffers (gs360/hostmem.py)
         contexts = [capi.Context(device=d, n_slots=1) for d in range(n_dev)]
         stage = color.ColorStage(input_lut, lut_space) if input_lut is not None else None
         renderers = {}

@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-from . import capi, imageio, video
+from . import capi, hostmem, imageio, video
 from .jobspec import JobSpec
 
 _FRAME_CACHE_BYTES = int(os.environ.get("GS360_FRAME_CACHE_MB", "4096")) << 20
@@ -90,6 +90,7 @@ class Engine:
         if n <= 0:
             raise capi.Gs360Error(-3, "no MI355X visible: the gs360 engine has no CPU fallback "
                                       "(use --engine ffmpeg to run the reference's ffmpeg path)")
+        hostmem.tune_malloc()                     # the codec threads' large short-lived buffers (see hostmem.py)
         want = os.environ.get("GS360_DEVICES")
         if devices is None and want:
             devices = [int(t) for t in want.split(",") if t.strip()]

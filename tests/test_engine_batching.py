@@ -175,3 +175,15 @@ def test_decode_ahead_runs_at_most_its_permits_ahead_and_hands_them_back(monkeyp
     eng._prefetch_stop.set()
     for t in list(eng._prefetch_threads):
         t.join(2.0)
+
+
+def test_malloc_tuning_is_idempotent_and_switchable(monkeypatch):
+    """gs360/hostmem.py: mallopt() through ctypes on glibc; off with GS360_MALLOC_TUNE=0"""
+    from gs360 import hostmem
+    monkeypatch.setattr(hostmem, "_done", False)
+    monkeypatch.setenv("GS360_MALLOC_TUNE", "0")
+    assert hostmem.tune_malloc() is False
+    monkeypatch.delenv("GS360_MALLOC_TUNE")
+    first = hostmem.tune_malloc()
+    assert first in (True, False)                 # False only off glibc
+    assert hostmem.tune_malloc() is first
