@@ -122,29 +122,4 @@ __device__ __forceinline__ int eq_quant_lon(float r0, int K, const EqLaunch& L, 
     return eq_lon_wrap(eq_lon_base(r0, K, L, V.x0f32), V.x0i32, 32 * L.W);
 }
 
-// EQ-SPEC v1 source coordinate of ONE output pixel (i, j) in 1/32-px units (sx wrapped to [0, 32W), sy unclamped):
-// the per-pixel statement of what eq_views_kernel evaluates with its mirror-symmetry sharing.
-__device__ __forceinline__ void eq_coord_px(const EqLaunch& L, const EqView& V, int i, int j, int& sx, int& sy) {
-    float x = (float)(2 * i + 1 - V.out_w) * V.sxu;
-    float yv = (float)(2 * j + 1 - V.out_h) * V.syv;
-    float bz, cy;
-    if (V.fish) {
-        const float q = __builtin_fmaf(x, x, yv * yv);
-        const float S = eq_poly8(kEqFishS, q), Cz = eq_poly8(kEqFishC, q);
-        x = x * S;
-        yv = yv * S;
-        bz = __builtin_fmaf(V.sp, yv, V.cp * Cz);
-        cy = __builtin_fmaf(-V.cp, yv, V.sp * Cz);
-    } else {
-        bz = __builtin_fmaf(V.sp, yv, V.cp);
-        cy = __builtin_fmaf(-V.cp, yv, V.sp);
-    }
-    const float h = eq_sqrt(__builtin_fmaf(x, x, bz * bz));
-    int Kl, Kt;
-    const float rl = eq_atan2_red(x, bz, Kl);
-    const float rt = eq_atan2_red<true>(cy, h, Kt);
-    sx = eq_quant_lon(rl, Kl, L, V);
-    sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
-}
-
 }  // namespace gs360

@@ -363,7 +363,7 @@ __device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, 
 
 // ---- cubic variant of the equirect sampler (4x4 Keys taps, OpenCV fixed-point table) -------------------------------
 // Two steps, like the bilinear fetch: cubic_issue_rgb puts the 4 row reads of one RGB pixel in flight (12 contiguous bytes
-// each, fetched as a dword-aligned 16-byte read) without control flow and without touching a result; cubic_finish_rgb shifts
+// each, fetched as a dword-aligned 16-byte read) without control flow and without touching a result; eq_cubic_blend shifts
 // the rows into place, reads the 32-byte weight entry (LDS: short latency, so it need not occupy 8 registers while the
 // gathers fly) and blends.  Lanes whose window touches the seam or the last columns are flagged and redone by eq_cubic_slow.
 struct EqCubicTaps {
