@@ -81,7 +81,7 @@ def test_late_jobs_form_their_own_batch_and_serial_callers_do_not_wait_forever(m
     monkeypatch.setattr(engine, "_LINGER_S", 0.05)
     launches, frame_calls = [], []
     eng, st = make_engine(monkeypatch, launches), FakeState()
-    out, errs = run_jobs(eng, st, [0, 90, 180], expected=16, frame_calls=frame_calls, stagger=0.15)   # arrive after the linger
+    out, errs = run_jobs(eng, st, [0, 90, 180], expected=16, frame_calls=frame_calls, stagger=0.5)    # arrive well after the linger
     assert not errs and len(out) == 3
     assert [len(b) for b in launches] == [1, 1, 1]
     launches.clear()
