@@ -344,12 +344,15 @@ def main():
                 print(line)
 
     # `-j auto` is cores // 2 ffmpeg processes in the reference (PC:563-567).  The HIP engine's view jobs are threads of this process
-    # that spend their time in the image codecs: past ~32 of them the run gets slower, not faster (MI355X host, 48 panoramas: 46
-    # frames/s at 32 workers, 35 at 128), so `auto` is capped for this engine; an explicit -j is taken as given.
+    # that spend their time in the image codecs, and os.cpu_count() ignores a container's CPU quota (the MI355X boxes of the build
+    # pool show 256 hardware threads and allow 16 CPUs: 48 panoramas run at 46 frames/s with 32 workers, 35 with 128).  `auto` is
+    # therefore capped at twice the CPUs the process may actually use; an explicit -j is taken as given.
     workers = jobs
     if _selected_engine() != "ffmpeg":
         if str(args.jobs).lower() == "auto":
-            workers = min(jobs, max(1, int(os.environ.get("GS360_AUTO_WORKERS", "32"))))
+            from gs360 import hostmem
+            cap = int(os.environ.get("GS360_AUTO_WORKERS", "0")) or max(8, 2 * hostmem.effective_cpus())
+            workers = min(jobs, max(1, cap))
         _announce_jobs(jobs_list, workers)
     ok = fail = done = 0
     last_pct = -1

@@ -40,9 +40,15 @@ SCRIPT_DIR = _HERE
 DEFAULT_CAMERA_XML = SCRIPT_DIR / "templates" / "Osmo360-Fisheye-Distortion.xml"
 DEFAULT_DLOGM_LUT = SCRIPT_DIR / "templates" / "DJI Osmo 360 D-Log M to Rec.709 V1.cube"
 # The reference defaults to one worker per CPU core (DF:2680-2701: its workers sit in cv2, outside the interpreter lock).  Here a worker
-# is a thread that decodes two images, queues ten GPU views and encodes them: past ~16 of them one Python process gets SLOWER (MI355X
-# host, 48 pairs: 22 pairs/s at 12-16 workers, 17 at 32, 14.7 at 256), so the default is capped; --workers N is taken as given.
-DEFAULT_WORKERS = max(1, min(16, os.cpu_count() or 1))
+# is a thread that decodes two images, queues ten GPU views and encodes them, and os.cpu_count() ignores a container's CPU quota (the
+# MI355X boxes of the build pool: 256 hardware threads, 16 CPUs allowed; 48 pairs run at 22 pairs/s with 12-16 workers, 17 with 32,
+# 14.7 with 256).  Default: the CPUs the process may actually use, at most 32; --workers N is taken as given.
+def _default_workers() -> int:
+    from gs360 import hostmem
+    return max(1, min(32, hostmem.effective_cpus()))
+
+
+DEFAULT_WORKERS = _default_workers()
 DEFAULT_PERSPECTIVE_METASHAPE_XML_NAME = "perspective_cams.xml"
 INTERPOLATION_MAP = dict(INTERPOLATIONS)
 
@@ -71,7 +77,7 @@ _OPTIONS = (
     (("--no-mask-outside-model",), dict(dest="mask_outside_model", action="store_false", help="leave pixels outside the lens model as sampled")),
     (("--mask-value",), dict(type=int, default=0, help="grey level 0-255 used for masked pixels and the resampling border")),
     (("--limit",), dict(type=int, default=0, help=H)),
-    (("--workers",), dict(type=int, default=DEFAULT_WORKERS, help="pairs processed concurrently (default: min(16, CPU cores) = {})".format(DEFAULT_WORKERS))),
+    (("--workers",), dict(type=int, default=DEFAULT_WORKERS, help="pairs processed concurrently (default: usable CPUs, at most 32 = {})".format(DEFAULT_WORKERS))),
     (("--memory-throttle-percent",), dict(type=float, default=80.0, help="accepted for compatibility (host-memory throttle threshold)")),
     (("--dry-run",), dict(action="store_true", help="list what would be written and stop")),
     (("--report-json",), dict(default=None, help=H)),

@@ -22,10 +22,12 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import hostmem
+
 SUPPORTED_MODELS = {"equisolid_fisheye"}
 F32 = np.float32
 # threads for the independent remap-table builds of choose_lens_tables (each holds a few 1750^2 float32 temporaries)
-_TABLE_BUILD_THREADS = int(os.environ.get("GS360_TABLE_BUILD_THREADS", str(min(16, os.cpu_count() or 1))))
+_TABLE_BUILD_THREADS = int(os.environ.get("GS360_TABLE_BUILD_THREADS", "0")) or min(16, hostmem.effective_cpus())
 
 
 @dataclass

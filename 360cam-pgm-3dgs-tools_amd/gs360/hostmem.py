@@ -33,3 +33,33 @@ def tune_malloc() -> bool:
     ok = (mallopt(_M_TOP_PAD, 256 << 20) == 1) and ok
     _done = ok
     return ok
+
+
+def effective_cpus() -> int:
+    """CPUs this process can actually use: the scheduler affinity mask, cut down by a cgroup CPU quota when there is one (cgroup v2
+    `cpu.max`, v1 `cpu.cfs_quota_us` / `cpu.cfs_period_us`).  os.cpu_count() alone reports the host's 256 hardware threads inside a
+    container that is allowed 16 CPUs' worth of time -- the MI355X boxes of the build pool are such containers -- and worker pools
+    sized by it thrash: there the codecs saturate at ~16 threads whatever `-j` says."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            quota = None
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)

@@ -187,3 +187,21 @@ def test_malloc_tuning_is_idempotent_and_switchable(monkeypatch):
     first = hostmem.tune_malloc()
     assert first in (True, False)                 # False only off glibc
     assert hostmem.tune_malloc() is first
+
+
+def test_effective_cpus_respects_affinity_and_quota(tmp_path, monkeypatch):
+    import builtins
+    import os
+    from gs360 import hostmem
+    n = hostmem.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):                         # a cgroup-v2 quota of 2.5 CPUs (rounded to 3)
+        if str(path) == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text("250000 100000\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert hostmem.effective_cpus() == min(len(os.sched_getaffinity(0)), 3)
