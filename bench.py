@@ -123,7 +123,9 @@ def cpu_baseline(np, frame, budget_s=10.0):
     for _ in range(2):
         orc.equirect_views_u8(frame, views, threads=1)
     dt1 = (time.perf_counter() - t1) / 2
+    from gs360 import hostmem                     # (CPUs this process may use: affinity mask cut by a cgroup quota, if any)
     return {"value": round(mpix / dt, 2), "unit": "MPix/s", "cores": best, "kind": "port",
+            "usable_cpus": hostmem.effective_cpus(),
             "sample": f"{n} passes of 1 frame x {N_VIEWS} views (same 8K->6x800^2 workload) in {dt:.1f} s; "
                       f"OpenMP over (view,row), {best} of {ncpu} host threads (best of {cand})",
             "single_thread": {"value": round(N_VIEWS * SIZE * SIZE / 1e6 / dt1, 2), "unit": "MPix/s", "cores": 1,
