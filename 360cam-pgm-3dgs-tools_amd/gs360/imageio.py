@@ -9,6 +9,7 @@ for 16-bit sources, which the reference keeps at native depth (DF:735 cv2.imread
 gs360_png_unfilter helper) and written with filter type 0; TIFF is read / written as baseline TIFF (uncompressed,
 LZW or Deflate, chunky, strips, predictor 1 or 2) -- anything else 16-bit raises ImageIOError rather than losing depth.
 """
+import os
 import pathlib
 import struct
 import zlib
@@ -314,6 +315,12 @@ def read_image(path) -> np.ndarray:
     raise ImageIOError(f"cannot read {path}: Pillow is not installed and the built-in codec is PNG only")
 
 
+# Optimised Huffman tables = the reference's `-huffman optimal` (PC:331-338): a second pass over every image.  GS360_JPEG_OPTIMIZE=0
+# skips it (slightly larger files); measured on the MI355X host it buys ~6 % end to end on the PerspCut CLI (46-47 -> 48-51 frames/s)
+# and nothing on the dual-fisheye CLI, so the reference's setting stays the default.
+_JPEG_OPTIMIZE = os.environ.get("GS360_JPEG_OPTIMIZE", "1") not in ("0", "off", "no")
+
+
 def write_image(path, arr: np.ndarray, jpeg_q: int = None) -> None:
     """Encode by extension.  jpeg_q is ffmpeg's -q:v (1 = best, 2 ~ 95 %), mapped onto Pillow qualities
     with 4:4:4 sampling and optimised Huffman tables like the reference's mjpeg flags (PC:331-338)."""
@@ -342,7 +349,7 @@ def write_image(path, arr: np.ndarray, jpeg_q: int = None) -> None:
             if mode == "RGBA":
                 im = im.convert("RGB")
             quality = 95 if (jpeg_q is not None and jpeg_q >= 2) else 100
-            im.save(path, "JPEG", quality=quality, subsampling=0, optimize=True)
+            im.save(path, "JPEG", quality=quality, subsampling=0, optimize=_JPEG_OPTIMIZE)
         elif ext == ".png":
             im.save(path, "PNG", compress_level=3)
         elif ext in (".tif", ".tiff"):
