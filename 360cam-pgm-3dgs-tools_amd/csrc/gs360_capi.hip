@@ -2,6 +2,7 @@
 // Host side only: context / streams / events / memory, per-view constant preparation (float64 -> one
 // rounding to float32) and launch batching.  No CPU compute path exists here on purpose: without a GPU
 // every entry point fails with GS360_ERR_NODEV / GS360_ERR_HIP.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -43,6 +44,7 @@ struct Staging {  // per-slot device staging used by the *_host conveniences
     void* d_src = nullptr; size_t src_cap = 0;
     void* d_dst = nullptr; size_t dst_cap = 0;
     void* d_aux = nullptr; size_t aux_cap = 0;
+    void* d_maskbits = nullptr; size_t maskbits_cap = 0;   // keep-bit images of one masked equirect launch (<= GS360_MAX_FRAMES frames)
 };
 
 }  // namespace
@@ -374,6 +376,7 @@ int gs360_ctx_destroy(gs360_ctx* c) {
         if (c->stage[s].d_src) (void)hipFree(c->stage[s].d_src);
         if (c->stage[s].d_dst) (void)hipFree(c->stage[s].d_dst);
         if (c->stage[s].d_aux) (void)hipFree(c->stage[s].d_aux);
+        if (c->stage[s].d_maskbits) (void)hipFree(c->stage[s].d_maskbits);
         if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
     }
     if (c->d_cubic) (void)hipFree(c->d_cubic);
@@ -560,6 +563,8 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
     if (W < 8 || H < 2 || W > (1 << 21) || H > (1 << 21))
         return fail(GS360_ERR_ARG, "bad source size %dx%d (an equirect frame is at least 8 texels wide)", W, H);
+    // the kernels form a flipped ring member's latitude with v_mad_i32_i24 (24-bit operands): 32 H must stay below 2^23
+    if (H >= (1 << 18)) return fail(GS360_ERR_UNSUPPORTED, "source height %d: the equirect kernels take H < 262144", H);
     if (interp != GS360_INTERP_LINEAR && interp != GS360_INTERP_CUBIC)
         return fail(GS360_ERR_UNSUPPORTED, "equirect path implements INTER_LINEAR (1) and INTER_CUBIC (2), got %d", interp);
     if (flags & ~(uint32_t)GS360_EQ_FISHEYE_OUT) return fail(GS360_ERR_ARG, "unknown flags 0x%x", flags);
@@ -640,6 +645,9 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         ring_max = (int)((longest + 1) / 2);
     }
 
+    // members with the ring's own pitch sign first, the upside-down ones behind them: the kernel's member loop re-derives its
+    // latitude-dependent row offsets once per change of sign (results do not depend on the order)
+    for (auto& r : rings) std::stable_partition(r.begin(), r.end(), [&](int k) { return ev[k].flip == 0; });
     size_t r0 = 0;
     while (r0 < rings.size()) {
         size_t r1 = r0;
@@ -678,9 +686,27 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             // The cv2 table kernel, 1024 pixels per tile, gains 12 % from it (launch_table_batch).
             L.persist_blocks = 0;
             if (const char* e = std::getenv("GS360_EQ_PERSIST")) L.persist_blocks = std::atoi(e);   // probes: grid cap
+            // keep-masks: thresholded once per launch into bit images (the kernels only test `< 128`), behind the caller's upload
+            // on the launch stream: a streaming pass over W x H bytes per frame, ~7 us for an 8K mask
+            const int pitch_dw = (W + 1 + 31) / 32;
+            const size_t bits_bytes = (size_t)pitch_dw * 4 * (size_t)(H + 1);
+            if (mask_frames && (r0 == 0 || n_frames > GS360_MAX_FRAMES)) {   // (one frame chunk: later ring groups reuse the images)
+                Staging& st = c->stage[slot];
+                // the previous launch on this stream may still read the images: the reallocation's hipFree synchronises the device
+                if (int rc = ensure(c, &st.d_maskbits, &st.maskbits_cap, bits_bytes * (size_t)nf)) return rc;
+                MaskPack P;
+                std::memset(&P, 0, sizeof(P));
+                for (int f = 0; f < nf; ++f) {
+                    P.src[f] = (const uint8_t*)mask_frames[f0 + f];
+                    P.dst[f] = (uint32_t*)((uint8_t*)st.d_maskbits + bits_bytes * (size_t)f);
+                }
+                P.W = W; P.H = H; P.pitch_dw = pitch_dw; P.n = nf;
+                P.stride = (int64_t)mask_stride;
+                HIP_TRY(launch_mask_pack(P, c->stream[slot]));
+            }
             for (int f = 0; f < nf; ++f) {
                 L.src[f] = (const uint8_t*)src_frames[f0 + f];
-                L.mask[f] = mask_frames ? (const uint8_t*)mask_frames[f0 + f] : nullptr;
+                L.mask[f] = mask_frames ? (const uint8_t*)c->stage[slot].d_maskbits + bits_bytes * (size_t)f : nullptr;
                 for (int k = 0; k < nv; ++k) L.dst[f * nv + k] = (uint8_t*)dst[(size_t)(f0 + f) * n_views + order[k]];
             }
             L.kx32 = (float)(32.0 * (double)W / (2.0 * kPi));
@@ -692,7 +718,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             L.total_tiles = base * nf;
             L.chunk = (L.total_tiles + 7) / 8;
             L.src_stride = (int64_t)src_stride;
-            L.mask_stride = (int64_t)mask_stride;
+            L.mask_stride = (int64_t)pitch_dw * 4;      // of the bit images
             L.dst_stride = (int64_t)dst_stride;
             L.cubic_tab = c->d_cubic;
             if (esize == 2) {

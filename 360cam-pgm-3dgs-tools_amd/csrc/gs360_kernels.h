@@ -45,7 +45,7 @@ static_assert(sizeof(EqView) == 64 && offsetof(EqView, x0i32) % 8 == 0, "EqView 
 
 struct EqLaunch {
     const uint8_t* src[GS360_MAX_FRAMES];
-    const uint8_t* mask[GS360_MAX_FRAMES];   // optional keep-masks (H x W u8), all null when unused
+    const uint8_t* mask[GS360_MAX_FRAMES];   // optional keep-BIT images ((H + 1) rows of mask_stride bytes, see mask_pack_kernel), all null when unused
     uint8_t* dst[GS360_MAX_FRAMES * GS360_MAX_VIEWS];
     EqView view[GS360_MAX_VIEWS];
     float kx32, ky32;    // 32*W/(2*pi), 32*H/pi
@@ -60,7 +60,7 @@ struct EqLaunch {
     // Yaw rings: views [ring_first[g], ring_first[g] + ring_count[g]) share every EQ-SPEC constant except the integer
     // longitude offset x0i32 (and the sign of the pitch: `flip`), so one workgroup evaluates the coordinates of a tile once
     // and samples it for every member.  Tiles are numbered per RING (view[ring_first[g]].tile_base); the 16-bit kernel
-    // runs with one-view rings.
+    // runs full rings as well.
     int32_t n_rings;
     int32_t xcd_group_log2;   // >= 0: XCD x takes runs of 2^g consecutive tiles round-robin (rings of unequal size in one launch:
                               // contiguous chunks would hand whole rings to single XCDs); -1: contiguous chunks (`chunk`)
@@ -176,6 +176,14 @@ hipError_t build_color_rtab(const float* d_lut, const float* d_pos_r, void* d_rt
 hipError_t launch_color(const ColorLaunch& L, int C, hipStream_t s);
 
 // kernel launchers (gs360_kernels.hip)
+// keep-mask threshold + pack (gs360_equirect_views_masked_u8): byte masks -> bit images, one launch for all frames of a call
+struct MaskPack {
+    const uint8_t* src[GS360_MAX_FRAMES];
+    uint32_t* dst[GS360_MAX_FRAMES];
+    int32_t W, H, pitch_dw, n;   // pitch_dw = (W + 1 + 31) / 32 dwords per row; H + 1 rows are written
+    int64_t stride;              // bytes per row of the byte masks
+};
+hipError_t launch_mask_pack(const MaskPack& P, hipStream_t s);
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s);
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16

@@ -84,6 +84,26 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_EQ_WAVES
 #define GS360_EQ_WAVES 5     // wavefronts per SIMD of the bilinear equirect kernel (measured optimum, see the kernel comment)
 #endif
+#ifndef GS360_LEAN_PAIRED
+#define GS360_LEAN_PAIRED 0  // lean member loop: row-paired gathers (v_permlane32_swap) or one gather per tap row
+#endif
+#ifndef GS360_ALIGNBYTE_RAW
+#define GS360_ALIGNBYTE_RAW 1
+#endif
+#if GS360_ALIGNBYTE_RAW      // v_alignbyte_b32 shifts by S2[1:0] bytes: a byte offset's upper bits need not be masked off
+#define GS360_AB(o) (o)
+#else
+#define GS360_AB(o) ((o) & 3u)
+#endif
+#ifndef GS360_PROBE
+#define GS360_PROBE 0        // measurement probes (never shipped): 1 = tap reads folded into 256 bytes, 2 = dword row stores dropped
+#endif
+#ifndef GS360_EQ_ROWS_KERNEL
+#define GS360_EQ_ROWS_KERNEL 1
+#endif
+#ifndef GS360_EQR_WAVES
+#define GS360_EQR_WAVES 5    // bilinear RGB kernel of launches without blocked views (pipelined member loop only)
+#endif
 #ifndef GS360_EQC_WAVES
 #define GS360_EQC_WAVES 4    // wavefronts per SIMD of the cubic equirect kernel (124 registers; 40 KiB of LDS = four workgroups per CU)
 #endif
@@ -95,6 +115,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef GS360_PAIRED_FETCH
 #define GS360_PAIRED_FETCH 1
+#endif
+#ifndef GS360_EQ_LEAN
+#define GS360_EQ_LEAN 1      // bilinear RGB row-per-slot views: the lean, software-pipelined member loop (0: the round-3 loop, A/B reference)
 #endif
 
 
@@ -173,7 +196,7 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
             const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)packed);
             const uint32_t dw = __builtin_amdgcn_perm(pb, pa, rp.sel);   // = (pa >> sh) | (pb << (24 - sh)) on 24-bit pixels, one instruction
             int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
-            if (lane < full) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
+            if (lane < full && !((GS360_PROBE & 2) && dw != 0x12345678u)) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
             if (lane == full && rem)
                 for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
             return;
@@ -279,8 +302,13 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
     // one full-rate v_mad_u32_u24 per row instead of 64-bit multiply/add chains, and the load can use the
     // SGPR-base + VGPR-offset addressing form.
     const uint32_t col = (uint32_t)ixl * C;
+#if GS360_PROBE & 1      // probe builds only: every tap read lands in the first 256 bytes of the frame (no misses)
+    const uint32_t o0 = (__umul24((uint32_t)y0, (uint32_t)stride) + col) & 0xffu;
+    const uint32_t o1 = (__umul24((uint32_t)y1, (uint32_t)stride) + col) & 0xffu;
+#else
     const uint32_t o0 = __umul24((uint32_t)y0, (uint32_t)stride) + col;
     const uint32_t o1 = __umul24((uint32_t)y1, (uint32_t)stride) + col;
+#endif
     const uint8_t* r0 = src + o0;
     const uint8_t* r1 = src + o1;
     EqTaps<C> t;
@@ -321,12 +349,17 @@ __device__ __forceinline__ int dot2_i16_from(uint32_t taps, uint32_t weights, in
 #define GS360_PAIR(lo, hi) (0x0c000c00u | ((uint32_t)(hi) << 16) | (uint32_t)(lo))
 
 template <int C>
+__device__ __forceinline__ void eq_blend_f(const EqTaps<C>& t, const int fx, const int fy, uint32_t (&out)[4]);
+template <int C>
 __device__ __forceinline__ void eq_blend(const EqTaps<C>& t, int sx, int sy, uint32_t (&out)[4]) {
-    const int fx = sx & 31, fy = sy & 31;
+    eq_blend_f<C>(t, sx & 31, sy & 31, out);
+}
+template <int C>
+__device__ __forceinline__ void eq_blend_f(const EqTaps<C>& t, const int fx, const int fy, uint32_t (&out)[4]) {   // fx, fy in [0, 31]
     // (sum S a b + 512) >> 10 with a in {32-fx, fx}, b in {32-fy, fy}: the weights of one row, a0 b | (a1 b) << 16, are
     // one multiply of the packed horizontal pair (a1 b <= 1024 cannot carry into the upper half)
-    const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);
-    const uint32_t wr0 = ah * (uint32_t)(32 - fy), wr1 = ah * (uint32_t)fy;
+    const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);             // < 2^22
+    const uint32_t wr0 = __umul24(ah, (uint32_t)(32 - fy)), wr1 = __umul24(ah, (uint32_t)fy);
     if constexpr (C == 3) {          // row bytes: r0 g0 b0 r1 | g1 b1 . .
         out[0] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.x, t.t1.x, GS360_PAIR(0, 3)), wr1,
                                     dot2_i16_from(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 3)), wr0, 512)) >> 10;
@@ -505,12 +538,17 @@ __device__ __forceinline__ void eq_cubic_slow(const EqSrc& L, const int16_t* wta
 // One pass over the wavefront's 4 row slots for one column per lane: all gathers first, then blend, repair, store.
 //   reversed = false: lane l is pixel l of the row segment starting at `col0`
 //   reversed = true : lane l is pixel n_px-1-l (the mirrored half of the view)
-// keep-mask sample of one pixel: nearest texel of the EQ-SPEC coordinate, wrap in x, clamp in y
+// keep-mask sample of one pixel: nearest texel of the EQ-SPEC coordinate, wrap in x, clamp in y.  The kernels only ever test
+// `mask < 128`, so the C ABI thresholds each mask once per call into a BIT image (mask_pack_kernel below): row pitch
+// `mask_stride` bytes (whole dwords), one extra column (bit W = bit 0: the wrap) and one extra row (row H = row H - 1: the
+// clamp; sy + 16 lies in [0, 32 H] because |lat| <= pi/2), so the sample is an aligned dword read + a bit test, no wrap, no
+// clamp, from an image that stays in L2 (3.7 MB for an 8K frame instead of 29.5 MB of bytes).  Returns the dword shifted so that
+// bit 0 is the keep bit.
 __device__ __forceinline__ uint32_t eq_mask_at(const EqSrc& L, const uint8_t* __restrict__ mask, int sx, int sy) {
-    int xn = (sx + 16) >> 5;
-    if (xn >= L.W) xn -= L.W;
-    const int yn = min(max((sy + 16) >> 5, 0), L.H - 1);
-    return mask[(uint32_t)yn * (uint32_t)L.mask_stride + (uint32_t)xn];
+    const uint32_t t = (uint32_t)(sx + 16);                      // xn = t >> 5 in [0, W]
+    const uint32_t row = __umul24((uint32_t)(sy + 16) >> 5, (uint32_t)L.mask_stride);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(mask + (size_t)(row + ((t >> 8) & ~3u)), 4));
+    return w >> ((t >> 5) & 31u);
 }
 
 // Hand the wavefront's pixels to memory: blocked patches (store_patch_rgb) or one row per slot (store_row).
@@ -543,6 +581,48 @@ __device__ __forceinline__ void eq_store(uint8_t* dst, int64_t dstride, const ui
         if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, rp, reversed, skip_first);
 }
 
+// The bilinear pass in two steps, so that the ring-member loop can put the NEXT pass's gathers in flight before the current
+// pass's pixels are shuffled and stored (eq_views_tile):
+//   eq_pass_issue    the tap reads (and keep-mask bytes) of the wavefront's four row slots, no control flow, nothing consumed
+//   eq_pass_resolve  shift / blend / repair of flagged lanes / keep-mask -> px
+template <int C, bool MASKED>
+struct EqPassTaps {
+    EqTaps<C> taps[kRowsPerWave];
+    uint32_t keep[MASKED ? kRowsPerWave : 1];
+};
+template <int C, bool MASKED>
+__device__ __forceinline__ void eq_pass_issue(const EqSrc& L, const uint8_t* __restrict__ src, const uint8_t* __restrict__ mask,
+                                              const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave], EqPassTaps<C, MASKED>& T) {
+    if constexpr (MASKED) {                               // compile time: the mask reads join the tap reads in flight (behind a
+#pragma unroll                                            // run-time test the compiler waits for each of them inside the branch)
+        for (int s = 0; s < kRowsPerWave; ++s) T.keep[s] = eq_mask_at(L, mask, sxs[s], sys[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) T.taps[s] = eq_fetch<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s]);
+}
+template <int C, bool MASKED>
+__device__ __forceinline__ void eq_pass_resolve(const EqSrc& L, const uint8_t* __restrict__ src,
+                                                const int (&sxs)[kRowsPerWave], const int (&sys)[kRowsPerWave],
+                                                EqPassTaps<C, MASKED>& T, uint32_t (&px)[kRowsPerWave][4]) {
+    bool any_fix = false;
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) {
+        any_fix |= T.taps[s].fix;
+        eq_taps_finish<C>(T.taps[s]);
+        eq_blend<C>(T.taps[s], sxs[s], sys[s], px[s]);
+    }
+    if (any_lane(any_fix)) {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s)
+            if (T.taps[s].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
+    }
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s)
+            if (!(T.keep[s] & 1u)) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
+    }
+}
+
 template <int C, bool CUBIC, int MODE, bool MASKED>
 __device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restrict__ src, const uint8_t* __restrict__ mask,
                                         uint8_t* dst, int64_t dstride,
@@ -573,42 +653,16 @@ __device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restric
         if constexpr (MASKED) {
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s)
-                if (eq_mask_at(L, mask, sxs[s], sys[s]) < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
+                if (!(eq_mask_at(L, mask, sxs[s], sys[s]) & 1u)) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
         }
         eq_store<C, MODE>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, blk, rp);
         return;
     }
-    EqTaps<C> taps[kRowsPerWave];
-    uint32_t keep[kRowsPerWave];
-#pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s) keep[s] = 255u;
-    if constexpr (MASKED) {                               // compile time: the mask reads join the tap reads in flight (behind a
-#pragma unroll                                            // run-time test the compiler waits for each of them inside the branch)
-        for (int s = 0; s < kRowsPerWave; ++s) keep[s] = eq_mask_at(L, mask, sxs[s], sys[s]);
-    }
-    bool any_fix = false;
-#pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s) {
-        taps[s] = eq_fetch<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s]);
-        any_fix |= taps[s].fix;
-    }
+    EqPassTaps<C, MASKED> T;
+    eq_pass_issue<C, MASKED>(L, src, mask, sxs, sys, T);
     __builtin_amdgcn_sched_barrier(0);                    // every gather of the pass is in flight before the first is consumed
     uint32_t px[kRowsPerWave][4];
-#pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s) {
-        eq_taps_finish<C>(taps[s]);
-        eq_blend<C>(taps[s], sxs[s], sys[s], px[s]);
-    }
-    if (any_lane(any_fix)) {
-#pragma unroll
-        for (int s = 0; s < kRowsPerWave; ++s)
-            if (taps[s].fix) eq_sample_slow<C>(src, L.src_stride, L.W, L.H, sxs[s], sys[s], px[s]);
-    }
-    if constexpr (MASKED) {
-#pragma unroll
-        for (int s = 0; s < kRowsPerWave; ++s)
-            if (keep[s] < 128u) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
-    }
+    eq_pass_resolve<C, MASKED>(L, src, sxs, sys, T, px);
     eq_store<C, MODE>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, blk, rp);
 }
 
@@ -868,18 +922,23 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
 // LDS of a workgroup besides the cubic weight table: the blocked store's transpose slices (256 dwords per wavefront; its read-back
 // may touch the dword after the slice, which is the next slice or the first parked dword -- never used), then the parked ring
 // coordinates (see the member loop).  Every thread / wavefront only ever touches its own part: no barrier.
-template <int C, bool CUBIC, int ES>
+template <int C, bool CUBIC, int ES, bool ROWS = false, bool MASKED = false>     // ROWS: instantiation for launches without blocked views
 struct EqLds {
-    static constexpr bool kBlocked = (C == 3) && (ES == 1) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map available
+    static constexpr bool kBlocked = !ROWS && (C == 3) && (ES == 1) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map available
     static constexpr int kParkN = (CUBIC && ES == 2) ? 3 : (CUBIC ? GS360_RING_PARK_CUBIC : GS360_RING_PARK);     // 0 none, 1 latitude only, 3 all three
     static constexpr int kBlkDw = kBlocked ? kWaves * 256 : 0;
     static constexpr int kParkDw = kParkN * kRowsPerWave * 64 * kWaves;
-    static constexpr int kDwords = kBlkDw + (kParkDw ? kParkDw : 4);
+    // the pipelined bilinear member loop keeps ALL ring-shared coordinates in LDS (three 16-byte entries per thread)
+    // lean member loop (bilinear RGB, row-per-slot map): six int4 entries per thread -- latitude, left / mirrored longitude, the two
+    // tap rows' byte offsets and the vertical phase of the current pitch sign
+    static constexpr bool kLean = GS360_EQ_LEAN && C == 3 && !CUBIC && ES == 1 && kRowsPerWave == 4;
+    static constexpr int kPipeDw = kLean ? (MASKED ? 7 : 6) * kRowsPerWave * 64 * kWaves : 0;   // masked: + the keep-bit image's row offsets
+    static constexpr int kDwords = kBlkDw + (kParkDw + kPipeDw ? kParkDw + kPipeDw : 4);
 };
 
 // One tile of a ring (all its members, both halves) -- the body of eq_views_kernel.  `b` is the workgroup's position in the
 // tile order (blockIdx.x, or the persistent walk of the cubic variants).
-template <int C, bool CUBIC, bool MASKED, int ES>
+template <int C, bool CUBIC, bool MASKED, int ES, bool ROWS = false>
 __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, const int16_t* s_wtab, uint32_t* const s_lds) {
     // XCD-aware tile order: XCD x (= b % 8) walks tiles [x*chunk, (x+1)*chunk), or -- when the launch mixes rings of
     // different sizes, whose tiles differ in cost -- runs of 2^g consecutive tiles dealt round-robin to the XCDs
@@ -889,9 +948,9 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
         t = ((((q >> g) << 3) + (b & 7)) << g) + (q & ((1 << g) - 1));
     }
     if (t >= L.total_tiles) return;
-    constexpr bool kBlocked = EqLds<C, CUBIC, ES>::kBlocked;
-    constexpr int kParkN = EqLds<C, CUBIC, ES>::kParkN;
-    constexpr int kBlkDw = EqLds<C, CUBIC, ES>::kBlkDw;
+    constexpr bool kBlocked = EqLds<C, CUBIC, ES, ROWS, MASKED>::kBlocked;
+    constexpr int kParkN = EqLds<C, CUBIC, ES, ROWS, MASKED>::kParkN;
+    constexpr int kBlkDw = EqLds<C, CUBIC, ES, ROWS, MASKED>::kBlkDw;
     uint32_t* const s_blk = s_lds;
     int* const s_park = reinterpret_cast<int*>(s_lds + kBlkDw);
     int f = t / L.tiles_per_frame;
@@ -1092,6 +1151,219 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
     const int dst_base = uniform_here(f * L.n_views + k0);
     auto members = [&](auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
+    if constexpr (EqLds<C, CUBIC, ES, ROWS, MASKED>::kLean && MODE == 0) {
+        // The preset-shaped views are bound by the vector ALU, not by memory (probes: tap reads folded into two cache lines and stores
+        // dropped leave 79 / 64 / 81 % of the cfg1 / cfg3 / cfg5 time), so this loop does per pass only what changes per pass:
+        //  * everything a ring shares waits in LDS (each thread's own int4 entries, no barrier): latitude, the left / mirrored
+        //    longitude bases, and -- derived once per pitch sign -- the byte offsets of the two tap rows and the vertical phase;
+        //    a pass adds the member's integer longitude offset, wraps, and adds column offsets to the parked row offsets;
+        //  * the horizontal phase is the base's (x0i32 and 32 W are multiples of 32);
+        //  * v_alignbyte reads only the low two bits of its shift operand: the tap offsets are passed as they are;
+        //  * one turn per pass, software-pipelined: the NEXT pass's gathers are issued before the current pass's pixels are
+        //    shuffled and stored, the last pass is resolved behind the loop (a conditional issue would keep consumed tap
+        //    registers alive: copies in front of every use).
+        // Members with the opposite pitch sign re-derive the latitude entries once (the host sorts them behind the others).
+        // The mirrored pass is fetched and blended even for the one-column centre tile of an odd-width view; only its store is dropped.
+        int4* const park = reinterpret_cast<int4*>(s_park) + threadIdx.x;    // [k][256]
+        constexpr int kP = 64 * kWaves;
+        const uint32_t stride = (uint32_t)S.src_stride;
+        const int fix_from = uniform_here(32 * (S.W - 4));                   // ix > W - 5: the 12-byte read would leave the row
+        bool flipstate = false;
+        auto derive_lat = [&](const int4 lat, const bool flip) {             // row offsets and vertical phase for one pitch sign
+            const int la[4] = {lat.x, lat.y, lat.z, lat.w};
+            int r0[4], r1[4], fy[4];
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                const int sy = flip ? y0x2 - la[s] : la[s];
+                const int iy = sy >> 5;                                      // in [-1, H - 1] (|lat| <= pi/2 by construction)
+                r0[s] = (int)__umul24((uint32_t)max(iy, 0), stride);
+                r1[s] = (int)__umul24((uint32_t)min(iy + 1, S.H - 1), stride);
+                fy[s] = sy & 31;
+            }
+            park[3 * kP] = make_int4(r0[0], r0[1], r0[2], r0[3]);
+            park[4 * kP] = make_int4(r1[0], r1[1], r1[2], r1[3]);
+            park[5 * kP] = make_int4(fy[0], fy[1], fy[2], fy[3]);
+            if constexpr (MASKED) {                       // byte offset of the pixel's row in the keep-bit image
+                int mr[4];
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s)
+                    mr[s] = (int)__umul24((uint32_t)((flip ? y0x2 - la[s] : la[s]) + 16) >> 5, (uint32_t)S.mask_stride);
+                park[6 * kP] = make_int4(mr[0], mr[1], mr[2], mr[3]);
+            }
+        };
+        park[0 * kP] = make_int4(sys[0], sys[1], sys[2], sys[3]);
+        park[1 * kP] = make_int4(sxl[0], sxl[1], sxl[2], sxl[3]);
+        park[2 * kP] = make_int4(sxm[0], sxm[1], sxm[2], sxm[3]);
+        int2 mem = *reinterpret_cast<const int2*>(&L.view[k0].x0i32);
+        uint8_t* dst = L.dst[dst_base];
+        flipstate = mem.y != 0;
+        derive_lat(make_int4(sys[0], sys[1], sys[2], sys[3]), flipstate);
+        const bool has_mirror = n_px > (centre_dup ? 1 : 0);
+        const int col0_m = out_w - x0 - n_px;
+        // the pass in flight: raw tap dwords (fetch order), tap byte offsets (low two bits = misalignment), longitude coordinate
+        uint32_t ra[kRowsPerWave][3], rb[kRowsPerWave][3], o0[kRowsPerWave], o1[kRowsPerWave], keep[kRowsPerWave], kbit[kRowsPerWave];
+        int cx[kRowsPerWave];
+        auto issue = [&](const int4 lon, const int x0i, const bool flip) {
+            const int4 r0q = park[3 * kP], r1q = park[4 * kP];
+            const int lo[4] = {lon.x, lon.y, lon.z, lon.w};
+            const int r0[4] = {r0q.x, r0q.y, r0q.z, r0q.w}, r1[4] = {r1q.x, r1q.y, r1q.z, r1q.w};
+            if constexpr (MASKED) {                       // keep bits: one aligned dword of the bit image per pixel (see eq_mask_at)
+                const int4 mrq = park[6 * kP];
+                const int mr[4] = {mrq.x, mrq.y, mrq.z, mrq.w};
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s) {
+                    const uint32_t t = (uint32_t)eq_lon_member(lo[s], x0i, W32) + 16u;
+                    kbit[s] = t >> 5;                     // nearest column; its low five bits pick the bit (v_bfe reads only those)
+                    keep[s] = *reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(mask + (size_t)((uint32_t)mr[s] + ((t >> 8) & ~3u)), 4));
+                }
+                (void)flip;
+            }
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                cx[s] = eq_lon_member(lo[s], x0i, W32);
+                const uint32_t col = (uint32_t)min(cx[s] >> 5, S.W - 5) * 3u;
+                o0[s] = (uint32_t)r0[s] + col;
+                o1[s] = (uint32_t)r1[s] + col;
+#if GS360_PROBE & 1
+                o0[s] &= 0xffu; o1[s] &= 0xffu;
+#endif
+#if GS360_LEAN_PAIRED
+                const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0[s] & ~3u, o1[s] & ~3u, false, false);
+                const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
+                const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
+#else
+                const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o0[s] & ~3u), 4));
+                const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o1[s] & ~3u), 4));
+#endif
+#if GS360_PROBE & 4      // probe: no tap reads at all
+                ra[s][0] = o0[s]; ra[s][1] = o1[s]; ra[s][2] = (uint32_t)cx[s]; rb[s][0] = o1[s]; rb[s][1] = o0[s]; rb[s][2] = (uint32_t)cx[s] + 1u;
+                (void)qa; (void)qb;
+#else
+                ra[s][0] = qa[0]; ra[s][1] = qa[1]; ra[s][2] = qa[2];
+#if GS360_PROBE & 16     // probe: one gather per pixel (the second tap row reuses the first one's data)
+                rb[s][0] = ra[s][1]; rb[s][1] = ra[s][2]; rb[s][2] = ra[s][0]; (void)qb;
+#else
+                rb[s][0] = qb[0]; rb[s][1] = qb[1]; rb[s][2] = qb[2];
+#endif
+#endif
+            }
+        };
+        auto resolve = [&](uint32_t (&pk)[kRowsPerWave], const bool flip) {
+            const int4 fyq = park[5 * kP];
+            const int fys[4] = {fyq.x, fyq.y, fyq.z, fyq.w};
+            uint32_t px[kRowsPerWave][4];
+            bool any_fix = false;
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                EqTaps<3> t;
+#if GS360_LEAN_PAIRED
+                const u32x2 d0 = __builtin_amdgcn_permlane32_swap(ra[s][0], rb[s][0], false, false);
+                const u32x2 d1 = __builtin_amdgcn_permlane32_swap(ra[s][1], rb[s][1], false, false);
+                const u32x2 d2 = __builtin_amdgcn_permlane32_swap(ra[s][2], rb[s][2], false, false);
+                t.t0.x = __builtin_amdgcn_alignbyte(d1.x, d0.x, GS360_AB(o0[s]));
+                t.t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, GS360_AB(o0[s]));
+                t.t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, GS360_AB(o1[s]));
+                t.t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, GS360_AB(o1[s]));
+#else
+                t.t0.x = __builtin_amdgcn_alignbyte(ra[s][1], ra[s][0], GS360_AB(o0[s]));
+                t.t0.y = __builtin_amdgcn_alignbyte(ra[s][2], ra[s][1], GS360_AB(o0[s]));
+                t.t1.x = __builtin_amdgcn_alignbyte(rb[s][1], rb[s][0], GS360_AB(o1[s]));
+                t.t1.y = __builtin_amdgcn_alignbyte(rb[s][2], rb[s][1], GS360_AB(o1[s]));
+#endif
+                eq_blend_f<3>(t, cx[s] & 31, fys[s], px[s]);
+                any_fix |= cx[s] >= fix_from;
+            }
+            if (any_lane(any_fix)) {
+                const int4 lat = park[0 * kP];
+                const int la[4] = {lat.x, lat.y, lat.z, lat.w};
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s)
+                    if (cx[s] >= fix_from) eq_sample_slow<3>(src, S.src_stride, S.W, S.H, cx[s], flip ? y0x2 - la[s] : la[s], px[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                pk[s] = px[s][0] | (px[s][1] << 8) | (px[s][2] << 16);
+                if constexpr (MASKED) pk[s] &= (uint32_t)__builtin_amdgcn_sbfe((int)keep[s], kbit[s] & 31u, 1u);   // 0 or all ones
+            }
+        };
+        const int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
+        auto store_pass = [&](const uint32_t (&pk)[kRowsPerWave], uint8_t* const d, const bool flip, const bool mirror) {
+            if (mirror && !has_mirror) return;
+            const bool aligned = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(d) & 3) == 0) &&
+                                 (!mirror || ((((col0_m * 3) & 3) == 0) && !centre_dup));
+            uint8_t* const d0 = d + (int64_t)(mirror ? col0_m : x0) * 3;
+            // the lane-derived constants are made here, behind an optimisation barrier, once per pass (hoisted out of the loop they
+            // would be spilled, and a reload from scratch memory waits for every gather in flight)
+            int lane = rp.lane, a4 = rp.a4;
+            asm volatile("" : "+v"(lane), "+v"(a4));
+            if (aligned) {                                // whole-dword rows: eight shuffles in flight together, then the stores
+                const int la4 = mirror ? 4 * (n_px - 1) - a4 : a4, lb4 = mirror ? la4 - 4 : la4 + 4;
+                uint32_t dw[kRowsPerWave];
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s) {
+#if GS360_PROBE & 8      // probe: no cross-lane repack
+                    dw[s] = pk[s] + (uint32_t)(la4 + lb4);
+#else
+                    const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(la4 & 252, (int)pk[s]);
+                    const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)pk[s]);
+                    dw[s] = __builtin_amdgcn_perm(pb, pa, rp.sel);
+#endif
+                }
+                const uint32_t off = (uint32_t)lane << 2;
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s) {
+                    if (!row_ok[s]) continue;
+                    uint8_t* const row = d0 + (int64_t)(flip ? out_h - 1 - ys[s] : ys[s]) * dstride;
+                    if (lane < full && !((GS360_PROBE & 2) && dw[s] != 0x12345678u)) __builtin_nontemporal_store(dw[s], reinterpret_cast<uint32_t*>(row + (size_t)off));
+                    if (rem && lane == full)
+                        for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw[s] >> (8 * k));
+                }
+                return;
+            }
+            const int pos = mirror ? n_px - 1 - lane : lane;
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                if (!row_ok[s]) continue;
+                uint8_t* const row = d0 + (int64_t)(flip ? out_h - 1 - ys[s] : ys[s]) * dstride;
+                if (lane < n_px && !(mirror && centre_dup && pos == 0))
+                    for (int c = 0; c < 3; ++c) row[(size_t)(uint32_t)(pos * 3 + c)] = (uint8_t)(pk[s] >> (8 * c));
+            }
+        };
+        issue(make_int4(sxl[0], sxl[1], sxl[2], sxl[3]), mem.x, flipstate);
+        const int p_last = 2 * n_members - 1;
+        int2 mem_nx = mem;
+        uint8_t* dst_nx = dst;
+        uint32_t pk[kRowsPerWave];
+#pragma unroll 1
+        for (int p = 0; p < p_last; ++p) {
+            const bool mirror = (p & 1) != 0;             // wave-uniform: the pass in flight is a mirrored half
+            const bool flip = flipstate;
+            uint8_t* const dst_cur = dst;
+            if (!mirror) {                                // the next member's scalars, one pass ahead of their use
+                const int mn = min((p >> 1) + 1, n_members - 1);
+                mem_nx = *reinterpret_cast<const int2*>(&L.view[k0 + mn].x0i32);
+                dst_nx = L.dst[dst_base + mn];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            resolve(pk, flip);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mirror) {                                 // next: left half of the next member
+                mem = mem_nx;
+                dst = dst_nx;
+                if ((mem.y != 0) != flipstate) {
+                    flipstate = !flipstate;
+                    derive_lat(park[0 * kP], flipstate);
+                }
+            }
+            issue(park[(mirror ? 1 : 2) * kP], mem.x, flipstate);
+            __builtin_amdgcn_sched_barrier(0);
+            store_pass(pk, dst_cur, flip, mirror);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        resolve(pk, flipstate);                           // the last member's mirrored half
+        store_pass(pk, dst, flipstate, true);
+        return;
+    }
     // the member's own scalars (x0i32, flip: one 8-byte read; dst) are fetched one iteration ahead
     int2 mem_next = *reinterpret_cast<const int2*>(&L.view[k0].x0i32);
     uint8_t* dst_next = L.dst[dst_base];
@@ -1159,10 +1431,15 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
 // workgroups walk positions b, b + gridDim.x, ... of the tile order (the stride is a multiple of 8: a workgroup stays on its
 // XCD's tiles) -- but the C ABI leaves that off (`persist_blocks` = 0 -> grid_total == gridDim.x, one turn of the loop): measured
 // slower than one tile per workgroup, see equirect_views_impl.
-template <int C, bool CUBIC, bool MASKED, int ES = 1>      // ES: bytes per sample (1: uint8, 2: uint16 -- row-per-slot lane map, no mask)
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES, (CUBIC || ES == 2) ? GS360_EQC_WAVES : GS360_EQ_WAVES))) void eq_views_kernel(const EqLaunch L) {
+// ROWS: the bilinear RGB instantiation for launches in which no view uses the blocked lane map (every preset-shaped view): without
+// the two blocked loop bodies the pipelined member loop alone sets the register budget (65-73 registers), so its occupancy can be
+// chosen on its own (GS360_EQR_WAVES).
+template <int C, bool CUBIC, bool ES2, bool ROWS>
+constexpr int eq_kernel_waves() { return (CUBIC || ES2) ? GS360_EQC_WAVES : (ROWS ? GS360_EQR_WAVES : GS360_EQ_WAVES); }
+template <int C, bool CUBIC, bool MASKED, int ES = 1, bool ROWS = false>      // ES: bytes per sample (1: uint8, 2: uint16 -- row-per-slot lane map, no mask)
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(eq_kernel_waves<C, CUBIC, ES == 2, ROWS>(), eq_kernel_waves<C, CUBIC, ES == 2, ROWS>()))) void eq_views_kernel(const EqLaunch L) {
     __shared__ __attribute__((aligned(16))) int16_t s_wtab[CUBIC ? 32 * 32 * 16 : 8];
-    __shared__ uint32_t s_lds[EqLds<C, CUBIC, ES>::kDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lds[EqLds<C, CUBIC, ES, ROWS, MASKED>::kDwords];
     if constexpr (CUBIC) {
         const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
         uint4* l = reinterpret_cast<uint4*>(s_wtab);
@@ -1170,9 +1447,9 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((CU
         for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
         __syncthreads();
 #pragma unroll 1
-        for (int b = blockIdx.x; b < L.grid_total; b += gridDim.x) eq_views_tile<C, CUBIC, MASKED, ES>(L, b, s_wtab, s_lds);
+        for (int b = blockIdx.x; b < L.grid_total; b += gridDim.x) eq_views_tile<C, CUBIC, MASKED, ES, ROWS>(L, b, s_wtab, s_lds);
     } else {
-        eq_views_tile<C, CUBIC, MASKED, ES>(L, blockIdx.x, s_wtab, s_lds);
+        eq_views_tile<C, CUBIC, MASKED, ES, ROWS>(L, blockIdx.x, s_wtab, s_lds);
     }
 }
 
@@ -1813,6 +2090,38 @@ void fe_views_kernel(const FeBatch B) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// Keep-mask threshold + pack: bit x of row y = (mask[y][x] >= 128), i.e. the byte's top bit; bit W repeats bit 0 and row H repeats
+// row H - 1 (eq_mask_at).  One thread per output dword (32 mask bytes); a streaming pass over the byte masks, run by the C ABI on the
+// launch stream in front of the view kernel.
+__global__ __launch_bounds__(256) void mask_pack_kernel(const MaskPack P) {
+    const int f = blockIdx.z, y = blockIdx.y;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= P.pitch_dw) return;
+    const int ys = min(y, P.H - 1);
+    const uint8_t* __restrict__ row = P.src[f] + (int64_t)ys * P.stride;
+    const int x0 = d * 32;
+    uint32_t bits = 0;
+    if (x0 + 32 <= P.W && ((reinterpret_cast<uintptr_t>(row) + (uintptr_t)x0) & 15) == 0) {
+        const uint4* q = reinterpret_cast<const uint4*>(row + x0);
+        const uint4 a = q[0], b = q[1];
+        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bits |= (((((v[k] >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu) << (4 * k);   // byte top bits -> nibble
+    } else {
+        for (int k = 0; k < 32; ++k) {
+            const int x = x0 + k;
+            if (x <= P.W) bits |= (uint32_t)(row[x == P.W ? 0 : x] >> 7) << k;
+        }
+    }
+    if (x0 <= P.W && P.W < x0 + 32) bits |= (uint32_t)(row[0] >> 7) << (P.W - x0);      // the wrap column (fast path of the last full dword)
+    P.dst[f][(int64_t)y * P.pitch_dw + d] = bits;
+}
+hipError_t launch_mask_pack(const MaskPack& P, hipStream_t s) {
+    dim3 grid((unsigned)((P.pitch_dw + 255) / 256), (unsigned)(P.H + 1), (unsigned)P.n), block(256);
+    hipLaunchKernelGGL(mask_pack_kernel, grid, block, 0, s, P);
+    return hipGetLastError();
+}
+
 static unsigned eq_grid_blocks(const EqLaunch& L) {
     if (L.xcd_group_log2 < 0) return (unsigned)(L.chunk * 8);
     const int per = 8 << L.xcd_group_log2;                 // tiles per round over the XCDs
@@ -1822,10 +2131,15 @@ static unsigned eq_grid_blocks(const EqLaunch& L) {
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
     dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
     const bool masked = L.mask[0] != nullptr;             // all frames or none (checked by the C ABI)
+    bool rows_only = GS360_EQ_ROWS_KERNEL != 0;
+    for (int k = 0; k < L.n_views; ++k) rows_only = rows_only && !L.view[k].blocked;
     switch (C) {
         case 1: if (masked) hipLaunchKernelGGL((eq_views_kernel<1, false, true>), grid, block, 0, s, L);
                 else hipLaunchKernelGGL((eq_views_kernel<1, false, false>), grid, block, 0, s, L); break;
-        case 3: if (masked) hipLaunchKernelGGL((eq_views_kernel<3, false, true>), grid, block, 0, s, L);
+        case 3: if (rows_only) {
+                    if (masked) hipLaunchKernelGGL((eq_views_kernel<3, false, true, 1, true>), grid, block, 0, s, L);
+                    else hipLaunchKernelGGL((eq_views_kernel<3, false, false, 1, true>), grid, block, 0, s, L);
+                } else if (masked) hipLaunchKernelGGL((eq_views_kernel<3, false, true>), grid, block, 0, s, L);
                 else hipLaunchKernelGGL((eq_views_kernel<3, false, false>), grid, block, 0, s, L); break;
         case 4: if (masked) hipLaunchKernelGGL((eq_views_kernel<4, false, true>), grid, block, 0, s, L);
                 else hipLaunchKernelGGL((eq_views_kernel<4, false, false>), grid, block, 0, s, L); break;

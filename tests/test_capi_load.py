@@ -131,11 +131,13 @@ def test_kernels_keep_their_register_budgets():
         # (SGPR spills into vector lanes show up as a few dozen bytes of reserved scratch without any scratch instruction)
         assert r["scratch"] <= 64 and r["vgpr_spill"] == 0, (name, r)
     want = {  # mangled-name fragment -> minimum wavefronts per SIMD
-        "eq_views_kernelILi3ELb0ELb0ELi1E": 5,      # u8 RGB bilinear
-        "eq_views_kernelILi3ELb0ELb1ELi1E": 5,      # + keep-mask
-        "eq_views_kernelILi3ELb1ELb0ELi1E": 4,      # u8 RGB bicubic
-        "eq_views_kernelILi3ELb0ELb0ELi2E": 4,      # u16 RGB bilinear
-        "eq_views_kernelILi3ELb1ELb0ELi2E": 3,      # u16 RGB bicubic
+        "eq_views_kernelILi3ELb0ELb0ELi1ELb0E": 5,  # u8 RGB bilinear (launches with blocked views)
+        "eq_views_kernelILi3ELb0ELb0ELi1ELb1E": 5,  # u8 RGB bilinear, row-per-slot views only (the presets)
+        "eq_views_kernelILi3ELb0ELb1ELi1ELb0E": 5,  # + keep-mask
+        "eq_views_kernelILi3ELb0ELb1ELi1ELb1E": 5,
+        "eq_views_kernelILi3ELb1ELb0ELi1ELb0E": 4,  # u8 RGB bicubic
+        "eq_views_kernelILi3ELb0ELb0ELi2ELb0E": 4,  # u16 RGB bilinear
+        "eq_views_kernelILi3ELb1ELb0ELi2ELb0E": 3,  # u16 RGB bicubic
         "table_remap_kernelILi3ELi1E": 5,           # cv2 bilinear
         "table_remap_kernelILi3ELi2E": 4,           # cv2 bicubic (persistent)
         "table_remap_kernelILi3ELi4E": 4,           # cv2 Lanczos-4 (weights rebuilt per pixel)
