@@ -11,9 +11,10 @@ Infinity Cache, so every step is served from HBM; measured: 1 frame/step (cache-
 ~18 % faster per frame and are NOT what is reported; 8 frames/step is 1-2 % slower per frame than 16 because a launch's
 last partial round of workgroups weighs twice as much).  `value` = output pixels written by all ranks / wall time.
 
-The timed job is FIXED: `--steps` x `--frames` frame renders.  With N ranks the frames of that job are dealt round-robin
-(gs360/sharding.py, the partition the engine uses), every rank renders its share from its own HBM-resident frames in
-launches of `--frames`, and `value` = the job's pixels / the slowest rank's time (common start after barrier + synchronize, each
+The timed job is FIXED: `--steps` steps of L launches of `--frames` frames; L = 1 on one rank (the headline run), 16 on N > 1
+ranks (a rank's timed share at the driver's --steps 20 is then 12 ms at N = 8 instead of 0.8 ms; `value` is a rate, so the
+lines compare across N).  The launches of that job are dealt round-robin to the ranks
+(gs360/sharding.py, the partition the engine uses), every rank renders its share from its own HBM-resident frames, and `value` = the job's pixels / the slowest rank's time (common start after barrier + synchronize, each
 rank's clock stops when its own work is synchronised, MAX over ranks; the closing barrier follows and the time including it is
 reported as `config.seconds_incl_closing_barrier`): strong scaling of a resident job
 (`"scaling": "strong"`; at N = 1 it is exactly the headline run).  Per-rank times travel in `config.per_rank_seconds`.
@@ -61,6 +62,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB
 # oracle's map, tests/test_oracle_equirect.py) -- plus the stores, at the 6.29 TB/s the HBM sustains for streaming copies.
 LINE_BYTES_PER_FRAME = 718_080 * 128 + 11_520_000
 HBM_STREAM_GBS = 6290.0
+MULTI_RANK_LAUNCHES_PER_STEP = 16  # N > 1: launches of `--frames` frames per step (N = 1: one) -- see the job comment in main()
 
 
 def norm_yaw(a):
@@ -314,6 +316,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed launches before the warm-up steps until the device has been busy this long (clock ramp); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` array (the other BASELINE configs, N = 1 only)")
     ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (gloo: control-flow tests on a box "
@@ -337,6 +340,13 @@ def main():
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
+        if args.backend == "nccl":                 # one rank per GPU over RCCL: refuse here instead of letting a rank die at the rendezvous
+            import torch                           # (device_count() does not initialise the GPU)
+            n_dev = torch.cuda.device_count()
+            if args.gpus > n_dev:
+                print(f"bench.py: rank {n_dev} needs GPU {n_dev} but only {n_dev} are visible (one rank per GPU over RCCL); "
+                      "--backend gloo lets ranks share devices for control-flow tests", file=sys.stderr)
+                sys.exit(3)
         sys.exit(_self_launch(args.gpus))          # nothing has touched the GPU yet; the ranks are child processes
     world = int(env_world or "1")
     if world != args.gpus:
@@ -420,12 +430,13 @@ def main():
         d_frames = [ctx.to_device(f) for f in frames_host]
     d_out = [ctx.alloc(SIZE * SIZE * C) for _ in range(nf * N_VIEWS)]
     step = ctx.make_equirect_call(d_frames, W, H, C, views, d_out, slot=0, src_stride=stride if args.stride_pad else 0)
-    # the fixed job: steps x nf frame renders, dealt round-robin; this rank renders its share in launches of nf (+ one short one)
-    n_mine = len(frames_for_rank(args.steps * nf, world, rank))
-    full, rem = divmod(n_mine, nf)
-    step_rem = (ctx.make_equirect_call(d_frames[:rem], W, H, C, views, d_out[:rem * N_VIEWS], slot=0,
-                                       src_stride=stride if args.stride_pad else 0) if rem else None)
-
+    # the fixed job: `--steps` steps of LAUNCHES_PER_STEP launches of nf frames, the launches dealt round-robin to the ranks.  One
+    # rank: a step is one launch (the headline run, unchanged).  N > 1 ranks: a step is MULTI_RANK_LAUNCHES_PER_STEP launches, so
+    # that at the driver's --steps 20 a rank still has >= 12 ms of timed work at N = 8 (one launch is 0.3 ms: with one launch per
+    # step a rank's share was 2.5 launches = 0.8 ms and launch jitter decided the curve); `value` is a rate, comparable across N
+    launches_per_step = 1 if world == 1 else MULTI_RANK_LAUNCHES_PER_STEP
+    n_launches = len(frames_for_rank(args.steps * launches_per_step, world, rank))
+    n_mine = n_launches * nf
     # settle: the same launches, untimed, until the device has been busy for --settle-ms (clocks ramp over the first ~100 ms of
     # load: with 5 warm-up steps = 1.6 ms alone the 20 timed steps that follow run 6 % slower than in steady state), then the
     # caller's W warm-up steps
@@ -439,10 +450,8 @@ def main():
     barrier()
     ctx.event_record(0, 0)
     t0 = time.perf_counter()
-    for _ in range(full):
+    for _ in range(n_launches):
         step()
-    if step_rem is not None:
-        step_rem()
     ctx.event_record(0, 1)
     ctx.sync(-1)
     local = time.perf_counter() - t0
@@ -458,7 +467,7 @@ def main():
         all_t = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(all_t, mine_t)
         per_rank = [round(float(x.item()), 6) for x in all_t]
-    if rem or full == 0:
+    if n_launches == 0:
         step()                                                       # leave a full batch in d_out for the check below
         ctx.sync(-1)
 
@@ -476,9 +485,26 @@ def main():
         parity = all(np.array_equal(g, w) for g, w in zip(got, want))
         if not parity:
             print("bench.py: GPU output differs from the oracle -- number is INVALID", file=sys.stderr)
+    # the other BASELINE configs on the same record (N = 1 only, after the headline's timed region and buffers are done with):
+    # cfg1 / cfg3 / cfg5 (+ mask), the cubic default, cfg4 -- same timing method, one view of each against the oracle
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_secondary and W == 7680 and args.stride_pad == 0:
+        for b in d_frames + d_out:
+            ctx.free(b)
+        d_frames, d_out = [], []
+        sys.path.insert(0, str(ROOT / "tests"))
+        sys.path.insert(0, str(ROOT / "tests" / "tools"))
+        try:
+            import bench_configs
+            t_sec = time.perf_counter()
+            secondary = bench_configs.secondary_rows(ctx, steps=20)
+            print(f"bench.py: secondary configs took {time.perf_counter() - t_sec:.1f} s", file=sys.stderr)
+        except Exception as e:      # the headline line must survive a failure here
+            print(f"bench.py: secondary configs failed: {e!r}", file=sys.stderr)
+            secondary = [{"error": repr(e)}]
 
     if rank == 0:
-        px_per_step = nf * N_VIEWS * SIZE * SIZE
+        px_per_step = launches_per_step * nf * N_VIEWS * SIZE * SIZE
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = px_per_step * args.steps / elapsed / 1e6             # the whole fixed job / the slowest rank's time
         baseline_shape = (W == 7680 and args.stride_pad == 0)   # ALGO_BYTES_PER_FRAME was counted for the 7680-wide source only
@@ -503,7 +529,9 @@ def main():
                                    "bilinear 1/32-px fixed point (BASELINE.json configs[1])",
                        "frames_per_step": nf, "views": N_VIEWS, "out_px_per_step": px_per_step,
                        "device": info["name"], "parallelism": f"frames sharded x{world}, no collective",
-                       "job": f"{args.steps} steps x {nf} frames = {args.steps * nf} frame renders, dealt round-robin to {world} rank(s)",
+                       "launches_per_step": launches_per_step,
+                       "job": f"{args.steps} steps x {launches_per_step} launch(es) x {nf} frames = {args.steps * launches_per_step * nf} frame renders, "
+                              f"launches dealt round-robin to {world} rank(s)",
                        "frames_rank0": n_mine, "per_rank_seconds": per_rank, "seconds_incl_closing_barrier": round(with_barrier, 6),
                        "settle_ms": args.settle_ms,
                        "parity_vs_oracle": parity},
@@ -520,6 +548,8 @@ def main():
                                         "frac": round(LINE_BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9 / HBM_STREAM_GBS, 4)}},
             "cpu_baseline": cpu,
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         emit(line)
     ctx.close()
     if use_dist:

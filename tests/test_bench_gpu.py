@@ -28,7 +28,8 @@ def test_bench_self_launch_two_ranks_share_device0():
     d = _run(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--frames", "2"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["parity_vs_oracle"] is True
-    assert d["config"]["frames_rank0"] == 3 and len(d["config"]["per_rank_seconds"]) == 2      # 3 x 2 frame renders dealt to 2 ranks
+    # 3 steps x 16 launches x 2 frames, the launches dealt to 2 ranks: 24 launches = 48 frame renders on rank 0
+    assert d["config"]["launches_per_step"] == 16 and d["config"]["frames_rank0"] == 48 and len(d["config"]["per_rank_seconds"]) == 2
     assert d["cpu_baseline"] is None                   # the timed CPU sample is an N=1 item
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel_ms"] > 0
     assert 0 < d["roofline"]["line_bound"]["frac"] < 1.5
@@ -39,6 +40,48 @@ def test_bench_single_rank_line_matches_the_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["frames_per_step"] == 16 and d["config"]["frames_rank0"] == 48
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 16 * 54495972
     assert d["roofline"]["line_bound"]["bytes_per_launch"] == 16 * (718080 * 128 + 11520000)
+
+
+def test_bench_rccl_world_of_one_prints_exactly_one_json_line():
+    """the RCCL leg (backend nccl = RCCL): init, barrier, all_reduce(MAX), all_gather on ONE rank -- stdout must carry exactly one
+    JSON line (RCCL's banners go to stderr through the fd-1 redirection) with the keys of the plain run"""
+    plain = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["NCCL_DEBUG"] = "VERSION"                   # make RCCL print its banner
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--with-torch", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1, p.stdout[-2000:]
+    d = json.loads(out_lines[0])
+    assert set(d) == set(plain) and set(d["config"]) == set(plain["config"]) and set(d["roofline"]) == set(plain["roofline"])
+    assert d["n_gpus"] == 1 and d["config"]["frames_rank0"] == 48 and d["config"]["launches_per_step"] == 1
+    assert len(d["config"]["per_rank_seconds"]) == 1 and d["value"] > 0
+
+
+def test_bench_more_rccl_ranks_than_gpus_exits_3_without_hanging():
+    """`--gpus 2` over RCCL on a 1-GPU box: the rank without a GPU of its own must leave with exit code 3 and the message, the
+    launcher must come down with it (no hang at the rendezvous)"""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert "needs GPU 1 but only 1 are visible" in p.stderr, p.stderr[-2000:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # the same under a launcher (what the driver does): the rank without a GPU leaves with 3 and takes the job down, no hang
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "needs GPU 1 but only 1 are visible" in p.stderr, p.stderr[-3000:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bench_job_mode_two_ranks():

@@ -50,7 +50,8 @@ def time_steps(ctx, call, steps, warmup=5):
 def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR, with_mask=False, dtype=np.uint8):
     if dtype == np.uint16:
         return equirect_u16_cfg(ctx, name, W, H, specs, n_frames, steps, interp)
-    frames = [synth(H, W, k) for k in range(n_frames)]
+    base = synth(H, W, 0)                       # frame k = the base image rolled 97 k texels (distinct HBM-resident frames, one synthesis)
+    frames = [base] + [np.ascontiguousarray(np.roll(base, 97 * k, axis=1)) for k in range(1, n_frames)]
     d_fr = [ctx.to_device(f) for f in frames]
     views = [gs360.View.make(*s) for s in specs]
     d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(n_frames) for s in specs]
@@ -215,13 +216,79 @@ def color_cfg(ctx, steps):
     return res
 
 
+def cfg4_rows(ctx, steps, interps=((1, "linear"), (2, "cubic"))):
+    """cfg4 (2 x 4000^2 fisheye -> 6 x 1750^2, table mode, one batched launch per pair) for the given cv2 interpolations."""
+    cal_kw = dict(TEMPLATE_CALIB, width=4000, height=4000)
+    c = fe.SensorCalibration("0", "equisolid_fisheye", 4000, 4000, cal_kw["f"], cal_kw["cx"], cal_kw["cy"], cal_kw["k1"], cal_kw["k2"], cal_kw["k3"])
+    specs = fe.sfm10_specs(1750, 14.0, "36 36", 40.0, 40.0)[:6]
+    tables = fe.choose_lens_tables({"0": c}, "0", "0", specs, 0.0, 180.0, 190.0)
+    imgs = {"X": synth(4000, 4000, 1), "Y": synth(4000, 4000, 2)}
+    dev = {k: ctx.to_device(v) for k, v in imgs.items()}
+    d_tab = {v: (ctx.to_device(t["map_x"]), ctx.to_device(t["map_y"]), ctx.to_device(np.ascontiguousarray(t["valid"], np.uint8)))
+             for v, t in tables.items()}
+    d_out = {v: ctx.alloc(1750 * 1750 * 3) for v in tables}
+    jobs = [(dev[tables[s["view_id"]]["lens_key"]], 4000, 4000) + tuple(d_tab[s["view_id"]]) + (1750, 1750, 0, d_out[s["view_id"]])
+            for s in specs]
+    uv = sum(orc.table_distinct_texels(tables[s["view_id"]]["map_x"], tables[s["view_id"]]["map_y"], 4000, 4000) for s in specs)
+    px = 6 * 1750 * 1750
+    algo = px * (3 + 8 + 1) + uv * 3
+    v0 = specs[1]["view_id"]
+    t = tables[v0]
+    timed = []
+    for interp, label in interps:           # time everything first: the oracle's OpenMP team spins on the host afterwards
+        ms = time_steps(ctx, lambda: ctx.remap_tables_dev(jobs, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0), steps)
+        timed.append((interp, label, ms, ctx.download(d_out[v0], (1750, 1750, 3))))
+    res = []
+    for interp, label, ms, got in timed:
+        want = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=interp, threads=0), t["valid"], 0)
+        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, table mode, {label}", "ms_per_pair": round(ms, 4),
+                    "algorithmic_MB_per_pair": round(algo / 1e6, 1), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
+                    "parity_vs_oracle": bool(np.array_equal(got, want))})
+    for b in list(dev.values()) + [x for tup in d_tab.values() for x in tup] + list(d_out.values()):
+        ctx.free(b)
+    return res
+
+
+def secondary_rows(ctx, steps=20):
+    """The other BASELINE configs in compact form for bench.py's `secondary` array: same timing method as the rows above (HIP events
+    around `steps` batched launches of 4 resident frames / one lens pair), one view of each checked against the oracle."""
+    full360 = [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360]
+    fishlike = [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE]
+    plan = [
+        ("cfg1", "5760x2880 -> default 8x1600^2, linear", 5760, 2880, ring_views(8, 1600, HFOV_12MM), gs360.INTERP_LINEAR, False),
+        ("cfg1-cubic", "5760x2880 -> default 8x1600^2, cubic (the tool's default)", 5760, 2880, ring_views(8, 1600, HFOV_12MM), gs360.INTERP_CUBIC, False),
+        ("cfg2-cubic", "8K -> 6x800^2, cubic", 7680, 3840, ring_views(6, 800, HFOV_12MM), gs360.INTERP_CUBIC, False),
+        ("cfg3", "8K -> full360coverage 12x1600^2, linear", 7680, 3840, full360, gs360.INTERP_LINEAR, False),
+        ("cfg5", "8K -> fisheyelike 10x2048^2, linear", 7680, 3840, fishlike, gs360.INTERP_LINEAR, False),
+        ("cfg5+mask", "8K -> fisheyelike 10x2048^2, linear, fused keep-mask (threshold + pack pass inside the timed region)", 7680, 3840,
+         fishlike, gs360.INTERP_LINEAR, True),
+    ]
+    out = []
+    for key, name, w, h, specs, interp, with_mask in plan:
+        # frames per launch as in the full rows of main(): 8 for the 5.7K / 6 x 800^2 shapes, 4 for the 8K large-view presets
+        r = equirect_cfg(ctx, name, w, h, specs, 8 if key in ("cfg1", "cfg1-cubic", "cfg2-cubic") else 4, steps, interp=interp, with_mask=with_mask)
+        out.append({"config": key, "workload": name, "unit": "frame", "us_per_unit": r["us_per_frame"], "frac": r["frac_of_8TBps"],
+                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "parity_vs_oracle": r["parity_vs_oracle"]})
+    for r in cfg4_rows(ctx, steps):
+        out.append({"config": "cfg4-" + r["config"].rsplit(", ", 1)[1], "workload": r["config"], "unit": "lens pair",
+                    "us_per_unit": round(r["ms_per_pair"] * 1e3, 1), "frac": r["frac_of_8TBps"],
+                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_pair"], "parity_vs_oracle": r["parity_vs_oracle"]})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--only", default="", help="comma list of: equirect, fisheye, color (default all)")
+    ap.add_argument("--secondary", action="store_true", help="print bench.py's compact `secondary` rows instead")
     ap.add_argument("--eq", default="", help="comma list of equirect rows: cfg1,cfg2,cfg2cubic,cfg2u16,cfg2u16cubic,cfg3,cfg1cubic,cfg3cubic,cfg5,cfg5mask (default all)")
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=1)
+    if args.secondary:
+        for r in secondary_rows(ctx, min(args.steps, 20)):
+            print(json.dumps(r))
+        ctx.close()
+        return
     rows = []
     only = {t for t in args.only.split(",") if t}
     if only and "equirect" not in only:
