@@ -285,6 +285,16 @@ def _announce_jobs(jobs_list, workers: int) -> None:
         pass
 
 
+def _retire_jobs() -> None:
+    """End of a run: the engine forgets what the announced list left behind (jobs of a cancelled or failed run never arrive)."""
+    try:
+        from gs360 import engine as _engine
+        if _engine._engine is not None:
+            _engine._engine.retire()
+    except Exception:  # noqa: BLE001
+        pass
+
+
 # ---- main (PC:983-1087) --------------------------------------------------------------------------------
 def _print_cmd(cmd):
     print("$ " + " ".join(shlex.quote(c) for c in cmd))
@@ -349,8 +359,9 @@ def main():
     # therefore capped at twice the CPUs the process may actually use; an explicit -j is taken as given.
     workers = jobs
     if _selected_engine() != "ffmpeg":
+        from gs360 import hostmem
+        hostmem.tune_malloc()                     # the codec threads' large short-lived buffers: this process is the tool itself
         if str(args.jobs).lower() == "auto":
-            from gs360 import hostmem
             cap = int(os.environ.get("GS360_AUTO_WORKERS", "0")) or max(8, 2 * hostmem.effective_cpus())
             workers = min(jobs, max(1, cap))
         _announce_jobs(jobs_list, workers)
@@ -378,6 +389,7 @@ def main():
     if total and last_pct >= 0:
         sys.stdout.write("\n")
         sys.stdout.flush()
+    _retire_jobs()
 
     if stop_event.is_set():
         print(f"[STOPPED] Interrupted: success={ok}, failed={fail}, total={total}")

@@ -399,7 +399,12 @@ int gs360_device_info(gs360_ctx* c, char* name, size_t n, int32_t* cu_count, uin
 int gs360_dev_alloc(gs360_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) return fail(GS360_ERR_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMalloc(dptr, bytes + kSlack));
+    const hipError_t e = hipMalloc(dptr, bytes + kSlack);
+    if (e == hipErrorOutOfMemory) {               // its own code: a streaming caller (gs360/video.py) retires frames and tries again
+        (void)hipGetLastError();
+        return fail(GS360_ERR_NOMEM, "out of device memory (%zu bytes)", bytes);
+    }
+    HIP_TRY(e);
     return GS360_OK;
 }
 int gs360_dev_free(gs360_ctx* c, void* dptr) {

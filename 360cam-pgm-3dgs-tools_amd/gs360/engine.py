@@ -44,6 +44,19 @@ class _Batch:
         self.abandoned = set()          # indices of followers that left (cancel) before the results existed
 
 
+class _Source:
+    """What the engine remembers about one source while it is in flight."""
+    __slots__ = ("dev", "expected", "remaining", "active", "touched", "ahead")
+
+    def __init__(self, dev):
+        self.dev = dev                  # index into Engine.states: all views of a source share a device
+        self.expected = None            # view jobs that can arrive together (announce()), None = not announced
+        self.remaining = None           # announced view jobs that have not finished yet, None = not announced
+        self.active = 0                 # view jobs inside run_job right now
+        self.touched = False            # a view job has asked for the frame (the read-ahead leaves it alone from then on)
+        self.ahead = False              # decoded ahead and still holding a read-ahead permit
+
+
 class _DeviceState:
     def __init__(self, device):
         # render slots 0.._SLOTS_PER_DEVICE-1 plus ONE upload stream that _render never uses: a frame upload's sync then
@@ -90,7 +103,6 @@ class Engine:
         if n <= 0:
             raise capi.Gs360Error(-3, "no MI355X visible: the gs360 engine has no CPU fallback "
                                       "(use --engine ffmpeg to run the reference's ffmpeg path)")
-        hostmem.tune_malloc()                     # the codec threads' large short-lived buffers (see hostmem.py)
         want = os.environ.get("GS360_DEVICES")
         if devices is None and want:
             devices = [int(t) for t in want.split(",") if t.strip()]
@@ -100,16 +112,20 @@ class Engine:
         self.videos = {}                          # DecodePlan.key -> the video.VideoSession new view jobs join
         self._video_done = {}                     # DecodePlan.key -> view jobs finished so far (all sessions of that video)
         self.videos_lock = threading.Lock()
-        self._expected = {}                       # str(source path) -> view jobs that can arrive together (announce())
-        self._announce_lock = threading.Lock()
-        self._assigned = {}                       # str(source path) -> index into self.states (device_for)
+        self._video_budget = video.SharedBudget(video._BUDGET_BYTES * max(1, len(self.states)))   # all live sessions together
+        self._init_bookkeeping()
+
+    def _init_bookkeeping(self):
+        # per-source bookkeeping (a long-lived host -- the GUI imports the module once and exports many times -- must not grow):
+        # one record per source that is announced or has a job running; it goes when its announced jobs have all finished (or, for
+        # sources nobody announced, when its last running job leaves), and announce() / retire() drop what a cancelled run left
+        self._sources = {}                        # str(source path) -> _Source
+        self._announce_lock = threading.Lock()    # guards _sources, _inflight, the prefetch queue
+        self._inflight = [0] * len(self.states)   # sources currently held per device (device_for balances on THIS, not on history)
         self._prefetch_queue = collections.deque()   # announced still-image sources not yet decoded ahead
         self._prefetch_threads = []
         self._prefetch_permits = threading.Semaphore(_PREFETCH_FRAMES)
         self._prefetch_stop = threading.Event()
-        self._ahead = set()                       # sources decoded ahead whose view jobs have not arrived yet
-        self._touched = set()                     # sources a view job has asked for
-        self._load = [0] * len(self.states)       # sources assigned per device
 
     def close(self):
         self._prefetch_stop.set()
@@ -130,19 +146,47 @@ class Engine:
         self.states = []
 
     # -- sharding ---------------------------------------------------------------------------------
+    def _source(self, key):
+        """(announce lock held) the record of `key`, created on the least-loaded device"""
+        rec = self._sources.get(key)
+        if rec is None:
+            dev = min(range(len(self.states)), key=lambda d: (self._inflight[d], d))
+            rec = self._sources[key] = _Source(dev)
+            self._inflight[dev] += 1
+        return rec
+
+    def _drop(self, key):
+        """(announce lock held) forget `key`: its device slot and, if it was decoded ahead and never used, its permit"""
+        rec = self._sources.pop(key, None)
+        if rec is None:
+            return
+        self._inflight[rec.dev] -= 1
+        if rec.ahead:
+            rec.ahead = False
+            self._prefetch_permits.release()
+
     def device_for(self, src_path) -> int:
-        """frame -> device index; all views of a frame share a device.  Sources are dealt to the least-loaded device in the
-        order they become known -- the order of the announced job list when the caller announces one (the drop-in CLI does),
-        else first come first served -- so a folder of n frames occupies min(n, devices) devices with at most one frame of
-        spread (a hash of the path left devices idle by chance on the 6-8 file folders of the presets' typical use)."""
-        key = str(src_path)
+        """frame -> device index; all views of a frame share a device.  Sources are dealt to the device holding the fewest
+        sources IN FLIGHT, in the order they become known -- the order of the announced job list when the caller announces one
+        (the drop-in CLI does), else first come first served -- so a folder of n frames occupies min(n, devices) devices with at
+        most one frame of spread (a hash of the path left devices idle by chance on the 6-8 file folders of the presets' typical
+        use), and an engine that has already served other folders starts level again."""
         with self._announce_lock:
-            dev = self._assigned.get(key)
-            if dev is None:
-                dev = min(range(len(self.states)), key=lambda d: (self._load[d], d))
-                self._assigned[key] = dev
-                self._load[dev] += 1
-            return dev
+            return self._source(str(src_path)).dev
+
+    def retire(self):
+        """End of a run (the drop-in CLI's main() calls it; announce() does the same for what an earlier run left behind): forget
+        every source no job is working on -- a cancelled or failed run leaves announced jobs that never arrive -- and empty the
+        read-ahead queue.  Permits of frames decoded ahead and never used go back."""
+        with self._announce_lock:
+            self._prefetch_queue.clear()
+            for key in [k for k, r in self._sources.items() if r.active == 0]:
+                self._drop(key)
+
+    def bookkeeping(self):
+        """sizes of the per-source tables (tests: a long-lived engine must come back to empty)"""
+        with self._announce_lock:
+            return {"sources": len(self._sources), "inflight": list(self._inflight), "queue": len(self._prefetch_queue)}
 
     # -- frame residency --------------------------------------------------------------------------
     def _frame_key(self, path):
@@ -316,12 +360,13 @@ class Engine:
         """Optional hint from a caller that knows its whole job list (the drop-in CLI's main()): how many view jobs each
         source has, and how many of them can be in flight at once.  Lets a batch leader stop lingering as soon as every
         view that can arrive has arrived.  Without it every batch simply lingers for the full window."""
+        self.retire()                             # leftovers of an earlier (cancelled) run
         counts = collections.Counter(str(j.src) for j in jobs)
         with self._announce_lock:
-            for k, n in counts.items():
-                self._expected[k] = min(n, workers) if workers else n
-        for k in counts:                          # deal the sources to the devices in job-list order (Counter keeps it)
-            self.device_for(k)
+            for k, n in counts.items():           # deal the sources to the devices in job-list order (Counter keeps it)
+                rec = self._source(k)
+                rec.expected = min(n, workers) if workers else n
+                rec.remaining = (rec.remaining or 0) + n
         self._start_prefetch([j.src for j in jobs if j.is_still_image])
 
     # -- decode-ahead -----------------------------------------------------------------------------
@@ -356,9 +401,10 @@ class Engine:
             with self._announce_lock:
                 while self._prefetch_queue:
                     cand = self._prefetch_queue.popleft()
-                    if cand not in self._touched:     # else its view jobs are already running (they decode it themselves)
+                    rec = self._sources.get(cand)
+                    if rec is not None and not rec.touched:   # else its view jobs are already running (they decode it themselves)
                         src = cand
-                        self._ahead.add(src)
+                        rec.ahead = True
                         break
             if src is None:
                 self._prefetch_permits.release()
@@ -367,47 +413,63 @@ class Engine:
                 st = self.states[self.device_for(src)]
                 self.release_frame(st, self.resident_frame(st, src))
             except Exception:  # noqa: BLE001  (the view job reports the real error when it gets there)
-                self._job_touches(src)
+                self._job_touches(src, entering=False)
         with self._announce_lock:
             self._prefetch_threads = [t for t in self._prefetch_threads if t is not threading.current_thread()]
 
-    def _job_touches(self, src):
-        """a view job (or a failed prefetch) reached `src`: whatever ran ahead for it is consumed"""
+    def _job_touches(self, src, entering=True):
+        """a view job (or a failed prefetch) reached `src`: whatever ran ahead for it is consumed.  -> the source's record"""
+        with self._announce_lock:
+            rec = self._source(str(src))
+            rec.touched = True
+            if entering:
+                rec.active += 1
+            if rec.ahead:
+                rec.ahead = False
+                self._prefetch_permits.release()
+            return rec
+
+    def _job_leaves(self, src):
+        """a view job is done with `src` (written, failed or cancelled): the record goes with the last announced job -- or, for a
+        source nobody announced, with the last job working on it"""
         key = str(src)
         with self._announce_lock:
-            self._touched.add(key)
-            if key in self._ahead:
-                self._ahead.discard(key)
-                self._prefetch_permits.release()
-
-    def _expected_for(self, src) -> int:
-        with self._announce_lock:
-            return self._expected.get(str(src), capi.MAX_VIEWS)
+            rec = self._sources.get(key)
+            if rec is None:
+                return
+            rec.active -= 1
+            if rec.remaining is not None:
+                rec.remaining -= 1
+            if rec.active <= 0 and (rec.remaining is None or rec.remaining <= 0):
+                self._drop(key)
 
     def run_job(self, job: JobSpec, stop_event=None, want_array: bool = False):
         """Execute one (frame, view) job: render (coalesced with the frame's other views) and write job.dst.  Returns a copy
         of the view when want_array is set (the result itself lives in pooled pinned memory), else None."""
         view, flags = self._view_for(job)
         interp = self._interp_for(job)
-        st = self.states[self.device_for(job.src)]
-        held = []
-        self._job_touches(job.src)
+        rec = self._job_touches(job.src)
+        try:
+            st = self.states[rec.dev]
+            held = []
 
-        def get_frame():
-            entry = self.resident_frame(st, job.src)
-            held.append(entry)
-            return entry[0], entry[1], entry[2], entry[3], entry[5]
-        try:
-            arr, release = self._render(st, self._frame_key(job.src), get_frame, view, interp, flags,
-                                        expected=self._expected_for(job.src), stop_event=stop_event)
+            def get_frame():
+                entry = self.resident_frame(st, job.src)
+                held.append(entry)
+                return entry[0], entry[1], entry[2], entry[3], entry[5]
+            try:
+                arr, release = self._render(st, self._frame_key(job.src), get_frame, view, interp, flags,
+                                            expected=rec.expected or capi.MAX_VIEWS, stop_event=stop_event)
+            finally:
+                for entry in held:
+                    self.release_frame(st, entry)
+            try:
+                imageio.write_image(job.dst, arr, jpeg_q=job.jpeg_q)
+                return np.array(arr) if want_array else None
+            finally:
+                release()
         finally:
-            for entry in held:
-                self.release_frame(st, entry)
-        try:
-            imageio.write_image(job.dst, arr, jpeg_q=job.jpeg_q)
-            return np.array(arr) if want_array else None
-        finally:
-            release()
+            self._job_leaves(job.src)
 
     def stats(self):
         """Counters since start: batched launches, views, seconds the launch+copy sections held a stream."""
@@ -429,7 +491,12 @@ class Engine:
                     self.videos.pop(key).close()          # idle sessions of other videos give their memory back
                 if sess is not None and sess.active_jobs == 0:
                     sess.close()
-                sess = self.videos[plan.key] = video.VideoSession(self.states, plan, stop_event, register_proc)
+                    sess = None
+                if sess is None:
+                    self._video_done.pop(plan.key, None)  # no session of this video is alive: a count left by a cancelled or partly
+                                                          # failed run must not make the new run's jobs look finished early
+                self._video_budget.total = video._BUDGET_BYTES * max(1, len(self.states))
+                sess = self.videos[plan.key] = video.VideoSession(self.states, plan, stop_event, register_proc, shared=self._video_budget)
                 token = sess.join()
             return sess, token
 

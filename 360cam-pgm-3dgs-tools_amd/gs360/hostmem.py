@@ -1,17 +1,24 @@
-"""Host allocator settings for the codec threads.
+"""Host allocator settings for the codec threads of the drop-in CLIs.
 
-Every decoded panorama and every encoded view is a 8-50 MB NumPy / Pillow buffer that lives for a few tens of milliseconds.  glibc
-hands such blocks back to the kernel as soon as they are freed (heap trimming), so each of the dozens of decode / encode threads
-page-faults its buffers in again and again, and the faults of all threads serialise on the process's memory-map lock: measured on the
-MI355X box (256 host threads, `scripts/bench_cli_e2e.py --frames 48 --jobs 32`) 33 -> 44-53 frames/s with trimming off.
-`tune_malloc()` tells glibc to keep freed memory (M_TRIM_THRESHOLD) and to grow heaps in larger steps (M_TOP_PAD).  Process-wide,
-glibc only, idempotent; `GS360_MALLOC_TUNE=0` leaves the allocator alone.
+Every decoded panorama and every encoded view is a 8-50 MB NumPy / Pillow buffer that lives for a few tens of milliseconds, in dozens
+of decode / encode threads at once.  `tune_malloc()` makes three glibc settings (mallopt): heap trimming off (M_TRIM_THRESHOLD), heaps
+grown in 256 MB steps (M_TOP_PAD), and the mmap threshold raised to its maximum of 32 MiB (M_MMAP_THRESHOLD) so that blocks up to
+that size are served from the heaps and recycled instead of being mapped and unmapped once per image (any mallopt call freezes glibc's
+dynamic threshold; left at its 128 KiB start value every one of these buffers would be an mmap / munmap pair and the first two
+settings would not touch them).  Blocks above 32 MiB (a decoded 5.7K panorama is 50 MB) stay mmap'ed.  Measured on the MI355X box
+(256 host threads under a 16-CPU quota, `scripts/bench_cli_e2e.py --frames 48 --jobs 32`): profiles/r03/cli_e2e_malloc.txt (first
+two settings) and profiles/r04/cli_e2e_malloc_mmap.txt (all three).
+
+Process-wide and permanent (a process that has called it never trims again and keeps a 256 MB top pad per heap), so it is the
+CLIs' `main()` that calls it, not the engine: a host application that imports the engine keeps its own allocator behaviour.
+glibc only, idempotent; `GS360_MALLOC_TUNE=0` leaves the allocator alone, `GS360_MALLOC_MMAP_MB=0` leaves the mmap threshold alone.
 """
 import ctypes
 import os
 
 _M_TRIM_THRESHOLD = -1
 _M_TOP_PAD = -2
+_M_MMAP_THRESHOLD = -3
 _done = False
 
 
@@ -31,6 +38,12 @@ def tune_malloc() -> bool:
     mallopt.restype = ctypes.c_int
     ok = mallopt(_M_TRIM_THRESHOLD, 2**31 - 1) == 1
     ok = (mallopt(_M_TOP_PAD, 256 << 20) == 1) and ok
+    try:
+        mmap_mb = int(os.environ.get("GS360_MALLOC_MMAP_MB", "32"))
+    except ValueError:
+        mmap_mb = 32
+    if mmap_mb > 0:
+        ok = (mallopt(_M_MMAP_THRESHOLD, min(mmap_mb, 32) << 20) == 1) and ok
     _done = ok
     return ok
 

@@ -28,6 +28,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import capi
 from .jobspec import JobSpec
 
 # options that belong to the encoder / muxer of the per-view process and have no meaning for the shared decoder
@@ -162,6 +163,21 @@ def read_exact_into(stream, mv: memoryview) -> None:
 
 
 # ---- session ---------------------------------------------------------------------------------------------------
+class SharedBudget:
+    """Device memory all live sessions of one engine may hold together (GS360_VIDEO_CACHE_GB per device x devices).  A session
+    superseded by a second decode of the same video stays alive until its last job leaves; with a budget of its own each, two
+    sessions could ask for twice the budget of a device."""
+
+    def __init__(self, total):
+        self.total = int(total)
+        self.used = 0
+        self.lock = threading.Lock()
+
+    def add(self, n):
+        with self.lock:
+            self.used += n
+
+
 class VideoSession:
     """Decoded frames of one video on the engine's devices, streamed: the reader keeps at most `budget` bytes resident, view
     jobs walk the frames with a cursor each, and a frame every registered job has passed is retired when the reader needs
@@ -170,13 +186,14 @@ class VideoSession:
     were retired cannot join (join() returns None): the engine starts a second session for it and its fellow late-comers.
     Thread-safe."""
 
-    def __init__(self, states, plan: DecodePlan, stop_event=None, register_proc=None, budget=None):
+    def __init__(self, states, plan: DecodePlan, stop_event=None, register_proc=None, budget=None, shared=None):
         self.states = states
         self.plan = plan
         self.stop_event = stop_event
         self.register_proc = register_proc       # callable(proc, add: bool): lets the caller's cancel handler see the decoder
         per_device = _BUDGET_BYTES if budget is None else budget
         self.budget = per_device * max(1, len(states))    # the budget is per device; frames are dealt round-robin
+        self.shared = shared if shared is not None else SharedBudget(self.budget)   # `shared`: the engine's, one for all sessions
         self.frames = {}                          # k -> (state, DeviceBuffer, H, W, dtype), k in [first, count)
         self.first = 0                            # frames below `first` have been retired
         self.count = 0                            # frames published so far
@@ -199,25 +216,50 @@ class VideoSession:
     def _make_room(self, nbytes):
         """Called by the reader with self.cond held: retire passed frames until `nbytes` more fit, waiting for the view jobs
         to advance when nothing can go.  A single frame larger than the whole budget is admitted alone."""
-        while self.bytes + nbytes > self.budget and self.bytes > 0:
-            low = min(self.cursors.values()) if self.cursors else self.first      # no job registered: nothing has been passed
-            if self.first < low:
-                st, buf, h, w, dt = self.frames.pop(self.first)
-                self.bytes -= h * w * 3 * np.dtype(dt).itemsize
-                self.first += 1
-                self.retired += 1
-                if st.ctx.handle:
-                    st.ctx.free(buf)
-                continue
-            if self.closing or (self.stop_event is not None and self.stop_event.is_set()):
-                raise PpmError("cancelled")
-            self.cond.wait(timeout=0.25)
+        while self.shared.used + nbytes > self.shared.total and self.bytes > 0:
+            if not self._retire_one():
+                if self.closing or (self.stop_event is not None and self.stop_event.is_set()):
+                    raise PpmError("cancelled")
+                self.cond.wait(timeout=0.25)
+
+    def _retire_one(self) -> bool:
+        """(self.cond held) free the oldest frame if every registered job has passed it"""
+        low = min(self.cursors.values()) if self.cursors else self.first      # no job registered: nothing has been passed
+        if self.first >= low or self.first not in self.frames:
+            return False
+        st, buf, h, w, dt = self.frames.pop(self.first)
+        n = h * w * 3 * np.dtype(dt).itemsize
+        self.bytes -= n
+        self.shared.add(-n)
+        self.first += 1
+        self.retired += 1
+        if st.ctx.handle:
+            st.ctx.free(buf)
+        return True
+
+    def _alloc(self, st, nbytes):
+        """device block for the next frame; when the device itself is out of memory (other users of the GPU, a budget set too
+        high) the reader does what it does at the budget: retire a passed frame, or wait for the view jobs, and try again"""
+        while True:
+            try:
+                return st.ctx.alloc(nbytes)
+            except capi.Gs360Error as exc:
+                if exc.code != -5:
+                    raise
+                with self.cond:
+                    if self.bytes == 0:
+                        raise                     # nothing of ours to give back: the frame does not fit at all
+                    if not self._retire_one():
+                        if self.closing or (self.stop_event is not None and self.stop_event.is_set()):
+                            raise PpmError("cancelled") from exc
+                        self.cond.wait(timeout=0.25)
 
     def _publish(self, st, buf, h, w, fdtype, nbytes):
         with self.cond:
             self.frames[self.count] = (st, buf, h, w, fdtype)
             self.count += 1
             self.bytes += nbytes
+            self.shared.add(nbytes)
             self.peak_bytes = max(self.peak_bytes, self.bytes)
             self.cond.notify_all()
 
@@ -264,7 +306,7 @@ class VideoSession:
                     pending = None
                 with self.cond:
                     self._make_room(nbytes)
-                buf = st.ctx.alloc(nbytes)
+                buf = self._alloc(st, nbytes)
                 ev = _EVENT_BASE + which
                 try:
                     with st.upload_lock:          # the engine's still-image uploads share this stream (engine.resident_frame)
@@ -369,4 +411,5 @@ class VideoSession:
                 if st.ctx.handle:
                     st.ctx.free(buf)
             self.frames = {}
+            self.shared.add(-self.bytes)
             self.bytes = 0

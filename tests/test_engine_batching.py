@@ -24,12 +24,16 @@ class FakeState:
         self.given_back.append(buf)
 
 
-def make_engine(monkeypatch, launches, fail=False, delay=0.0):
+def make_engine(monkeypatch, launches, fail=False, started=None, release=None):
+    """`started` / `release`: events of the test double -- the fake launch reports that it is running and then waits to be let go,
+    so the tests order things by handshake, never by how long something takes"""
     eng = engine.Engine.__new__(engine.Engine)
 
     def fake_launch(st, buf, H, W, C, views, interp, flags, dtype=np.uint8):
-        if delay:
-            time.sleep(delay)
+        if started is not None:
+            started.set()
+        if release is not None:
+            assert release.wait(10)
         if fail:
             raise capi.Gs360Error(-2, "boom")
         launches.append([v.yaw_deg for v in views])
@@ -38,7 +42,20 @@ def make_engine(monkeypatch, launches, fail=False, delay=0.0):
     return eng
 
 
-def run_jobs(eng, st, yaws, expected, frame_calls, linger=0.2, stagger=0.0):
+def wait_for_views(st, key_prefix, n, timeout=10.0):
+    """block until the open batch of the frame has n views (the condition variable the engine itself notifies)"""
+    deadline = time.monotonic() + timeout
+    with st.batch_cond:
+        while True:
+            hit = [b for k, b in st.open_batches.items() if k[0] == key_prefix]
+            if hit and len(hit[0].views) >= n:
+                return
+            left = deadline - time.monotonic()
+            assert left > 0, "batch never reached the expected size"
+            st.batch_cond.wait(left)
+
+
+def run_jobs(eng, st, yaws, expected, frame_calls, serial=False):
     out, errs = {}, {}
 
     def get_frame():
@@ -57,23 +74,23 @@ def run_jobs(eng, st, yaws, expected, frame_calls, linger=0.2, stagger=0.0):
         t = threading.Thread(target=job, args=(y,))
         t.start()
         threads.append(t)
-        if stagger:
-            time.sleep(stagger)
+        if serial:                       # the next caller arrives after this one's batch has left
+            t.join(10)
+            assert not t.is_alive()
     for t in threads:
         t.join(10)
+        assert not t.is_alive()
     return out, errs
 
 
 def test_views_of_one_frame_leave_as_one_launch(monkeypatch):
-    monkeypatch.setattr(engine, "_LINGER_S", 3.0)
+    monkeypatch.setattr(engine, "_LINGER_S", 3600.0)              # the linger can not be what ends the wait: the arrivals must
     launches, frame_calls = [], []
     eng, st = make_engine(monkeypatch, launches), FakeState()
-    t0 = time.monotonic()
-    out, errs = run_jobs(eng, st, [0, 60, 120, 180, 240, 300], expected=6, frame_calls=frame_calls)
+    out, errs = run_jobs(eng, st, [0, 60, 120, 180, 240, 300], expected=6, frame_calls=frame_calls)   # (threads joined within 10 s)
     assert not errs and out == {y: y % 251 for y in [0, 60, 120, 180, 240, 300]}
     assert len(launches) == 1 and sorted(launches[0]) == [0, 60, 120, 180, 240, 300]
     assert len(frame_calls) == 1                                  # the leader alone made the frame resident
-    assert time.monotonic() - t0 < 2.0                            # it left as soon as the announced six had arrived, not after 3 s
     assert len(st.given_back) == 6 and not st.open_batches        # every pinned buffer returned, no batch left open
 
 
@@ -81,7 +98,7 @@ def test_late_jobs_form_their_own_batch_and_serial_callers_do_not_wait_forever(m
     monkeypatch.setattr(engine, "_LINGER_S", 0.05)
     launches, frame_calls = [], []
     eng, st = make_engine(monkeypatch, launches), FakeState()
-    out, errs = run_jobs(eng, st, [0, 90, 180], expected=16, frame_calls=frame_calls, stagger=0.5)    # arrive well after the linger
+    out, errs = run_jobs(eng, st, [0, 90, 180], expected=16, frame_calls=frame_calls, serial=True)    # each arrives after the previous batch left
     assert not errs and len(out) == 3
     assert [len(b) for b in launches] == [1, 1, 1]
     launches.clear()
@@ -105,9 +122,10 @@ def test_leader_failure_reaches_every_member(monkeypatch):
 def test_cancelled_follower_does_not_strand_its_pinned_block(monkeypatch):
     """a follower that leaves on stop_event while the launch is still running never collects its view: the leader hands the
     pinned block back to the pool when the results exist (round-2 ADVICE, engine.py:211)"""
-    monkeypatch.setattr(engine, "_LINGER_S", 0.2)
+    monkeypatch.setattr(engine, "_LINGER_S", 3600.0)
     launches = []
-    eng, st = make_engine(monkeypatch, launches, delay=0.8), FakeState()
+    started, let_go = threading.Event(), threading.Event()
+    eng, st = make_engine(monkeypatch, launches, started=started, release=let_go), FakeState()
     stop = threading.Event()
     res, errs = {}, {}
 
@@ -121,32 +139,59 @@ def test_cancelled_follower_does_not_strand_its_pinned_block(monkeypatch):
             errs[y] = exc
     lead = threading.Thread(target=job, args=(0, None))
     lead.start()
-    time.sleep(0.05)
+    wait_for_views(st, "frameA", 1)       # the leader has opened the batch
     foll = threading.Thread(target=job, args=(60, stop))
     foll.start()
-    time.sleep(0.4)                       # both joined, the (slow) launch is running
+    assert started.wait(10)               # both joined (expected = 2 ended the wait) and the launch is running
     stop.set()
-    foll.join(5)
-    lead.join(5)
+    foll.join(10)
+    assert not foll.is_alive()            # the follower left while the launch was still running
+    let_go.set()
+    lead.join(10)
+    assert not lead.is_alive()
     assert res == {0: 0} and list(errs) == [60] and "cancelled" in str(errs[60])
     assert len(launches) == 1 and len(launches[0]) == 2
     assert sorted(b[1] for b in st.given_back) == [0.0, 60.0]     # the leader's own block and the abandoned one both came back
 
 
+class _CountingPermits:
+    """the read-ahead's semaphore, instrumented: `starved` is set whenever a thread asked for a permit and none came"""
+
+    def __init__(self, n):
+        self._sem = threading.Semaphore(n)
+        self.starved = threading.Event()
+
+    def acquire(self, timeout=None):
+        ok = self._sem.acquire(timeout=timeout)
+        if not ok:
+            self.starved.set()
+        return ok
+
+    def release(self):
+        self._sem.release()
+
+
+def bare_engine(n_devices=2):
+    eng = engine.Engine.__new__(engine.Engine)
+    eng.states = [object() for _ in range(n_devices)]
+    eng._init_bookkeeping()
+    return eng
+
+
+def wait_until(pred, timeout=10.0):
+    deadline = time.monotonic() + timeout
+    while not pred():
+        assert time.monotonic() < deadline, "condition never became true"
+        time.sleep(0.005)
+
+
 def test_decode_ahead_runs_at_most_its_permits_ahead_and_hands_them_back(monkeypatch):
     """Engine._start_prefetch / _job_touches (host logic, no GPU): announced sources are decoded in order by the background
     threads, never more than GS360_PREFETCH_FRAMES beyond what the view jobs have reached; a job touching a source frees its permit."""
-    import collections as c
-    eng = engine.Engine.__new__(engine.Engine)
-    eng.states = [object(), object()]
-    eng._announce_lock = threading.Lock()
-    eng._assigned, eng._load = {}, [0, 0]
-    eng._prefetch_queue, eng._prefetch_threads = c.deque(), []
+    eng = bare_engine(2)
     monkeypatch.setattr(engine, "_PREFETCH_FRAMES", 3)
     monkeypatch.setattr(engine, "_PREFETCH_THREADS", 2)
-    eng._prefetch_permits = threading.Semaphore(3)
-    eng._prefetch_stop = threading.Event()
-    eng._ahead, eng._touched = set(), set()
+    eng._prefetch_permits = permits = _CountingPermits(3)
     decoded, lock = [], threading.Lock()
 
     def fake_resident(st, src):
@@ -156,25 +201,78 @@ def test_decode_ahead_runs_at_most_its_permits_ahead_and_hands_them_back(monkeyp
     monkeypatch.setattr(eng, "resident_frame", fake_resident, raising=False)
     monkeypatch.setattr(eng, "release_frame", lambda st, entry: None, raising=False)
     srcs = [f"/p/{k}.png" for k in range(8)]
-    eng._start_prefetch(srcs + srcs[:3])                      # duplicates (several views per source) collapse
-    deadline = time.monotonic() + 2.0
-    while len(decoded) < 3 and time.monotonic() < deadline:
-        time.sleep(0.01)
-    time.sleep(0.3)
-    assert sorted(decoded) == srcs[:3]                        # three permits: three frames ahead, in order, no more
-    assert [eng.device_for(s) for s in srcs[:4]] == [0, 1, 0, 1] or len({eng.device_for(s) for s in srcs}) == 2
+    jobs = [type("J", (), {"src": s, "is_still_image": True})() for s in srcs + srcs[:3]]   # duplicates (several views per source) collapse
+    eng.announce(jobs, workers=4)
+    assert [eng.device_for(s) for s in srcs[:4]] == [0, 1, 0, 1]
+    wait_until(lambda: len(decoded) >= 3)
+    permits.starved.clear()
+    assert permits.starved.wait(10)                           # a thread asked for a fourth permit and did not get one ...
+    assert sorted(decoded) == srcs[:3]                        # ... three permits: three frames ahead, in order, no more
     eng._job_touches(srcs[0])                                 # the first view job arrives: one permit comes back
-    deadline = time.monotonic() + 2.0
-    while len(decoded) < 4 and time.monotonic() < deadline:
-        time.sleep(0.01)
+    wait_until(lambda: len(decoded) >= 4)
+    permits.starved.clear()
+    assert permits.starved.wait(10)
     assert sorted(decoded) == srcs[:4]
     for s in srcs[1:]:
         eng._job_touches(s)                                   # jobs overtake the read-ahead: touched sources are skipped
-    time.sleep(0.6)
+    wait_until(lambda: not eng._prefetch_threads)             # queue drained: the read-ahead threads have left
     assert len(decoded) <= 8 and len(set(decoded)) == len(decoded)
-    eng._prefetch_stop.set()
-    for t in list(eng._prefetch_threads):
-        t.join(2.0)
+
+
+def test_a_cancelled_run_hands_its_read_ahead_permits_back(monkeypatch):
+    """frames decoded ahead whose view jobs never arrive (cancel, an earlier failure): retire() -- the CLI's main() calls it, and so does
+    the next announce() -- returns their permits and empties the tables (round-3 ADVICE, engine.py:349)"""
+    eng = bare_engine(2)
+    monkeypatch.setattr(engine, "_PREFETCH_FRAMES", 2)
+    monkeypatch.setattr(engine, "_PREFETCH_THREADS", 2)
+    eng._prefetch_permits = permits = _CountingPermits(2)
+    decoded = []
+    monkeypatch.setattr(eng, "resident_frame", lambda st, src: decoded.append(src) or [None, 0, 0, 0, 1, None], raising=False)
+    monkeypatch.setattr(eng, "release_frame", lambda st, entry: None, raising=False)
+    srcs = [f"/q/{k}.png" for k in range(5)]
+    eng.announce([type("J", (), {"src": s, "is_still_image": True})() for s in srcs], workers=2)
+    wait_until(lambda: len(decoded) >= 2)
+    assert permits.starved.wait(10)                           # both permits are out, nothing touches the frames: the run was cancelled
+    eng.retire()
+    wait_until(lambda: not eng._prefetch_threads)             # the read-ahead threads see the empty queue and leave
+    assert eng.bookkeeping() == {"sources": 0, "inflight": [0, 0], "queue": 0}
+    assert permits.acquire(timeout=1) and permits.acquire(timeout=1)      # both permits are back
+
+
+def test_three_runs_leave_the_engine_empty_and_level(monkeypatch, tmp_path):
+    """A long-lived host (the GUI imports the module once and exports many times): three announce -> run cycles over disjoint folders;
+    every cycle spreads its sources over the devices with at most one frame of difference, whatever came before, and the
+    per-source tables are empty again after every cycle (round-3 VERDICT #7)."""
+    eng = bare_engine(3)
+    monkeypatch.setattr(engine, "_PREFETCH_FRAMES", 0)        # (read-ahead off: this test is about the bookkeeping)
+    used = []
+
+    def fake_render(st, fkey, get_frame, view, interp, flags=0, expected=1, stop_event=None):
+        used.append(eng.states.index(st))
+        return np.zeros((2, 2, 3), np.uint8), (lambda: None)
+    monkeypatch.setattr(eng, "_render", fake_render, raising=False)
+    monkeypatch.setattr(eng, "_view_for", lambda job: (None, 0), raising=False)
+    monkeypatch.setattr(eng, "_interp_for", lambda job: capi.INTERP_LINEAR, raising=False)
+    monkeypatch.setattr(eng, "_frame_key", lambda path: str(path), raising=False)
+    monkeypatch.setattr(engine.imageio, "write_image", lambda dst, arr, jpeg_q=None: None)
+    for cycle, n_src in enumerate((7, 4, 8)):                 # 7 = 3 + 2 + 2: the first cycle leaves an uneven history behind
+        jobs = [type("J", (), {"src": tmp_path / f"run{cycle}" / f"f{k}.png", "dst": "x", "jpeg_q": 2, "is_still_image": True})()
+                for k in range(n_src) for _view in range(6)]
+        eng.announce(jobs, workers=8)
+        per_dev = collections.Counter(eng.device_for(j.src) for j in {str(j.src): j for j in jobs}.values())
+        assert max(per_dev.values()) - min(per_dev.get(d, 0) for d in range(3)) <= 1, (cycle, per_dev)
+        used.clear()
+        threads = [threading.Thread(target=eng.run_job, args=(j,)) for j in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(10)
+            assert not t.is_alive()
+        assert len(used) == len(jobs)
+        assert eng.bookkeeping() == {"sources": 0, "inflight": [0, 0, 0], "queue": 0}, cycle
+    # a source nobody announced (the GUI path calls run_one without a job list) is remembered only while a job works on it
+    eng.run_job(type("J", (), {"src": tmp_path / "loose.png", "dst": "x", "jpeg_q": 2, "is_still_image": True})())
+    assert eng.bookkeeping()["sources"] == 0
 
 
 def test_malloc_tuning_is_idempotent_and_switchable(monkeypatch):

@@ -62,6 +62,20 @@ def test_equirect_poles_seam_and_odd_shapes(ctx, orc, lanemap):
     _assert_same(got, want, "poles/seam/odd")
 
 
+def test_equirect_tallest_source_the_kernels_take(ctx, orc):
+    """a flipped ring member's latitude is formed with a 24-bit multiply-add (32 H < 2^23): the tallest source the C ABI admits,
+    H = 2^18 - 1, one view pair that forms a ring with a flipped member -- and one row more is refused, not mis-sampled
+    (round-3 ADVICE, gs360_kernels.hip:1130)"""
+    H, W = (1 << 18) - 1, 8
+    src = np.random.default_rng(5).integers(0, 256, (H, W, 1), dtype=np.uint8)
+    specs = [(0, 40, 50, 50, 48, 48), (0, -40, 50, 50, 48, 48), (90, 89, 70, 70, 32, 32)]
+    got, want = _eq_both(ctx, orc, src, specs)
+    _assert_same(got, want, "H = 2^18 - 1")
+    with pytest.raises(gs360.Gs360Error) as exc:
+        ctx.equirect_views(np.zeros((H + 1, W, 1), np.uint8), [gs360.View.make(*specs[0])])
+    assert exc.value.code == -4
+
+
 @pytest.mark.parametrize("channels", [1, 4])
 def test_equirect_channels(ctx, orc, channels):
     src = rand_image(256, 512, c=channels, seed=11)

@@ -352,6 +352,82 @@ def test_closing_a_blocked_session_releases_the_reader(tmp_path):
     assert sess.finished and not sess.thread.is_alive()
 
 
+def _walk_all(sess, tok, out, pause=None):
+    k = 0
+    while True:
+        if pause is not None:
+            pause.wait(10)
+        fr = sess.frame(tok, k)
+        if fr is None:
+            break
+        out.append(k)
+        k += 1
+    sess.leave(tok)
+
+
+def test_two_sessions_of_one_engine_share_one_budget(tmp_path):
+    """a superseded session stays alive next to the one that replaces it (engine._video_session): together they hold at most the
+    engine's budget (+ the frames in flight), not one budget each (round-3 ADVICE, video.py:178)"""
+    import threading
+    make_clip(tmp_path / "clip.npy", n=10, h=64, w=128)       # 24 KB frames
+    states = [_FakeState()]
+    shared = video.SharedBudget(60 << 10)                      # two frames and a bit for BOTH sessions together
+    peak = [0]
+    real_add = shared.add
+
+    def add(n):
+        real_add(n)
+        peak[0] = max(peak[0], shared.used)
+    shared.add = add
+    a = video.VideoSession(states, _decode_plan(tmp_path), shared=shared)
+    b = video.VideoSession(states, _decode_plan(tmp_path), shared=shared)
+    seen = {0: [], 1: []}
+    threads = [threading.Thread(target=_walk_all, args=(s, s.join(), seen[i])) for i, s in enumerate((a, b))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(30)
+        assert not t.is_alive()
+    assert seen[0] == list(range(10)) and seen[1] == list(range(10)) and a.error is None and b.error is None
+    assert peak[0] <= (60 << 10) + 2 * 24576                  # one frame in flight per session above the shared budget at most
+    a.close()
+    b.close()
+    assert shared.used == 0 and not states[0].ctx.live
+
+
+def test_device_out_of_memory_is_back_pressure_not_a_decoder_error(tmp_path):
+    """the device refuses an allocation (other tenants, a budget set above what is free): the reader retires a passed frame or waits
+    for the view jobs and tries again, exactly as at its budget; the job still sees every frame"""
+    import threading
+    from gs360 import capi
+    clip = make_clip(tmp_path / "clip.npy", n=8, h=64, w=128)
+    st = _FakeState()
+    real_alloc = st.ctx.alloc
+    refused = [0]
+
+    def alloc(nbytes):                                          # the "device" holds two frames
+        if len(st.ctx.live) >= 2:
+            refused[0] += 1
+            raise capi.Gs360Error(-5, "out of device memory")
+        return real_alloc(nbytes)
+    st.ctx.alloc = alloc
+    sess = video.VideoSession([st], _decode_plan(tmp_path), budget=1 << 30)     # the budget alone would admit everything
+    got = []
+    tok = sess.join()
+    k = 0
+    while True:
+        fr = sess.frame(tok, k)
+        if fr is None:
+            break
+        _st, buf, h, w, _dt = fr
+        got.append(_st.ctx.live[buf].reshape(h, w, 3).copy())
+        k += 1
+    sess.leave(tok)
+    assert sess.error is None and len(got) == 8 and all(np.array_equal(a, b) for a, b in zip(got, clip))
+    assert refused[0] > 0 and sess.retired >= 6
+    sess.close()
+
+
 @pytest.mark.gpu
 def test_video_streams_past_the_budget_on_the_gpu(tmp_path, orc, monkeypatch):
     """the whole path with a budget of ~two frames: 10 frames x 3 views with only TWO workers, so that the third view job
