@@ -28,7 +28,7 @@ O=sys.argv[1]
 out=collections.defaultdict(dict)
 for f in sorted(glob.glob(O+'/p*/*/*counter_collection.csv')):
     acc=collections.defaultdict(list)
-    for r in csv.DictReader(open(f)): acc[(r['Kernel_Name'].split('(')[0],r['Counter_Name'])].append(float(r['Counter_Value']))
+    for r in csv.DictReader(open(f)): acc[(r['Kernel_Name'].split('(gs360::')[0].split('(float')[0],r['Counter_Name'])].append(float(r['Counter_Value']))
     for (k,c),v in acc.items(): out[k][c]={'mean_per_launch':sum(v)/len(v),'launches':len(v)}
 json.dump(out,open(O+'/pmc_summary.json','w'),indent=1)
 for k,d in out.items():
