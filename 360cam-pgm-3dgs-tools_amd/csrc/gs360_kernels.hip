@@ -464,7 +464,35 @@ __device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqSrc& L, const uint
 
 // 48 multiply-adds per pixel as 24 v_dot2_i32_i16 (see eq_blend): constant selectors -- the 12 tap bytes of a row are
 // b0..b11, channel c owns b[c], b[3+c], b[6+c], b[9+c] -- and the table already stores the weights as int16 pairs.
-// `wtab` is the LDS copy in the equirect kernel and the global table in the cv2 kernels.
+// `wtab` is the workgroup's LDS copy of the table (cubic_lds_fill / cubic_lds_weights).
+
+// The LDS copy of the 32 x 32-phase weight table is kept as TWO half tables -- window rows 0-1 of every phase (16 bytes each), then
+// rows 2-3 -- instead of 1024 entries of 32 bytes: a lane's two 16-byte reads then collide with another lane's only when their
+// phases differ by a multiple of 16 instead of 8 (round 3: 59 % of the cubic kernels' LDS-active cycles were bank conflicts).
+#ifndef GS360_CUBIC_SPLIT
+#define GS360_CUBIC_SPLIT 1
+#endif
+__device__ __forceinline__ void cubic_lds_weights(const int16_t* wtab, int phase, uint32_t (&wpk)[8]) {
+    const uint4* wq = reinterpret_cast<const uint4*>(wtab);
+#if GS360_CUBIC_SPLIT
+    const uint4 wa = wq[phase], wb = wq[1024 + phase];
+#else
+    const uint4 wa = wq[2 * phase], wb = wq[2 * phase + 1];
+#endif
+    wpk[0] = wa.x; wpk[1] = wa.y; wpk[2] = wa.z; wpk[3] = wa.w; wpk[4] = wb.x; wpk[5] = wb.y; wpk[6] = wb.z; wpk[7] = wb.w;
+}
+// fill: thread t copies 16-byte piece i of the global table ([phase][2] pieces) to its place in the LDS layout
+__device__ __forceinline__ void cubic_lds_fill(int16_t* s_wtab, const int16_t* g_tab, int n_threads) {
+    const uint4* g = reinterpret_cast<const uint4*>(g_tab);
+    uint4* l = reinterpret_cast<uint4*>(s_wtab);
+    for (int i = threadIdx.x; i < 2048; i += n_threads) {
+#if GS360_CUBIC_SPLIT
+        l[(i & 1) * 1024 + (i >> 1)] = g[i];
+#else
+        l[i] = g[i];
+#endif
+    }
+}
 
 template <bool ONE_SHIFT>
 __device__ __forceinline__ void eq_cubic_rows(const EqCubicTaps& t, const uint32_t (&wpk)[8], int (&acc)[3]) {
@@ -495,9 +523,8 @@ __device__ __forceinline__ void eq_cubic_rows(const EqCubicTaps& t, const uint32
 }
 
 __device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, const int16_t* wtab, bool stride4, uint32_t (&out)[4]) {
-    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
-    const uint4 wa = wq[0], wb = wq[1];
-    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    uint32_t wpk[8];
+    cubic_lds_weights(wtab, t.phase, wpk);
     int acc[3];                                           // (sum + 2^14) >> 15: the chains start at 2^14
     if (stride4) eq_cubic_rows<true>(t, wpk, acc);        // wave-uniform
     else eq_cubic_rows<false>(t, wpk, acc);
@@ -509,9 +536,8 @@ __device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, const int16
 template <int C>
 __device__ __forceinline__ void eq_cubic_slow(const EqSrc& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
     const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
-    const uint4* wq = reinterpret_cast<const uint4*>(wtab + (fy * 32 + fx) * 16);
-    const uint4 wa = wq[0], wb = wq[1];
-    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    uint32_t wpk[8];
+    cubic_lds_weights(wtab, fy * 32 + fx, wpk);
     int cols[4];
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx) {
@@ -817,9 +843,8 @@ __device__ __forceinline__ void eq16_cubic_rows(const Eq16CubicTaps& t, const ui
     }
 }
 __device__ __forceinline__ void eq16_cubic_blend_rgb(const Eq16CubicTaps& t, const int16_t* wtab, bool stride4, uint32_t (&out)[4]) {
-    const uint4* wq = reinterpret_cast<const uint4*>(wtab + t.phase * 16);
-    const uint4 wa = wq[0], wb = wq[1];
-    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    uint32_t wpk[8];
+    cubic_lds_weights(wtab, t.phase, wpk);
     // (sum w S' + 2^30 + 2^14) >> 15 in 32 bits: the chains start at 2^14 -- |sum w S'| + 2^14 <= 32768 * 1.9 * 32768 + 2^14 < 2^31
     // (the bound asserted on the table in tests/test_u16.py) -- and 2^30 >> 15 = 32768 is added after the shift, exactly
     int acc[3];
@@ -831,7 +856,8 @@ __device__ __forceinline__ void eq16_cubic_blend_rgb(const Eq16CubicTaps& t, con
 template <int C>
 __device__ __forceinline__ void eq16_cubic_slow(const EqSrc& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
     const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
-    const int16_t* wt = wtab + (fy * 32 + fx) * 16;
+    uint32_t wpk[8];
+    cubic_lds_weights(wtab, fy * 32 + fx, wpk);
     int cols[4];
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx) {
@@ -844,7 +870,8 @@ __device__ __forceinline__ void eq16_cubic_slow(const EqSrc& L, const int16_t* w
         const uint8_t* row = src + (int64_t)min(max(iy - 1 + ky, 0), L.H - 1) * L.src_stride;
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
-            const int w = wt[ky * 4 + kx];
+            const uint32_t pk = wpk[(ky * 4 + kx) >> 1];
+            const int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] += (int64_t)((int)ld_u16(row + 2 * (cols[kx] * C + c)) * w);
         }
@@ -1441,10 +1468,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(eq_
     __shared__ __attribute__((aligned(16))) int16_t s_wtab[CUBIC ? 32 * 32 * 16 : 8];
     __shared__ __attribute__((aligned(16))) uint32_t s_lds[EqLds<C, CUBIC, ES, ROWS, MASKED>::kDwords];
     if constexpr (CUBIC) {
-        const uint4* g = reinterpret_cast<const uint4*>(L.cubic_tab);
-        uint4* l = reinterpret_cast<uint4*>(s_wtab);
-#pragma unroll
-        for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+        cubic_lds_fill(s_wtab, L.cubic_tab, 64 * kWaves);
         __syncthreads();
 #pragma unroll 1
         for (int b = blockIdx.x; b < L.grid_total; b += gridDim.x) eq_views_tile<C, CUBIC, MASKED, ES, ROWS>(L, b, s_wtab, s_lds);
@@ -1929,10 +1953,7 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBat
     __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : (kLanczosRgb ? (256 + 2048) * 2 : 8)];
     if constexpr (kFastCubic) {
         if (B.job[0].cubic_tab) {             // (the context's table: the same pointer in every job)
-            const uint4* g = reinterpret_cast<const uint4*>(B.job[0].cubic_tab);
-            uint4* l = reinterpret_cast<uint4*>(s_wtab);
-#pragma unroll
-            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+            cubic_lds_fill(s_wtab, B.job[0].cubic_tab, 64 * kWaves);
             __syncthreads();
         }
 #pragma unroll 1
@@ -2074,10 +2095,7 @@ void fe_views_kernel(const FeBatch B) {
     __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
     if constexpr (kFastCubic) {
         if (B.common.pipelined) {
-            const uint4* g = reinterpret_cast<const uint4*>(B.common.cubic_tab);
-            uint4* l = reinterpret_cast<uint4*>(s_wtab);
-#pragma unroll
-            for (int i = 0; i < (32 * 32 * 16 * 2 / 16) / (64 * kWaves); ++i) l[i * 64 * kWaves + threadIdx.x] = g[i * 64 * kWaves + threadIdx.x];
+            cubic_lds_fill(s_wtab, B.common.cubic_tab, 64 * kWaves);
             __syncthreads();
         }
 #pragma unroll 1
@@ -2160,6 +2178,8 @@ hipError_t launch_equirect_cubic(const EqLaunch& L0, int C, hipStream_t s) {
     dim3 grid(eq_grid_blocks(L0)), block(64 * kWaves);
     const EqLaunch L = eq_persistent(L0, grid);
     const bool masked = L.mask[0] != nullptr;
+    // (a rows-only instantiation like the bilinear kernel's halves the SGPR spills -- 61 -> 33 -- and changes nothing measurable:
+    // profiles/r04/cubic_split_ab.txt)
     switch (C) {
         case 1: if (masked) hipLaunchKernelGGL((eq_views_kernel<1, true, true>), grid, block, 0, s, L);
                 else hipLaunchKernelGGL((eq_views_kernel<1, true, false>), grid, block, 0, s, L); break;
