@@ -609,6 +609,21 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         ev[k].flip = 0;
         if (esize == 2) ev[k].blocked = 0;   // 16-bit samples: row-per-slot lane map only
     }
+    // LDS-staged kernel (eq_staged_kernel, north_star's "LDS-staged source texels"): bilinear RGB u8 calls in which every view is
+    // mildly minified (the presets) and the row stride keeps dword alignment from row to row.  Its wavefront tiles are 16 x 16
+    // pixels of the general (non-level) tiling.  OPT-IN (GS360_STAGE=1): bit-identical to the gather kernels and measured level
+    // with them at best -- cfg1 / cfg3 / cfg5 48.6 / 88-96 / 100.6 us per frame against 43.8 / 89.6 / 90.3 (profiles/r04/staged_ab.txt):
+    // what it saves in the texture-address path it spends in LDS reads, 48-byte row-fragment stores and the level views' lost
+    // mirror sharing.
+    bool staged = false;
+    if (const char* e = std::getenv("GS360_STAGE"))
+        staged = std::atoi(e) != 0 && C == 3 && esize == 1 && interp == GS360_INTERP_LINEAR && (src_stride & 3) == 0 && n_views > 0;
+    for (int k = 0; k < n_views && staged; ++k) staged = ev[k].blocked == 0;
+    for (int k = 0; k < n_views && staged; ++k) {
+        ev[k].blocked = 2;
+        ev[k].level = 0;
+        ev[k].tiles_y = (ev[k].out_h + kTileH - 1) / kTileH;
+    }
     // Ring size: unlimited for the row-per-slot lane map (arithmetic-bound views: cfg3 119 -> 99 -> 95 -> 93 us per frame for
     // rings of 1 / 2 / 3 / 4-8 views).  Views on the blocked lane map are memory-bound and gain nothing from shared arithmetic,
     // while a workgroup that walks six views in a row lengthens the launch's tail (cfg2 20.3 -> 22.6 us per frame): no sharing.
@@ -626,7 +641,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             int hit = -1;
             for (size_t r = 0; r < rings.size() && hit < 0; ++r) {
                 const EqView& a = ev[rings[r][0]];
-                if ((int)rings[r].size() < (b.blocked ? ring_max_blocked : ring_max) && a.sxu == b.sxu && a.syv == b.syv && a.cp == b.cp && (a.sp == b.sp || a.sp == -b.sp) &&
+                if ((int)rings[r].size() < (b.blocked == 1 ? ring_max_blocked : ring_max) && a.sxu == b.sxu && a.syv == b.syv && a.cp == b.cp && (a.sp == b.sp || a.sp == -b.sp) &&
                     a.x0f32 == b.x0f32 && a.out_w == b.out_w && a.out_h == b.out_h && a.level == b.level && a.fish == b.fish &&
                     a.blocked == b.blocked)
                     hit = (int)r;
@@ -730,6 +745,8 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
                 HIP_TRY(launch_equirect_u16(L, C, interp == GS360_INTERP_CUBIC, c->stream[slot]));
             } else if (interp == GS360_INTERP_CUBIC) {   // same tiling and symmetry reuse, 4x4 taps
                 HIP_TRY(launch_equirect_cubic(L, C, c->stream[slot]));
+            } else if (staged) {
+                HIP_TRY(launch_equirect_staged(L, c->stream[slot]));
             } else {
                 HIP_TRY(launch_equirect(L, C, c->stream[slot]));
             }

@@ -35,7 +35,8 @@ struct EqView {
     int32_t tile_base;   // first tile index of this view's RING inside one frame
     int32_t level;       // pitch == 0 exactly (sp == 0, cp == 1): horizon-symmetric fast path
     int32_t fish;        // equidistant-fisheye output (GS360_EQ_FISHEYE_OUT): sxu/syv = fov/180/size, general row path
-    int32_t blocked;     // RGB bilinear only: 4-row x 16-column gather patches instead of 64-pixel rows (strong minification)
+    int32_t blocked;     // RGB bilinear only: 1 = 4-row x 16-column gather patches instead of 64-pixel rows (strong minification);
+                         // 2 = the view is rendered by eq_staged_kernel (LDS-staged source texels; all views of the launch then are)
     int32_t pad_;
     // the two per-member scalars of a yaw ring, adjacent and 8-byte aligned: the kernel reads them with one scalar load
     int32_t x0i32;       // 32 * (floor((yaw/360 + 1/2) * W - 1/2) mod W)
@@ -185,6 +186,7 @@ struct MaskPack {
 };
 hipError_t launch_mask_pack(const MaskPack& P, hipStream_t s);
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s);
+hipError_t launch_equirect_staged(const EqLaunch& L, hipStream_t s);   // bilinear RGB u8, every view with blocked == 2 (LDS-staged 16x16 wavefront tiles)
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64

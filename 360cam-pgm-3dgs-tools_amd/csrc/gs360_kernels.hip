@@ -104,6 +104,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_EQR_WAVES
 #define GS360_EQR_WAVES 5    // bilinear RGB kernel of launches without blocked views (pipelined member loop only)
 #endif
+#ifndef GS360_EQS_WAVES
+#define GS360_EQS_WAVES 4    // LDS-staged bilinear RGB kernel: 40 KiB of LDS per workgroup = four workgroups per CU
+#endif
+#ifndef GS360_STAGE_ENABLE
+#define GS360_STAGE_ENABLE 1 // 0: every pass of eq_staged_kernel takes the gather form (A/B of the lane map alone)
+#endif
 #ifndef GS360_EQC_WAVES
 #define GS360_EQC_WAVES 4    // wavefronts per SIMD of the cubic equirect kernel (124 registers; 40 KiB of LDS = four workgroups per CU)
 #endif
@@ -1230,12 +1236,12 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
         // the pass in flight: raw tap dwords (fetch order), tap byte offsets (low two bits = misalignment), longitude coordinate
         uint32_t ra[kRowsPerWave][3], rb[kRowsPerWave][3], o0[kRowsPerWave], o1[kRowsPerWave], keep[kRowsPerWave], kbit[kRowsPerWave];
         int cx[kRowsPerWave];
-        auto issue = [&](const int4 lon, const int x0i, const bool flip) {
-            const int4 r0q = park[3 * kP], r1q = park[4 * kP];
+        // (the parked entries a pass needs are read one step ahead by the caller: an LDS round trip in front of the gathers would
+        // delay every one of them)
+        auto issue = [&](const int4 lon, const int4 r0q, const int4 r1q, const int4 mrq, const int x0i) {
             const int lo[4] = {lon.x, lon.y, lon.z, lon.w};
             const int r0[4] = {r0q.x, r0q.y, r0q.z, r0q.w}, r1[4] = {r1q.x, r1q.y, r1q.z, r1q.w};
             if constexpr (MASKED) {                       // keep bits: one aligned dword of the bit image per pixel (see eq_mask_at)
-                const int4 mrq = park[6 * kP];
                 const int mr[4] = {mrq.x, mrq.y, mrq.z, mrq.w};
 #pragma unroll
                 for (int s = 0; s < kRowsPerWave; ++s) {
@@ -1243,7 +1249,6 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                     kbit[s] = t >> 5;                     // nearest column; its low five bits pick the bit (v_bfe reads only those)
                     keep[s] = *reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(mask + (size_t)((uint32_t)mr[s] + ((t >> 8) & ~3u)), 4));
                 }
-                (void)flip;
             }
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s) {
@@ -1275,8 +1280,7 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
 #endif
             }
         };
-        auto resolve = [&](uint32_t (&pk)[kRowsPerWave], const bool flip) {
-            const int4 fyq = park[5 * kP];
+        auto resolve = [&](uint32_t (&pk)[kRowsPerWave], const bool flip, const int4 fyq) {
             const int fys[4] = {fyq.x, fyq.y, fyq.z, fyq.w};
             uint32_t px[kRowsPerWave][4];
             bool any_fix = false;
@@ -1356,7 +1360,8 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                     for (int c = 0; c < 3; ++c) row[(size_t)(uint32_t)(pos * 3 + c)] = (uint8_t)(pk[s] >> (8 * c));
             }
         };
-        issue(make_int4(sxl[0], sxl[1], sxl[2], sxl[3]), mem.x, flipstate);
+        const int4 mr0 = MASKED ? park[6 * kP] : make_int4(0, 0, 0, 0);
+        issue(make_int4(sxl[0], sxl[1], sxl[2], sxl[3]), park[3 * kP], park[4 * kP], mr0, mem.x);
         const int p_last = 2 * n_members - 1;
         int2 mem_nx = mem;
         uint8_t* dst_nx = dst;
@@ -1364,16 +1369,14 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
 #pragma unroll 1
         for (int p = 0; p < p_last; ++p) {
             const bool mirror = (p & 1) != 0;             // wave-uniform: the pass in flight is a mirrored half
-            const bool flip = flipstate;
+            const bool flip = flipstate;                  // ... and its pitch sign
             uint8_t* const dst_cur = dst;
             if (!mirror) {                                // the next member's scalars, one pass ahead of their use
                 const int mn = min((p >> 1) + 1, n_members - 1);
                 mem_nx = *reinterpret_cast<const int2*>(&L.view[k0 + mn].x0i32);
                 dst_nx = L.dst[dst_base + mn];
             }
-            __builtin_amdgcn_sched_barrier(0);
-            resolve(pk, flip);
-            __builtin_amdgcn_sched_barrier(0);
+            const int4 fyq = park[5 * kP];                // this pass's vertical phases, before a change of sign rewrites them
             if (mirror) {                                 // next: left half of the next member
                 mem = mem_nx;
                 dst = dst_nx;
@@ -1382,12 +1385,18 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                     derive_lat(park[0 * kP], flipstate);
                 }
             }
-            issue(park[(mirror ? 1 : 2) * kP], mem.x, flipstate);
+            // the next pass's entries come back from LDS while this pass is blended
+            const int4 lonq = park[(mirror ? 1 : 2) * kP], r0q = park[3 * kP], r1q = park[4 * kP];
+            const int4 mrq = MASKED ? park[6 * kP] : make_int4(0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            resolve(pk, flip, fyq);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(lonq, r0q, r1q, mrq, mem.x);
             __builtin_amdgcn_sched_barrier(0);
             store_pass(pk, dst_cur, flip, mirror);
         }
         __builtin_amdgcn_sched_barrier(0);
-        resolve(pk, flipstate);                           // the last member's mirrored half
+        resolve(pk, flipstate, park[5 * kP]);             // the last member's mirrored half
         store_pass(pk, dst, flipstate, true);
         return;
     }
@@ -1476,6 +1485,404 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(eq_
         eq_views_tile<C, CUBIC, MASKED, ES, ROWS>(L, blockIdx.x, s_wtab, s_lds);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// eq_staged_kernel -- bilinear RGB, LDS-staged source texels (launches whose views are all mildly minified: the presets)
+// ------------------------------------------------------------------------------------------------
+// Why: on the preset shapes the gather form is bound by the texture-address path, not by HBM (profiles/r04: TA busy 87 % of the cfg3
+// launch; half the gathers = -14 / -18 / -9 % time on cfg1 / cfg3 / cfg5).  A 64-lane dwordx3 gather costs ~17 cycles of that path
+// for 8 useful bytes per lane.  Here a wavefront owns a 16 x 16-pixel tile (lane = column + 16 * (row & 3), slot = row >> 2; the
+// workgroup's four wavefronts sit side by side, so the workgroup tile is the other kernels' 64 x 16) whose source footprint is a
+// compact box whatever the view's orientation.  Per pass (ring member x half) the box -- rows [iy_lo, iy_hi], bytes
+// [xa, xa + pitch) of each, xa 16-byte aligned -- is copied into the wavefront's LDS slice by LDS-DMA loads (16 contiguous bytes
+// per lane, every byte useful), and every pixel then reads its two 12-byte tap windows from LDS.  The pipeline per turn: blend
+// pass p (taps in registers) -> wait for pass p+1's box, read its taps from LDS -> start the DMA of pass p+2's box -> repack and
+// store pass p; the DMA flies under a whole blend + store.  No workgroup barrier: a wavefront only touches its own slice.
+// A pass whose box does not qualify -- it crosses the 360-degree seam, touches the first / last two rows (pole clamps), or the
+// tile's box exceeds the slice -- takes its taps with the gather form of the lean member loop instead (same registers, same
+// blend): the two paths are bit-identical by construction, both read the same source bytes.
+// Ring-shared coordinates wait in LDS as in the lean loop (latitude, left / mirrored longitude); per pitch sign one more
+// entry holds each pixel's row offset inside the box with the vertical phase in its low five bits (the pitch is a multiple of 32).
+constexpr int kStageBytes = 6144;                         // per wavefront: 24 KiB + 16 KiB of parked coordinates = four workgroups per CU
+constexpr int kStageRounds = kStageBytes / 16 / 64;       // DMA instructions per box at most
+// s_waitcnt immediates (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]); issued through the builtin so that the
+// compiler's own wait-count bookkeeping sees them (it does not look into inline assembly)
+#define GS360_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)      /* vmcnt(0) */
+#define GS360_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)    /* lgkmcnt(0) */
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_void_t;
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS360_EQS_WAVES, GS360_EQS_WAVES))) void eq_staged_kernel(const EqLaunch L) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWaves * kStageBytes / 4];
+    __shared__ __attribute__((aligned(16))) int4 s_park[(MASKED ? 5 : 4) * 64 * kWaves];
+    const int b = blockIdx.x;
+    int t = (b & 7) * L.chunk + (b >> 3);
+    if (L.xcd_group_log2 >= 0) {
+        const int q = b >> 3, g = L.xcd_group_log2;
+        t = ((((q >> g) << 3) + (b & 7)) << g) + (q & ((1 << g) - 1));
+    }
+    if (t >= L.total_tiles) return;
+    const int f = t / L.tiles_per_frame;
+    int r = t - f * L.tiles_per_frame;
+    int g = 0;
+    while (g + 1 < L.n_rings && r >= L.view[L.ring_first[g + 1]].tile_base) ++g;
+    const int k0 = L.ring_first[g], n_members = L.ring_count[g];
+    const EqView& V = L.view[k0];
+    r -= V.tile_base;
+    const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half_w = (V.out_w + 1) >> 1;
+    const int x0 = tile_x * kTileW + 16 * wave;           // this wavefront's first column (left half of the view)
+    const int n_w = min(16, half_w - x0);                 // its columns
+    if (n_w <= 0) return;                                 // (no workgroup barrier anywhere below)
+    const int col = lane & 15, rowq = lane >> 4;
+    const int xl = min(x0 + col, half_w - 1);
+    const uint8_t* __restrict__ src = L.src[f];
+    const uint8_t* __restrict__ mask = L.mask[f];
+    const int out_w = uniform_here(V.out_w), out_h = uniform_here(V.out_h);
+    const uint32_t dstride = (uint32_t)(L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3);
+    const int W = uniform_here(L.W), H = uniform_here(L.H), W32 = uniform_here(32 * L.W);
+    const uint32_t stride = (uint32_t)uniform_here((int)L.src_stride);
+    const uint32_t mstride = (uint32_t)uniform_here((int)L.mask_stride);
+    const int y0x2 = uniform_here(2 * L.y0i32);
+
+    // ---- coordinates (EQ-SPEC v1, the general per-pixel form; level views give the same bits through it) --------------------------
+    const float x = (float)(2 * xl + 1 - V.out_w) * V.sxu;
+    int ys[kRowsPerWave], sxl[kRowsPerWave], sxm[kRowsPerWave], sys[kRowsPerWave];
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) {
+        ys[s] = tile_y * kTileH + 4 * s + rowq;           // rows past the image repeat the last one (computed, never stored)
+        float yv = (float)(2 * min(ys[s], V.out_h - 1) + 1 - V.out_h) * V.syv;
+        float xr = x, bz, cy;
+        if (V.fish) {
+            const float q = __builtin_fmaf(x, x, yv * yv);
+            const float Sx = eq_poly8(kEqFishS, q), Cz = eq_poly8(kEqFishC, q);
+            xr = x * Sx;
+            yv = yv * Sx;
+            bz = __builtin_fmaf(V.sp, yv, V.cp * Cz);
+            cy = __builtin_fmaf(-V.cp, yv, V.sp * Cz);
+        } else {
+            bz = __builtin_fmaf(V.sp, yv, V.cp);
+            cy = __builtin_fmaf(-V.cp, yv, V.sp);
+        }
+        const float h = eq_sqrt(__builtin_fmaf(xr, xr, bz * bz));
+        int Kl, Kt;
+        const float rl = eq_atan2_red(xr, bz, Kl);
+        const float rt = eq_atan2_red<true>(cy, h, Kt);
+        sxl[s] = eq_lon_base(rl, Kl, L, V.x0f32);         // in [-18 W, 18 W + 32]: no wrap inside a tile
+        sxm[s] = eq_lon_base(-rl, -Kl, L, V.x0f32);
+        sys[s] = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+    }
+    // ---- the tile's box in ring-shared coordinates (1/32-texel units): raw longitude ranges of the two halves, latitude range -----
+    const int minL = wave_min_i32(min(min(sxl[0], sxl[1]), min(sxl[2], sxl[3]))), maxL = wave_max_i32(max(max(sxl[0], sxl[1]), max(sxl[2], sxl[3])));
+    const int minM = wave_min_i32(min(min(sxm[0], sxm[1]), min(sxm[2], sxm[3]))), maxM = wave_max_i32(max(max(sxm[0], sxm[1]), max(sxm[2], sxm[3])));
+    const int symin = wave_min_i32(min(min(sys[0], sys[1]), min(sys[2], sys[3]))), symax = wave_max_i32(max(max(sys[0], sys[1]), max(sys[2], sys[3])));
+    // row pitch of the box: the taps' texel span + the 12-byte read of the last one + the 16-byte alignment of xa, in 32-byte steps
+    const int tspan = (max(maxL - minL, maxM - minM) >> 5) + 1;
+    const int pitch = (3 * tspan + 27 + 31) & ~31;
+    const int ny_max = ((symax - symin) >> 5) + 3;
+    const bool tile_fits = ny_max * pitch <= kStageBytes && (stride & 3u) == 0 && GS360_STAGE_ENABLE;
+    const int nchp = pitch >> 4;                          // 16-byte chunks per box row
+    // DMA lane map, fixed for the tile: round k moves chunks 64 k + lane; chunk c = (row c / nchp, piece c % nchp)
+    uint32_t voff[kStageRounds];
+    {
+        const float inv = 1.0f / (float)nchp;
+#pragma unroll
+        for (int k = 0; k < kStageRounds; ++k) {
+            const int c = lane + 64 * k;
+            const int row = (int)(((float)c + 0.5f) * inv);          // exact for c < 2^10
+            voff[k] = (uint32_t)row * stride + (uint32_t)(c - row * nchp) * 16u;
+        }
+    }
+    uint32_t* const stage = s_stage + wave * (kStageBytes / 4);
+    int4* const park = s_park + threadIdx.x;
+    constexpr int kP = 64 * kWaves;
+#pragma unroll
+    for (int s = 0; s < kRowsPerWave; ++s) {              // members wrap with one unsigned minimum: bases into [0, 32 W)
+        sxl[s] = eq_lon_norm(sxl[s], W32);
+        sxm[s] = eq_lon_norm(sxm[s], W32);
+    }
+    park[0 * kP] = make_int4(sys[0], sys[1], sys[2], sys[3]);
+    park[1 * kP] = make_int4(sxl[0], sxl[1], sxl[2], sxl[3]);
+    park[2 * kP] = make_int4(sxm[0], sxm[1], sxm[2], sxm[3]);
+
+    // ---- per pitch sign: the box's rows, each pixel's row offset in it (| vertical phase) ----------------------------------------
+    bool flipstate = false;
+    int iy_lo = 0, ny = 0;                                // box rows [iy_lo, iy_lo + ny) for the current pitch sign
+    bool rows_ok = false;                                 // ... lie inside [0, H - 2]: no pole clamp, the last image row is never staged
+    auto derive_lat = [&](const int4 lat, const bool flip) {
+        const int lo = flip ? y0x2 - symax : symin, hi = flip ? y0x2 - symin : symax;
+        iy_lo = lo >> 5;
+        ny = (hi >> 5) + 2 - iy_lo;
+        rows_ok = tile_fits && iy_lo >= 0 && iy_lo + ny - 1 <= H - 2;
+        const int la[4] = {lat.x, lat.y, lat.z, lat.w};
+        int a[4];
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const int sy = flip ? y0x2 - la[s] : la[s];
+            a[s] = (int)__umul24((uint32_t)((sy >> 5) - iy_lo), (uint32_t)pitch) | (sy & 31);
+        }
+        park[3 * kP] = make_int4(a[0], a[1], a[2], a[3]);
+        if constexpr (MASKED) {
+            int mr[4];
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s)
+                mr[s] = (int)__umul24((uint32_t)((flip ? y0x2 - la[s] : la[s]) + 16) >> 5, mstride);
+            park[4 * kP] = make_int4(mr[0], mr[1], mr[2], mr[3]);
+        }
+    };
+    // the box of one pass along x: member offset applied to the raw range, reduced to [0, 32 W); qualifies if it does not cross the seam
+    struct Box { bool ok; int xa; uint32_t origin; };
+    auto box_of = [&](const int x0i, const bool mirror) {
+        int a = (mirror ? minM : minL) + x0i;
+        const int span = mirror ? maxM - minM : maxL - minL;
+        if (a < 0) a += W32;
+        if (a >= W32) a -= W32;
+        Box bx;
+        const int ix_lo = a >> 5, ix_hi = (a + span) >> 5;            // left taps' texels
+        bx.ok = rows_ok && ix_hi + 1 <= W - 1;
+        bx.xa = (3 * ix_lo) & ~15;
+        bx.origin = (uint32_t)iy_lo * stride + (uint32_t)bx.xa;
+        return bx;
+    };
+    auto dma = [&](const Box& bx) {                       // start the copy of a box into the wavefront's slice
+        const int total = ny * nchp;
+        const uint8_t* const base = src + (size_t)bx.origin;
+#pragma unroll
+        for (int k = 0; k < kStageRounds; ++k)
+            if (64 * k < total) {                         // wave-uniform
+                if (lane + 64 * k < total)
+                    __builtin_amdgcn_global_load_lds((global_void_t*)(base + (size_t)voff[k]), (lds_void_t*)(stage + 256 * k), 16, 0, 0);
+            }
+    };
+
+    int2 mem = *reinterpret_cast<const int2*>(&L.view[k0].x0i32);
+    const int dst_base = uniform_here(f * L.n_views + k0);
+    uint8_t* dst = L.dst[dst_base];
+    flipstate = mem.y != 0;
+    derive_lat(make_int4(sys[0], sys[1], sys[2], sys[3]), flipstate);
+    const bool centre_dup = (V.out_w & 1) && (x0 + n_w == half_w);
+    const bool has_mirror = n_w > (centre_dup ? 1 : 0);
+    const int c0_m = out_w - x0 - n_w;                    // first column of the mirrored segment
+    const int fix_from = uniform_here(32 * (W - 4));
+
+    // the pass in flight: raw tap dwords, tap byte offsets (low two bits = misalignment), longitude coordinate, vertical phase
+    uint32_t ra[kRowsPerWave][3], rb[kRowsPerWave][3], o0[kRowsPerWave], o1[kRowsPerWave], keep[kRowsPerWave], kbit[kRowsPerWave];
+    int cx[kRowsPerWave], fyv[kRowsPerWave];
+    bool taps_staged = false;                             // how the pass in flight got its taps (wave-uniform)
+    // taps of a pass from the staged box (LDS) ...
+    auto taps_from_lds = [&](const int4 lon, const int x0i, const Box& bx) {
+        const int4 aq = park[3 * kP];
+        const int lo[4] = {lon.x, lon.y, lon.z, lon.w}, a[4] = {aq.x, aq.y, aq.z, aq.w};
+        const uint8_t* const sb = reinterpret_cast<const uint8_t*>(stage);
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            cx[s] = eq_lon_member(lo[s], x0i, W32);
+            fyv[s] = a[s] & 31;
+            o0[s] = (uint32_t)(a[s] & ~31) + (uint32_t)(3 * (cx[s] >> 5) - bx.xa);
+            o1[s] = o0[s] + (uint32_t)pitch;
+            const uint32_t* qa = reinterpret_cast<const uint32_t*>(sb + (o0[s] & ~3u));
+            const uint32_t* qb = reinterpret_cast<const uint32_t*>(sb + (o1[s] & ~3u));
+            ra[s][0] = qa[0]; ra[s][1] = qa[1]; ra[s][2] = qa[2];
+            rb[s][0] = qb[0]; rb[s][1] = qb[1]; rb[s][2] = qb[2];
+        }
+    };
+    // ... or gathered from memory (the lean member loop's fetch, row offsets from scratch: rare)
+    auto taps_from_memory = [&](const int4 lon, const int x0i, const bool flip) {
+        const int4 lat = park[0 * kP];
+        const int lo[4] = {lon.x, lon.y, lon.z, lon.w}, la[4] = {lat.x, lat.y, lat.z, lat.w};
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const int sy = flip ? y0x2 - la[s] : la[s];
+            const int iy = sy >> 5;
+            cx[s] = eq_lon_member(lo[s], x0i, W32);
+            fyv[s] = sy & 31;
+            const uint32_t cb = (uint32_t)min(cx[s] >> 5, W - 5) * 3u;
+            o0[s] = __umul24((uint32_t)max(iy, 0), stride) + cb;
+            o1[s] = __umul24((uint32_t)min(iy + 1, H - 1), stride) + cb;
+            const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o0[s] & ~3u), 4));
+            const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o1[s] & ~3u), 4));
+            ra[s][0] = qa[0]; ra[s][1] = qa[1]; ra[s][2] = qa[2];
+            rb[s][0] = qb[0]; rb[s][1] = qb[1]; rb[s][2] = qb[2];
+        }
+    };
+    auto mask_fetch = [&](const int4 lon, const int x0i) {
+        if constexpr (MASKED) {
+            const int4 mrq = park[4 * kP];
+            const int lo[4] = {lon.x, lon.y, lon.z, lon.w}, mr[4] = {mrq.x, mrq.y, mrq.z, mrq.w};
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                const uint32_t tt = (uint32_t)eq_lon_member(lo[s], x0i, W32) + 16u;
+                kbit[s] = tt >> 5;
+                keep[s] = *reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(mask + (size_t)((uint32_t)mr[s] + ((tt >> 8) & ~3u)), 4));
+            }
+        }
+    };
+    auto resolve = [&](uint32_t (&pk)[kRowsPerWave], const bool flip) {
+        uint32_t px[kRowsPerWave][4];
+        bool any_fix = false;
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            EqTaps<3> tp;
+            tp.t0.x = __builtin_amdgcn_alignbyte(ra[s][1], ra[s][0], GS360_AB(o0[s]));
+            tp.t0.y = __builtin_amdgcn_alignbyte(ra[s][2], ra[s][1], GS360_AB(o0[s]));
+            tp.t1.x = __builtin_amdgcn_alignbyte(rb[s][1], rb[s][0], GS360_AB(o1[s]));
+            tp.t1.y = __builtin_amdgcn_alignbyte(rb[s][2], rb[s][1], GS360_AB(o1[s]));
+            eq_blend_f<3>(tp, cx[s] & 31, fyv[s], px[s]);
+            any_fix |= cx[s] >= fix_from;
+        }
+        if (!taps_staged && any_lane(any_fix)) {          // a staged box never reaches the seam columns
+            const int4 lat = park[0 * kP];
+            const int la[4] = {lat.x, lat.y, lat.z, lat.w};
+            EqSrc S;
+            S.W = W; S.H = H; S.src_stride = (int64_t)stride; S.mask_stride = 0; S.stride4 = false;
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s)
+                if (cx[s] >= fix_from) eq_sample_slow<3>(src, S.src_stride, S.W, S.H, cx[s], flip ? y0x2 - la[s] : la[s], px[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            pk[s] = px[s][0] | (px[s][1] << 8) | (px[s][2] << 16);
+            if constexpr (MASKED) pk[s] &= (uint32_t)__builtin_amdgcn_sbfe((int)keep[s], kbit[s] & 31u, 1u);
+        }
+    };
+    // store of one pass: each 16-lane group holds 16 pixels of one row = 12 dwords; lanes 0..11 of the group re-slice and write them
+    const int dsel = col < 12 ? col : 0;                                   // dword of the row fragment this lane writes
+    const int a16 = (4 * dsel) / 3, sh16 = (4 * dsel) - 3 * a16;          // first contributing pixel, byte offset in it
+    const uint32_t sel16 = sh16 == 0 ? 0x04020100u : (sh16 == 1 ? 0x05040201u : 0x06050402u);
+    auto store_pass = [&](const uint32_t (&pk)[kRowsPerWave], uint8_t* const d, const bool flip, const bool mirror) {
+        if (mirror && !has_mirror) return;
+        const int c0 = mirror ? c0_m : x0;
+        const bool aligned = ((dstride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(d) & 3) == 0) && (((c0 * 3) & 3) == 0) &&
+                             !(mirror && centre_dup) && ((3 * n_w) & 3) == 0;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                      // lane-derived constants are made here, once per pass (see the lean loop)
+        const int grp = ln & ~15, cc = ln & 15;
+        if (aligned) {
+            // pixel at position q of the row fragment sits in lane grp + q (left half) or grp + n_w - 1 - q (mirrored half)
+            const int qa = a16, qb = a16 + 1;
+            const int la4 = 4 * (grp + (mirror ? n_w - 1 - qa : qa)), lb4 = 4 * (grp + (mirror ? n_w - 1 - qb : qb));
+            uint32_t dw[kRowsPerWave];
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(la4 & 252, (int)pk[s]);
+                const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)pk[s]);
+                dw[s] = __builtin_amdgcn_perm(pb, pa, sel16);
+            }
+            const int full = (3 * n_w) >> 2;
+#pragma unroll
+            for (int s = 0; s < kRowsPerWave; ++s) {
+                const int y = flip ? out_h - 1 - ys[s] : ys[s];
+                if (cc < full && ys[s] < out_h && !((GS360_PROBE & 2) && dw[s] != 0x12345678u))
+                    *reinterpret_cast<uint32_t*>(d + (size_t)(__umul24((uint32_t)y, dstride) + (uint32_t)(c0 * 3 + 4 * cc))) = dw[s];
+            }
+            return;
+        }
+        const int pos = mirror ? n_w - 1 - cc : cc;
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const int y = flip ? out_h - 1 - ys[s] : ys[s];
+            if (cc < n_w && ys[s] < out_h && !(mirror && centre_dup && pos == 0)) {
+                uint8_t* q = d + (size_t)(__umul24((uint32_t)y, dstride) + (uint32_t)((c0 + pos) * 3));
+                q[0] = (uint8_t)pk[s]; q[1] = (uint8_t)(pk[s] >> 8); q[2] = (uint8_t)(pk[s] >> 16);
+            }
+        }
+    };
+
+    // ---- the passes: member 0 left, member 0 mirrored, member 1 left, ... ---------------------------------------------------------
+    const int p_last = 2 * n_members - 1;
+    // prologue: pass 0's taps into registers, pass 1's box on its way
+    Box bx = box_of(mem.x, false);
+    if (bx.ok) {
+        dma(bx);
+        GS360_WAIT_VM0();
+        taps_from_lds(make_int4(sxl[0], sxl[1], sxl[2], sxl[3]), mem.x, bx);
+        taps_staged = true;
+    } else {
+        taps_from_memory(make_int4(sxl[0], sxl[1], sxl[2], sxl[3]), mem.x, flipstate);
+        GS360_WAIT_VM0();                                 // (see the loop)
+        taps_staged = false;
+    }
+    mask_fetch(make_int4(sxl[0], sxl[1], sxl[2], sxl[3]), mem.x);
+    Box bx_next = box_of(mem.x, true);                    // pass 1: the mirrored half of member 0, same rows
+    GS360_WAIT_LGKM0();    // the slice has been read: it may be overwritten
+    __builtin_amdgcn_sched_barrier(0);
+    if (p_last >= 1 && bx_next.ok) dma(bx_next);
+    int2 mem_nx = mem;
+    uint8_t* dst_nx = dst;
+    uint32_t pk[kRowsPerWave];
+    bool pflip = flipstate;                               // pitch sign of the pass whose taps are in registers
+#pragma unroll 1
+    for (int p = 0; p < p_last; ++p) {
+        const bool mirror = (p & 1) != 0;                 // the pass whose taps are in registers is a mirrored half
+        const bool flip = pflip;
+        uint8_t* const dst_cur = dst;
+        if (!mirror) {                                    // the next member's scalars, ahead of their use
+            const int mn = min((p >> 1) + 1, n_members - 1);
+            mem_nx = *reinterpret_cast<const int2*>(&L.view[k0 + mn].x0i32);
+            dst_nx = L.dst[dst_base + mn];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        resolve(pk, flip);
+        __builtin_amdgcn_sched_barrier(0);
+        // pass p + 1: its box was started a turn ago (bx_next); take its taps, then start pass p + 2's box
+        const Box bcur = bx_next;
+        if (mirror) {                                     // p + 1 = left half of the next member
+            mem = mem_nx;
+            dst = dst_nx;
+        }
+        const int4 lon = park[(mirror ? 1 : 2) * kP];
+        if (bcur.ok) {
+            GS360_WAIT_VM0();
+            taps_from_lds(lon, mem.x, bcur);
+            taps_staged = true;
+        } else {
+            // the rare gather form waits for its reads here: left in flight they would sit in front of the next box's DMA in the
+            // memory queue, and the blend at the top of the next turn -- which cannot know which form filled its registers -- would
+            // have to wait for everything, the DMA included
+            taps_from_memory(lon, mem.x, flipstate);
+            GS360_WAIT_VM0();
+            taps_staged = false;
+        }
+        mask_fetch(lon, mem.x);
+        pflip = flipstate;                                // (the entries derived for pass p + 1's pitch sign are still the current ones)
+        // pass p + 2 (if any): mirrored half of the same member, or the left half of the member after it (whose pitch sign may differ:
+        // the latitude entry is re-derived, which needs pass p + 1's taps out of LDS first -- they are, and A was read above)
+        if (p + 2 <= p_last) {
+            if (mirror) {
+                bx_next = box_of(mem.x, true);
+            } else {
+                if ((mem_nx.y != 0) != flipstate) {
+                    // pass p + 1 (mirrored half of the current member) already has its taps and phases in registers
+                    flipstate = !flipstate;
+                    derive_lat(park[0 * kP], flipstate);
+                }
+                bx_next = box_of(mem_nx.x, false);
+            }
+            GS360_WAIT_LGKM0();
+            __builtin_amdgcn_sched_barrier(0);
+            if (bx_next.ok) dma(bx_next);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_pass(pk, dst_cur, flip, mirror);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    resolve(pk, pflip);
+    store_pass(pk, dst, pflip, true);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // cv2.remap semantics (shared by the table kernel and the fused fisheye kernel)
@@ -2144,6 +2551,13 @@ static unsigned eq_grid_blocks(const EqLaunch& L) {
     if (L.xcd_group_log2 < 0) return (unsigned)(L.chunk * 8);
     const int per = 8 << L.xcd_group_log2;                 // tiles per round over the XCDs
     return (unsigned)((L.total_tiles + per - 1) / per * per);
+}
+
+hipError_t launch_equirect_staged(const EqLaunch& L, hipStream_t s) {
+    dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
+    if (L.mask[0] != nullptr) hipLaunchKernelGGL((eq_staged_kernel<true>), grid, block, 0, s, L);
+    else hipLaunchKernelGGL((eq_staged_kernel<false>), grid, block, 0, s, L);
+    return hipGetLastError();
 }
 
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {

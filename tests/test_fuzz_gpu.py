@@ -9,14 +9,17 @@ from conftest import ROOT
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanemap,ring", [("", ""), ("rows", ""), ("blocked", ""), ("", "1"), ("blocked", "3")])
+@pytest.mark.parametrize("lanemap,ring", [("", ""), ("rows", ""), ("blocked", ""), ("", "1"), ("blocked", "3"), ("staged", ""), ("staged", "2")])
 def test_fuzz_parity_short(lanemap, ring):
     """lanemap forces one lane map of the equirect kernel, ring caps the members of a yaw ring (1 = no coordinate sharing)"""
     import os
     env = dict(os.environ)
     env.pop("GS360_LANEMAP", None)
     env.pop("GS360_RING", None)
-    if lanemap:
+    env.pop("GS360_STAGE", None)
+    if lanemap == "staged":                            # the opt-in LDS-staged kernel on every call that qualifies
+        env["GS360_LANEMAP"], env["GS360_STAGE"] = "rows", "1"
+    elif lanemap:
         env["GS360_LANEMAP"] = lanemap
     if ring:
         env["GS360_RING"] = ring

@@ -47,9 +47,14 @@ def _disk_mask(H, W, seed, n=40):
     return m
 
 
-@pytest.mark.parametrize("interp", [1, 2])
-def test_cfg5_full_size_fisheyelike_masked_10x2048(ctx, orc, interp):
-    """BASELINE configs[4] as specified: 8K -> fisheyelike 10 x 2048^2 with the keep-mask multiply fused in the launch."""
+@pytest.mark.parametrize("interp", [1, 2, "staged"])
+def test_cfg5_full_size_fisheyelike_masked_10x2048(ctx, orc, interp, monkeypatch):
+    """BASELINE configs[4] as specified: 8K -> fisheyelike 10 x 2048^2 with the keep-mask multiply fused in the launch.
+    "staged" = bilinear through the opt-in LDS-staged kernel (GS360_STAGE=1)."""
+    monkeypatch.delenv("GS360_STAGE", raising=False)
+    if interp == "staged":
+        monkeypatch.setenv("GS360_STAGE", "1")
+        interp = 1
     H, W = 3840, 7680
     src = rand_image(H, W, seed=102)
     mask = _disk_mask(H, W, 103)
