@@ -29,6 +29,7 @@ _SLOTS_PER_DEVICE = 4
 _LINGER_S = float(os.environ.get("GS360_BATCH_LINGER_MS", "3")) * 1e-3
 _PREFETCH_FRAMES = int(os.environ.get("GS360_PREFETCH_FRAMES", "8"))      # still images decoded ahead of their view jobs (0 = off)
 _PREFETCH_THREADS = int(os.environ.get("GS360_PREFETCH_THREADS", "4"))    # decoder threads of the read-ahead
+_RECENT_SOURCES = 512                   # sources whose device is remembered after their record is gone (bounded)
 
 
 class _Batch:
@@ -122,6 +123,8 @@ class Engine:
         self._sources = {}                        # str(source path) -> _Source
         self._announce_lock = threading.Lock()    # guards _sources, _inflight, the prefetch queue
         self._inflight = [0] * len(self.states)   # sources currently held per device (device_for balances on THIS, not on history)
+        self._recent = collections.OrderedDict()  # source -> device of its last record, the newest _RECENT_SOURCES of them
+        self._last_dev = len(self.states) - 1     # round-robin tie-break starts at device 0
         self._prefetch_queue = collections.deque()   # announced still-image sources not yet decoded ahead
         self._prefetch_threads = []
         self._prefetch_permits = threading.Semaphore(_PREFETCH_FRAMES)
@@ -147,10 +150,20 @@ class Engine:
 
     # -- sharding ---------------------------------------------------------------------------------
     def _source(self, key):
-        """(announce lock held) the record of `key`, created on the least-loaded device"""
+        """(announce lock held) the record of `key`.  A new source goes where an earlier record of it lived (a bounded memory of
+        recent sources: the views of a frame that a serial caller hands over one by one stay on one device), else to the device
+        with the fewest sources in flight, ties broken round-robin from the last choice."""
         rec = self._sources.get(key)
         if rec is None:
-            dev = min(range(len(self.states)), key=lambda d: (self._inflight[d], d))
+            dev = self._recent.get(key)
+            if dev is None or dev >= len(self.states):
+                n = len(self.states)
+                dev = min(range(n), key=lambda d: (self._inflight[d], (d - self._last_dev - 1) % n))
+                self._last_dev = dev
+            self._recent[key] = dev
+            self._recent.move_to_end(key)
+            while len(self._recent) > _RECENT_SOURCES:
+                self._recent.popitem(last=False)
             rec = self._sources[key] = _Source(dev)
             self._inflight[dev] += 1
         return rec
@@ -186,6 +199,7 @@ class Engine:
     def bookkeeping(self):
         """sizes of the per-source tables (tests: a long-lived engine must come back to empty)"""
         with self._announce_lock:
+            assert len(self._recent) <= _RECENT_SOURCES
             return {"sources": len(self._sources), "inflight": list(self._inflight), "queue": len(self._prefetch_queue)}
 
     # -- frame residency --------------------------------------------------------------------------

@@ -7,7 +7,8 @@ that size are served from the heaps and recycled instead of being mapped and unm
 dynamic threshold; left at its 128 KiB start value every one of these buffers would be an mmap / munmap pair and the first two
 settings would not touch them).  Blocks above 32 MiB (a decoded 5.7K panorama is 50 MB) stay mmap'ed.  Measured on the MI355X box
 (256 host threads under a 16-CPU quota, `scripts/bench_cli_e2e.py --frames 48 --jobs 32`): profiles/r03/cli_e2e_malloc.txt (first
-two settings) and profiles/r04/cli_e2e_malloc_mmap.txt (all three).
+two settings: 34-36 -> 40-47 frames/s) and profiles/r04/cli_e2e_malloc_mmap.txt (all three: 45-47 frames/s with or without the third --
+the run is bound by the codecs under the CPU quota by then).
 
 Process-wide and permanent (a process that has called it never trims again and keeps a 256 MB top pad per heap), so it is the
 CLIs' `main()` that calls it, not the engine: a host application that imports the engine keeps its own allocator behaviour.

@@ -270,9 +270,20 @@ def test_three_runs_leave_the_engine_empty_and_level(monkeypatch, tmp_path):
             assert not t.is_alive()
         assert len(used) == len(jobs)
         assert eng.bookkeeping() == {"sources": 0, "inflight": [0, 0, 0], "queue": 0}, cycle
-    # a source nobody announced (the GUI path calls run_one without a job list) is remembered only while a job works on it
+    # a source nobody announced (the GUI path calls run_one without a job list) is remembered only while a job works on it ...
     eng.run_job(type("J", (), {"src": tmp_path / "loose.png", "dst": "x", "jpeg_q": 2, "is_still_image": True})())
     assert eng.bookkeeping()["sources"] == 0
+    # ... but serial un-announced callers still get level devices, and the views of one frame one device (bounded memory of recent sources)
+    used.clear()
+    for k in range(9):
+        for _view in range(3):
+            eng.run_job(type("J", (), {"src": tmp_path / "serial" / f"f{k}.png", "dst": "x", "jpeg_q": 2, "is_still_image": True})())
+    assert [used[3 * k] for k in range(9)] == [used[3 * k + 2] for k in range(9)]          # a frame's views together
+    assert sorted(collections.Counter(used[::3]).values()) == [3, 3, 3]
+    for k in range(2000):                                                                 # the memory itself is bounded
+        eng.device_for(tmp_path / "many" / f"{k}.png")
+        eng.retire()
+    assert len(eng._recent) <= engine._RECENT_SOURCES and eng.bookkeeping()["sources"] == 0
 
 
 def test_malloc_tuning_is_idempotent_and_switchable(monkeypatch):
