@@ -18,7 +18,7 @@
 // which touches about half the cache lines where a view row bends across many source rows; results are then
 // transposed through LDS into row-segment stores (store_patch_rgb).  Tiles are numbered row-major per
 // view and handed to XCDs in contiguous chunks (block b runs on XCD b % 8) so that neighbouring tiles --
-// which share source cache lines -- hit the same per-XCD L2.  DESIGN.md section 5 has the measurements behind
+// which share source cache lines -- hit the same per-XCD L2.  DESIGN.md section 5 and profiles/HISTORY.md have the measurements behind
 // each of these choices.
 //
 // Compile with -ffp-contract=off: the float32 specs are defined operation by operation and must match the
@@ -429,7 +429,7 @@ __device__ __forceinline__ EqCubicTaps cubic_issue_rgb(const uint8_t* __restrict
         t.sh = o;
         const uint32_t cb = col - o;
         // Common case (wave-uniform test): no window of the wavefront touches the first or the last image row -- the four rows
-        // are off0 + k * stride (the kernel is arithmetic-bound, DESIGN.md section 5.4).
+        // are off0 + k * stride (the kernel is arithmetic-bound, DESIGN.md section 5.3).
         if (!any_lane(iy < 1 || iy > H - 3)) {
             offs[0] = __umul24((uint32_t)(iy - 1), stride) + cb;
 #pragma unroll

@@ -57,7 +57,7 @@ HFOV = 112.61986494804043          # fov_from_focal_mm(12, 36)  (reference PC:77
 #   sum_v U_v = 14,325,324 texels * 3 B = 42,975,972 B   (counted by the oracle; tests/test_oracle_equirect.py)
 ALGO_BYTES_PER_FRAME = 11_520_000 + 14_325_324 * 3
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# The bound a gather that moves whole 128-B lines can reach: every view has to pull each distinct
+# The bound a gather that moves whole 128-B lines can reach (profiles/HISTORY.md): every view has to pull each distinct
 # line its taps touch at least once -- 718,080 lines per frame summed over the six views (119,680 each; counted from the
 # oracle's map, tests/test_oracle_equirect.py) -- plus the stores, at the 6.29 TB/s the HBM sustains for streaming copies.
 LINE_BYTES_PER_FRAME = 718_080 * 128 + 11_520_000
