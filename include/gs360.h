@@ -92,7 +92,8 @@ int gs360_device_info(gs360_ctx *ctx, char *name, size_t name_len, int32_t *cu_c
 /* ---- memory (device buffers carry 64 B of readable slack after the requested size) ---------
  * Images handed to the hot-path entry points must come with that slack (the aligned 12- / 16-byte tap reads of the last
  * pixels of the last row run past the image) and, for 3-channel images, a 4-byte aligned base pointer; equirect sources
- * are at least 8 texels wide, H * stride < 2^32 and stride < 2^24 (32-bit tap offsets).  gs360_dev_alloc satisfies
+ * are at least 8 texels wide and less than 2^18 rows tall (the kernels form latitudes with 24-bit multiply-adds), H * stride < 2^32
+ * and stride < 2^24 (32-bit tap offsets).  gs360_dev_alloc satisfies
  * the first two; the size limits are checked and reported as GS360_ERR_ARG / GS360_ERR_UNSUPPORTED. */
 int gs360_dev_alloc(gs360_ctx *ctx, size_t bytes, void **dptr);
 int gs360_dev_free(gs360_ctx *ctx, void *dptr);
@@ -138,6 +139,9 @@ int gs360_equirect_views_u8(gs360_ctx *ctx, const void *const *src_frames, int n
  * reference cli_tools/gs360_SegmentationMaskTool.py:765-774).  The mask is sampled NEAREST at the same source
  * coordinate (texel ((sx+16)>>5 mod W, clamp((sy+16)>>5)) of EQ-SPEC v1) and the output pixel is written as 0 on all
  * channels where the mask value is < 128.  mask_stride in bytes (0 = W).
+ * Only that comparison is ever used, so every call first thresholds its masks into bit images (context scratch of the slot, one
+ * streaming pass over the mask bytes on the slot's stream, 6 us per 8K mask) and the kernels sample those; the masks themselves are
+ * only read, and may be reused or released as soon as the call's stream work is complete.
  */
 int gs360_equirect_views_masked_u8(gs360_ctx *ctx, const void *const *src_frames, const void *const *mask_frames,
                                    int n_frames, int W, int H, int C, size_t src_stride, size_t mask_stride,
