@@ -609,20 +609,34 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         ev[k].flip = 0;
         if (esize == 2) ev[k].blocked = 0;   // 16-bit samples: row-per-slot lane map only
     }
-    // LDS-staged kernel (eq_staged_kernel, north_star's "LDS-staged source texels"): bilinear RGB u8 calls in which every view is
-    // mildly minified (the presets) and the row stride keeps dword alignment from row to row.  Its wavefront tiles are 16 x 16
-    // pixels of the general (non-level) tiling.  OPT-IN (GS360_STAGE=1): bit-identical to the gather kernels and measured level
-    // with them at best -- cfg1 / cfg3 / cfg5 48.6 / 88-96 / 100.6 us per frame against 43.8 / 89.6 / 90.3 (profiles/r04/staged_ab.txt):
-    // what it saves in the texture-address path it spends in LDS reads, 48-byte row-fragment stores and the level views' lost
-    // mirror sharing.
-    bool staged = false;
-    if (const char* e = std::getenv("GS360_STAGE"))
-        staged = std::atoi(e) != 0 && C == 3 && esize == 1 && interp == GS360_INTERP_LINEAR && (src_stride & 3) == 0 && n_views > 0;
-    for (int k = 0; k < n_views && staged; ++k) staged = ev[k].blocked == 0;
-    for (int k = 0; k < n_views && staged; ++k) {
-        ev[k].blocked = 2;
-        ev[k].level = 0;
-        ev[k].tiles_y = (ev[k].out_h + kTileH - 1) / kTileH;
+    // LDS-staged kernel (eq_staged_kernel, north_star's "LDS-staged source texels"): bilinear RGB u8 views whose row stride keeps dword
+    // alignment from row to row; its wavefront tiles are 16 x 16 pixels of the general (non-level) tiling.  When it is taken
+    // (steady-state clocks, profiles/r04/stage_sweep.txt, settle_ab.txt, stage_auto_ab.txt): the gather form of PITCHED views that step
+    // >= 1.75 source texels per output pixel at their centre is bound by the texture-address path, and staging wins there (8K ->
+    // full360coverage: -2 % at step 1.75, -8 % at 1.96, -14 % at 2.6); level views keep the gather kernels' horizon sharing (an all-level
+    // ring: level at step 2, -6 % at 2.6; cfg1 36.6 vs 44.3 us staged) and below 1.75 the arithmetic decides (cfg5 75.2 vs 88.7).
+    // Splitting a call into a staged and a gather launch loses more in launch tails than it wins (cfg3 95.8 us against 84.4 all
+    // gathered and 78.4 all staged), so the CALL is staged as a whole when such views write most of its pixels.
+    // GS360_STAGE=0: never; GS360_STAGE=1: every call that can (tests, probes).
+    {
+        int mode = -1;                                    // auto
+        if (const char* e = std::getenv("GS360_STAGE")) mode = std::atoi(e) != 0 ? 1 : 0;
+        bool can = mode != 0 && C == 3 && esize == 1 && interp == GS360_INTERP_LINEAR && (src_stride & 3) == 0;
+        double px_all = 0.0, px_win = 0.0;
+        for (int k = 0; k < n_views && can; ++k) {
+            can = ev[k].blocked == 0;
+            const double hf = clampd(views[k].hfov_deg, 1e-3, 179.9) * kPi / 180.0;
+            const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[k].width;
+            const double px = (double)views[k].width * (double)views[k].height;
+            px_all += px;
+            if (!ev[k].level && !ev[k].fish && step >= 1.75) px_win += px;
+        }
+        if (can && (mode == 1 || 2.0 * px_win > px_all))
+            for (int k = 0; k < n_views; ++k) {
+                ev[k].blocked = 2;
+                ev[k].level = 0;
+                ev[k].tiles_y = (ev[k].out_h + kTileH - 1) / kTileH;
+            }
     }
     // Ring size: unlimited for the row-per-slot lane map (arithmetic-bound views: cfg3 119 -> 99 -> 95 -> 93 us per frame for
     // rings of 1 / 2 / 3 / 4-8 views).  Views on the blocked lane map are memory-bound and gain nothing from shared arithmetic,
@@ -668,11 +682,14 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // members with the ring's own pitch sign first, the upside-down ones behind them: the kernel's member loop re-derives its
     // latitude-dependent row offsets once per change of sign (results do not depend on the order)
     for (auto& r : rings) std::stable_partition(r.begin(), r.end(), [&](int k) { return ev[k].flip == 0; });
+    std::stable_partition(rings.begin(), rings.end(), [&](const std::vector<int>& r) { return ev[r[0]].blocked != 2; });   // gather rings, then staged ones
     size_t r0 = 0;
     while (r0 < rings.size()) {
         size_t r1 = r0;
         int nv = 0;
-        while (r1 < rings.size() && nv + (int)rings[r1].size() <= GS360_MAX_VIEWS) nv += (int)rings[r1++].size();
+        const bool staged = ev[rings[r0][0]].blocked == 2;          // staged rings and gather rings never share a launch
+        while (r1 < rings.size() && nv + (int)rings[r1].size() <= GS360_MAX_VIEWS && (ev[rings[r1][0]].blocked == 2) == staged)
+            nv += (int)rings[r1++].size();
         for (int f0 = 0; f0 < n_frames; f0 += GS360_MAX_FRAMES) {
             int nf = n_frames - f0 < GS360_MAX_FRAMES ? n_frames - f0 : GS360_MAX_FRAMES;
             EqLaunch L;

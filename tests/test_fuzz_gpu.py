@@ -17,7 +17,7 @@ def test_fuzz_parity_short(lanemap, ring):
     env.pop("GS360_LANEMAP", None)
     env.pop("GS360_RING", None)
     env.pop("GS360_STAGE", None)
-    if lanemap == "staged":                            # the opt-in LDS-staged kernel on every call that qualifies
+    if lanemap == "staged":                            # the LDS-staged kernel forced on every call that can take it (auto: only calls dominated by pitched, >= 1.75-texel-step views)
         env["GS360_LANEMAP"], env["GS360_STAGE"] = "rows", "1"
     elif lanemap:
         env["GS360_LANEMAP"] = lanemap

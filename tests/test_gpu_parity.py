@@ -30,8 +30,8 @@ def _assert_same(got, want, what):
 @pytest.fixture(params=["rows", "blocked", "auto", "staged"])
 def lanemap(request, monkeypatch):
     """the equirect kernel has two lane maps (64-pixel rows / 4x16 patches) chosen per view on the host by the
-    minification; GS360_LANEMAP forces one so that every shape below is checked under both.  "staged" = the opt-in LDS-staged
-    kernel (GS360_STAGE=1; 16 x 16 wavefront tiles, boxes copied into LDS, gather form where a box does not qualify)"""
+    minification; GS360_LANEMAP forces one so that every shape below is checked under both.  "staged" = the LDS-staged
+    kernel forced on (GS360_STAGE=1; 16 x 16 wavefront tiles, boxes copied into LDS, gather form where a box does not qualify)"""
     monkeypatch.delenv("GS360_STAGE", raising=False)
     if request.param == "staged":
         monkeypatch.setenv("GS360_LANEMAP", "rows")

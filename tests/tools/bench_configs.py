@@ -36,8 +36,10 @@ def synth(h, w, k=0, c=3):
     return img
 
 
-SETTLE_MS = 0.0      # secondary_rows(): untimed launches until the device has been busy this long (its clocks ramp over ~100 ms of load;
-                     # bench.py runs these rows right after a CPU-bound phase)
+# untimed launches before every timed loop until the device has been busy this long: its clocks ramp over ~100 ms of load, and a
+# 5-launch warm-up (2 ms) in front of a 10-20 ms timed loop measures the ramp (cfg5: 89 us per frame against 74 in steady state).
+# bench.py's headline has done this since round 3 (--settle-ms); since round 4 every row here does (GS360_BENCH_SETTLE_MS, 0 = off).
+SETTLE_MS = float(os.environ.get("GS360_BENCH_SETTLE_MS", "100"))
 
 
 def time_steps(ctx, call, steps, warmup=5):
@@ -261,8 +263,6 @@ def cfg4_rows(ctx, steps, interps=((1, "linear"), (2, "cubic"))):
 def secondary_rows(ctx, steps=20):
     """The other BASELINE configs in compact form for bench.py's `secondary` array: same timing method as the rows above (HIP events
     around `steps` batched launches of 4 resident frames / one lens pair), one view of each checked against the oracle."""
-    global SETTLE_MS
-    SETTLE_MS = 80.0
     full360 = [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360]
     fishlike = [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE]
     plan = [
