@@ -1593,7 +1593,9 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
     const int tspan = (max(maxL - minL, maxM - minM) >> 5) + 1;
     const int pitch = (3 * tspan + 27 + 31) & ~31;
     const int ny_max = ((symax - symin) >> 5) + 3;
-    const bool tile_fits = ny_max * pitch <= kStageBytes && (stride & 3u) == 0 && GS360_STAGE_ENABLE;
+    // (pitch <= stride: a box row that starts inside row y ends inside row y + 1 at the latest, and the last row a box may hold is
+    // H - 2 -- the copy never leaves the frame)
+    const bool tile_fits = ny_max * pitch <= kStageBytes && (stride & 3u) == 0 && (uint32_t)pitch <= stride && GS360_STAGE_ENABLE;
     const int nchp = pitch >> 4;                          // 16-byte chunks per box row
     // DMA lane map, fixed for the tile: round k moves chunks 64 k + lane; chunk c = (row c / nchp, piece c % nchp)
     uint32_t voff[kStageRounds];

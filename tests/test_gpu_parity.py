@@ -81,6 +81,16 @@ def test_equirect_tallest_source_the_kernels_take(ctx, orc):
     assert exc.value.code == -4
 
 
+@pytest.mark.parametrize("W,H", [(8, 4), (8, 64), (12, 7), (20, 10), (44, 22)])
+def test_equirect_sources_narrower_than_a_staged_box_row(ctx, orc, W, H, lanemap):
+    """sources whose row (24-132 bytes) is shorter than the 32-byte-granular pitch of a staged box: the staged kernel must fall back
+    to the gather form rather than copy past the frame; exact-size device buffers so an overrun would fault or mis-sample"""
+    src = rand_image(H, W, seed=W * 100 + H)
+    specs = [(0, 0, 90, 90, 48, 48), (30, 35, 8, 8, 33, 17), (-100, -60, 2, 2, 16, 16), (179, 0, 1, 1, 64, 64), (10, 80, 40, 40, 16, 32)]
+    got, want = _eq_both(ctx, orc, src, specs)
+    _assert_same(got, want, f"{W}x{H} source")
+
+
 @pytest.mark.parametrize("channels", [1, 4])
 def test_equirect_channels(ctx, orc, channels):
     src = rand_image(256, 512, c=channels, seed=11)
