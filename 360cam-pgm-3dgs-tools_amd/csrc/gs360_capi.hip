@@ -951,8 +951,9 @@ struct gs360_color_plan {
     int device = 0;
     int lut_size = 0;
     int fixups = 0;
-    void* d_rtab = nullptr;     // float3[n*n*256], see gs360_color.hip
+    void* d_rtab = nullptr;     // cell-major red-interpolated LUT, see gs360_color.hip (released once the cube is built)
     float* d_tables = nullptr;  // level positions, thresholds, bin levels
+    void* d_cube = nullptr;     // uint32[2^24]: the stage evaluated for every 8-bit pixel (NULL with GS360_COLOR_CUBE=0)
 };
 
 int gs360_color_plan_create(gs360_ctx* c, const float* lut, int lut_size, const float* level_pos,
@@ -986,13 +987,28 @@ int gs360_color_plan_create(gs360_ctx* c, const float* lut, int lut_size, const 
     if (e == hipSuccess) e = hipMemcpy(d_lut, lut, n3 * 3 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = build_color_rtab(d_lut, p->d_tables /* red positions come first */, p->d_rtab, lut_size, c->stream[0]);
+    bool want_cube = true;
+    if (const char* env = std::getenv("GS360_COLOR_CUBE")) want_cube = std::atoi(env) != 0;
+    if (e == hipSuccess && want_cube) {
+        e = hipMalloc(&p->d_cube, color_cube_bytes());
+        if (e == hipSuccess) {
+            ColorLaunch B{};
+            B.rtab = p->d_rtab; B.tables = p->d_tables; B.lut_size = lut_size; B.fixups = p->fixups;
+            e = build_color_cube(B, p->d_cube, c->stream[0]);
+        }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream[0]);
     if (d_lut) (void)hipFree(d_lut);
+    if (e == hipSuccess && p->d_cube) {          // the cube replaces the tables it was built from
+        (void)hipFree(p->d_rtab);
+        p->d_rtab = nullptr;
+    }
     if (e != hipSuccess) {
         if (p->d_rtab) (void)hipFree(p->d_rtab);
         if (p->d_tables) (void)hipFree(p->d_tables);
+        if (p->d_cube) (void)hipFree(p->d_cube);
         delete p;
-        return fail(GS360_ERR_HIP, "colour plan setup failed: %s", hipGetErrorString(e));
+        return fail(e == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "colour plan setup failed: %s", hipGetErrorString(e));
     }
     *out = p;
     return GS360_OK;
@@ -1005,6 +1021,7 @@ int gs360_color_plan_destroy(gs360_ctx* c, gs360_color_plan* p) {
     HIP_TRY(hipDeviceSynchronize());
     if (p->d_rtab) HIP_TRY(hipFree(p->d_rtab));
     if (p->d_tables) HIP_TRY(hipFree(p->d_tables));
+    if (p->d_cube) HIP_TRY(hipFree(p->d_cube));
     delete p;
     return GS360_OK;
 }
@@ -1024,7 +1041,7 @@ int gs360_color_apply_u8(gs360_ctx* c, const gs360_color_plan* p, const void* sr
     if (src_stride < (size_t)W * C || dst_stride < (size_t)W * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
     HIP_TRY(hipSetDevice(c->device));
     ColorLaunch L;
-    L.src = (const uint8_t*)src; L.dst = (uint8_t*)dst; L.rtab = p->d_rtab; L.tables = p->d_tables;
+    L.src = (const uint8_t*)src; L.dst = (uint8_t*)dst; L.rtab = p->d_rtab; L.tables = p->d_tables; L.cube = p->d_cube;
     L.H = H; L.W = W; L.lut_size = p->lut_size; L.red_index = red_index; L.fixups = p->fixups;
     L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
     HIP_TRY(launch_color(L, C, c->stream[slot]));

@@ -16,6 +16,14 @@
 // 0.18 of the roofline on a smooth image and 0.04 on noise, where every pixel pulled four lines).  The output quantiser is a 1024-bin lower-bound table plus
 // one or two threshold compares (exact: the bin table is derived from the thresholds), falling back to a binary
 // search when the thresholds are too dense for that.
+//
+// The cube.  An 8-bit pixel has 2^24 possible values and the whole stage is a pure function of the value, so a plan evaluates that
+// function ONCE for every value (color_cube_kernel: the pipeline above, 16.7 M evaluations -- one 4096 x 4096 image's worth of work) into
+// a 64 MiB table of output pixels indexed by the input pixel, (blue << 16 | green << 8 | red) -> red | green << 8 | blue << 16.  Applying a
+// plan is then ONE dword read per pixel and no arithmetic (color_cube_quad_kernel / color_cube_bytes_kernel); the table sits in HBM (a
+// 4400th of it), the part of it an image touches -- a natural image occupies a small fraction of the colour cube -- in the L2 / Infinity
+// Cache.  Results are those of the evaluating kernels by construction.  GS360_COLOR_CUBE=0 at plan creation keeps the per-pixel
+// evaluation (A/B, or to save the 64 MiB).
 #include <cstring>
 #include <vector>
 
@@ -250,6 +258,112 @@ __global__ __launch_bounds__(kColorThreads) __attribute__((amdgpu_waves_per_eu(G
     }
 }
 
+// ---- the cube: every possible 8-bit pixel through the pipeline once, then one read per pixel ---------------------------------------
+struct CubeArgs {
+    const uint8_t* src;
+    uint8_t* dst;
+    const uint32_t* cube;   // [blue][green][red] -> red | green << 8 | blue << 16
+    int32_t H, W;
+    int32_t red;            // memory index of the red channel (0 or 2)
+    int64_t src_stride, dst_stride;
+};
+
+template <int FIX>
+__global__ __launch_bounds__(kColorThreads) void color_cube_kernel(ColorArgs A, uint32_t* cube) {
+    __shared__ Lds S;
+    load_tables(A, S);
+    for (uint32_t i = blockIdx.x * kColorThreads + threadIdx.x; i < (1u << 24); i += gridDim.x * kColorThreads) {
+        const Rgb8 q = color_px<FIX>(A, S, (int)(i & 255u), (int)((i >> 8) & 255u), (int)(i >> 16));
+        cube[i] = (uint32_t)q.r | ((uint32_t)q.g << 8) | ((uint32_t)q.b << 16);
+    }
+}
+
+// v_perm_b32 selectors (bytes 0-3 = the second operand, 0x0c = a zero byte): keep the three colour bytes of a pixel in memory order
+// (red first) or swap the outer two (blue first); the swap is its own inverse, so the same selector turns a table entry back into
+// memory order
+__device__ __forceinline__ uint32_t cube_selector(int red) { return red != 0 ? 0x0c000102u : 0x0c020100u; }
+
+template <int C>
+__global__ __launch_bounds__(kColorThreads) void color_cube_bytes_kernel(CubeArgs A) {
+    const int x = blockIdx.x * kColorThreads + threadIdx.x;
+    if (x >= A.W) return;
+    const uint8_t* sp = A.src + (int64_t)blockIdx.y * A.src_stride + (int64_t)x * C;
+    uint8_t* dp = A.dst + (int64_t)blockIdx.y * A.dst_stride + (int64_t)x * C;
+    const int iR = A.red, iB = 2 - A.red;
+    const int alpha = (C == 4) ? sp[3] : 0;
+    const uint32_t q = A.cube[(uint32_t)sp[iR] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[iB] << 16)];
+    dp[iR] = (uint8_t)q; dp[1] = (uint8_t)(q >> 8); dp[iB] = (uint8_t)(q >> 16);
+    if (C == 4) dp[3] = (uint8_t)alpha;
+}
+
+// Rows that start on a dword boundary: a thread takes kCubeQuads groups of four pixels (C dwords in, four table reads, C dwords out each),
+// the groups of a thread one wavefront-row (256 pixels x 4) apart so that every load and store instruction of a wavefront covers
+// contiguous bytes; all table reads of a thread are in flight together.
+constexpr int kCubeQuads = 2;
+template <int C>
+__global__ __launch_bounds__(kColorThreads) void color_cube_quad_kernel(CubeArgs A) {
+    const uint32_t sel = cube_selector(A.red);
+    const int x0 = (blockIdx.x * kCubeQuads * kColorThreads + threadIdx.x) * 4;
+    const uint8_t* srow = A.src + (int64_t)blockIdx.y * A.src_stride;
+    uint8_t* drow = A.dst + (int64_t)blockIdx.y * A.dst_stride;
+    uint32_t w[kCubeQuads][C], q[kCubeQuads][4];
+#pragma unroll
+    for (int k = 0; k < kCubeQuads; ++k) {
+        const int x = x0 + k * 4 * kColorThreads;
+        if (x + 4 <= A.W) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) w[k][i] = ((const uint32_t*)(srow + (int64_t)x * C))[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kCubeQuads; ++k) {
+        const int x = x0 + k * 4 * kColorThreads;
+        if (x + 4 <= A.W) {
+            uint32_t px[4];
+            if (C == 4) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) px[p] = w[k][p];
+            } else {
+                px[0] = w[k][0];
+                px[1] = __builtin_amdgcn_alignbit(w[k][1], w[k][0], 24);
+                px[2] = __builtin_amdgcn_alignbit(w[k][2], w[k][1], 16);
+                px[3] = w[k][2] >> 8;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) q[k][p] = A.cube[__builtin_amdgcn_perm(0u, px[p], sel)];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kCubeQuads; ++k) {
+        const int x = x0 + k * 4 * kColorThreads;
+        if (x >= A.W) continue;
+        if (x + 4 <= A.W) {
+            uint32_t o[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) o[p] = __builtin_amdgcn_perm(0u, q[k][p], sel);
+            uint32_t* d32 = (uint32_t*)(drow + (int64_t)x * C);
+            if (C == 4) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) d32[p] = o[p] | (w[k][p] & 0xff000000u);
+            } else {
+                d32[0] = o[0] | (o[1] << 24);
+                d32[1] = (o[1] >> 8) | (o[2] << 16);
+                d32[2] = (o[2] >> 16) | (o[3] << 8);
+            }
+        } else {                                   // the last, partial group of a row
+            const int iR = A.red, iB = 2 - A.red;
+            for (int p = 0; x + p < A.W; ++p) {
+                const uint8_t* s1 = srow + (int64_t)(x + p) * C;
+                uint8_t* d1 = drow + (int64_t)(x + p) * C;
+                const int alpha = (C == 4) ? s1[3] : 0;
+                const uint32_t v = A.cube[(uint32_t)s1[iR] | ((uint32_t)s1[1] << 8) | ((uint32_t)s1[iB] << 16)];
+                d1[iR] = (uint8_t)v; d1[1] = (uint8_t)(v >> 8); d1[iB] = (uint8_t)(v >> 16);
+                if (C == 4) d1[3] = (uint8_t)alpha;
+            }
+        }
+    }
+}
+
 // Plan creation: the red stage of DF:672-675 for the four corners of every (blue cell, green cell) at every red level.  The upper
 // neighbours are min(i + 1, n - 1) as in cell_of, so the last cell of an axis repeats its own node (its weight is then 0).
 __global__ void color_rtab_kernel(const float* lut /* [b][g][r][3] */, const float* pos_r /* 256 */, CellEntry* rtab, int n) {
@@ -381,6 +495,37 @@ hipError_t build_color_rtab(const float* d_lut, const float* d_pos_r, void* d_rt
     return hipGetLastError();
 }
 
+size_t color_cube_bytes() { return ((size_t)1 << 24) * sizeof(uint32_t); }
+
+hipError_t build_color_cube(const ColorLaunch& L, void* d_cube, hipStream_t s) {
+    ColorArgs A;
+    A.src = nullptr; A.dst = nullptr; A.rtab = (const CellEntry*)L.rtab; A.tables = L.tables;
+    A.H = 0; A.W = 0; A.n = L.lut_size; A.red = 0; A.src_stride = 0; A.dst_stride = 0;
+    const dim3 grid(kColorBlocks), block(kColorThreads);
+    if (L.fixups == 1) hipLaunchKernelGGL((color_cube_kernel<1>), grid, block, 0, s, A, (uint32_t*)d_cube);
+    else if (L.fixups == 2) hipLaunchKernelGGL((color_cube_kernel<2>), grid, block, 0, s, A, (uint32_t*)d_cube);
+    else hipLaunchKernelGGL((color_cube_kernel<0>), grid, block, 0, s, A, (uint32_t*)d_cube);
+    return hipGetLastError();
+}
+
+static hipError_t launch_color_cube(const ColorLaunch& L, int C, hipStream_t s) {
+    CubeArgs A;
+    A.src = L.src; A.dst = L.dst; A.cube = (const uint32_t*)L.cube; A.H = L.H; A.W = L.W; A.red = L.red_index;
+    A.src_stride = L.src_stride; A.dst_stride = L.dst_stride;
+    const bool aligned = (((uintptr_t)L.src | (uintptr_t)L.dst | (uint64_t)L.src_stride | (uint64_t)L.dst_stride) & 3u) == 0;
+    if (aligned) {
+        const int per_block = 4 * kCubeQuads * kColorThreads;
+        const dim3 grid((unsigned)((L.W + per_block - 1) / per_block), (unsigned)L.H);
+        if (C == 3) hipLaunchKernelGGL((color_cube_quad_kernel<3>), grid, dim3(kColorThreads), 0, s, A);
+        else hipLaunchKernelGGL((color_cube_quad_kernel<4>), grid, dim3(kColorThreads), 0, s, A);
+    } else {
+        const dim3 grid((unsigned)((L.W + kColorThreads - 1) / kColorThreads), (unsigned)L.H);
+        if (C == 3) hipLaunchKernelGGL((color_cube_bytes_kernel<3>), grid, dim3(kColorThreads), 0, s, A);
+        else hipLaunchKernelGGL((color_cube_bytes_kernel<4>), grid, dim3(kColorThreads), 0, s, A);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_color16(const Color16Launch& L, int C, hipStream_t s) {
     Color16Args A;
     A.src = (const uint16_t*)L.src; A.dst = (uint16_t*)L.dst; A.lut = L.lut; A.thr = L.thr;
@@ -396,6 +541,7 @@ hipError_t launch_color16(const Color16Launch& L, int C, hipStream_t s) {
 }
 
 hipError_t launch_color(const ColorLaunch& L, int C, hipStream_t s) {
+    if (L.cube) return launch_color_cube(L, C, s);
     ColorArgs A;
     A.src = L.src; A.dst = L.dst; A.rtab = (const CellEntry*)L.rtab; A.tables = L.tables;
     A.H = L.H; A.W = L.W; A.n = L.lut_size; A.red = L.red_index;

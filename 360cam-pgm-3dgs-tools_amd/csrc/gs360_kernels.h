@@ -154,6 +154,7 @@ struct ColorLaunch {
     uint8_t* dst;
     const void* rtab;       // device float3[n*n*256]: LUT pre-interpolated along red for every red level
     const float* tables;    // device: level positions R,G,B x 256, 256 output thresholds, packed bin levels
+    const void* cube;       // device uint32[2^24]: the stage evaluated for every 8-bit pixel (NULL: evaluate per pixel from rtab / tables)
     int32_t H, W, lut_size, red_index;
     int32_t fixups;         // 1 or 2 in-bin threshold compares, 0 = binary search (color_build_bins)
     int64_t src_stride, dst_stride;
@@ -174,6 +175,8 @@ size_t color_rtab_bytes(int lut_size);
 size_t color_tables_floats();
 int color_build_bins(const float* thresholds, uint8_t* bins);
 hipError_t build_color_rtab(const float* d_lut, const float* d_pos_r, void* d_rtab, int lut_size, hipStream_t s);
+size_t color_cube_bytes();
+hipError_t build_color_cube(const ColorLaunch& L /* rtab, tables, lut_size, fixups */, void* d_cube, hipStream_t s);
 hipError_t launch_color(const ColorLaunch& L, int C, hipStream_t s);
 
 // kernel launchers (gs360_kernels.hip)

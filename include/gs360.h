@@ -210,6 +210,11 @@ int gs360_fisheye_views_u8(gs360_ctx *ctx, const void *const *src_lens, const gs
  *                         step is monotone, so the output level is the number of thresholds <= clip(x, 0, 1).
  *   lut                   size^3 RGB float32 triples, red fastest ([b][g][r][3], the .cube order, DF:556-562)
  * All three are HOST pointers, copied at plan creation.
+ *
+ * A plan evaluates the stage once for every possible 8-bit pixel (2^24 values) and keeps the results in 64 MiB of device memory;
+ * gs360_color_apply_u8 then reads one table entry per pixel (GS360_ERR_NOMEM when the table cannot be allocated).  With
+ * GS360_COLOR_CUBE=0 in the environment at plan creation the plan keeps its interpolation tables instead (18 MB for a 33^3 LUT)
+ * and every apply evaluates the stage per pixel -- same results, about half the speed on photographs.
  */
 typedef struct gs360_color_plan gs360_color_plan;
 int gs360_color_plan_create(gs360_ctx *ctx, const float *lut, int lut_size, const float *level_pos,

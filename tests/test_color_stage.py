@@ -251,6 +251,38 @@ def test_gpu_full_size_lens_image_33_cube(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("space", ["srgb", "passthrough"])
+def test_gpu_cube_equals_per_pixel_evaluation_on_every_colour(ctx, space, monkeypatch):
+    """the 2^24-entry cube a plan applies is the per-pixel evaluation of every 8-bit colour: one 4096x4096 image that holds each
+    colour once goes through a plan with the cube and through one without (GS360_COLOR_CUBE=0), RGB and BGR, and a strided sample
+    of rows through the oracle"""
+    table, dmin, dmax = lut_of("dom9")
+    v = np.arange(1 << 24, dtype=np.uint32)
+    rng = np.random.default_rng(24)
+    rng.shuffle(v)
+    image = np.stack([v & 255, (v >> 8) & 255, v >> 16], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    rows = np.r_[0:4096:173, 4095]
+    for red in (0, 2):
+        out = {}
+        for cube in ("1", "0"):
+            monkeypatch.setenv("GS360_COLOR_CUBE", cube)
+            stage = color.ColorStage(color.CubeLUT(table.shape[0], table, dmin, dmax), space)
+            out[cube] = stage.apply(ctx, image, red_index=red)
+            stage.close()
+        assert np.array_equal(out["1"], out["0"]), (space, red)
+        want = color_np.color_pipeline(image[rows], table, dmin, dmax, space, red_index=red)
+        assert np.array_equal(out["1"][rows], want), (space, red)
+    # 4 channels (alpha passes through) and the byte path (odd width) read the same cube
+    monkeypatch.setenv("GS360_COLOR_CUBE", "1")
+    stage = color.ColorStage(color.CubeLUT(table.shape[0], table, dmin, dmax), space)
+    rgba = np.concatenate([image[:64, :1021], rng.integers(0, 256, (64, 1021, 1), dtype=np.uint8)], -1)
+    got = stage.apply(ctx, rgba, red_index=2)
+    assert np.array_equal(got[..., 3], rgba[..., 3])
+    assert np.array_equal(got[..., :3], color_np.color_pipeline(np.ascontiguousarray(rgba[..., :3]), table, dmin, dmax, space, red_index=2))
+    stage.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,thr_of_k", [("one_per_bin", lambda k: k / 520.0), ("two_per_bin", lambda k: 0.3 + k / 1800.0),
                                             ("dense", lambda k: 0.5 + k * 1e-5), ("ties_and_never", lambda k: np.where(k < 200, (k // 4) / 64.0, np.inf)),
                                             ("zero_start", lambda k: np.maximum(k - 3, 0) / 300.0)])

@@ -205,8 +205,16 @@ def color_cfg(ctx, steps):
     table = np.stack([rr ** 0.8, 0.9 * gg + 0.1 * bb, np.sqrt(bb)], -1).astype(np.float32)
     stage = color.ColorStage(color.CubeLUT(n, table, np.zeros(3, np.float32), np.ones(3, np.float32)), "srgb")
     res = []
-    for label, img in (("smooth+hash image", synth(4000, 4000, 3)),
-                       ("i.i.d. noise image", np.random.default_rng(1).integers(0, 256, (4000, 4000, 3), dtype=np.uint8))):
+    t0 = time.perf_counter()
+    stage._plan(ctx)                               # plan creation: host tables, upload, the 2^24-entry cube (synchronous)
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    which = os.environ.get("GS360_BENCH_COLOR_IMAGES", "smooth,noise")     # one kind per run for counter passes
+    images = []
+    if "smooth" in which:
+        images.append(("smooth+hash image", synth(4000, 4000, 3)))
+    if "noise" in which:
+        images.append(("i.i.d. noise image", np.random.default_rng(1).integers(0, 256, (4000, 4000, 3), dtype=np.uint8)))
+    for label, img in images:
         d_in, d_out = ctx.to_device(img), ctx.alloc(img.nbytes)
         plan = stage._plan(ctx)
 
@@ -220,7 +228,7 @@ def color_cfg(ctx, steps):
         res.append({"config": "colour stage 4000x4000x3, 33^3 LUT + Rec.709->sRGB, " + label, "ms_per_image": round(ms, 4),
                     "MPix_per_s": round(16.0 / ms * 1e3, 0), "algorithmic_MB_per_image": round(algo / 1e6, 1),
                     "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
-                    "parity_vs_oracle": bool(np.array_equal(got[rows], want))})
+                    "plan_create_ms": round(plan_ms, 2), "parity_vs_oracle": bool(np.array_equal(got[rows], want))})
         ctx.free(d_in)
         ctx.free(d_out)
     stage.close()
