@@ -1503,8 +1503,13 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(eq_
 // blend): the two paths are bit-identical by construction, both read the same source bytes.
 // Ring-shared coordinates wait in LDS as in the lean loop (latitude, left / mirrored longitude); per pitch sign one more
 // entry holds each pixel's row offset inside the box with the vertical phase in its low five bits (the pitch is a multiple of 32).
-constexpr int kStageBytes = 6144;                         // per wavefront: 24 KiB + 16 KiB of parked coordinates = four workgroups per CU
-constexpr int kStageRounds = kStageBytes / 16 / 64;       // DMA instructions per box at most
+#ifndef GS360_STAGE_BYTES
+#define GS360_STAGE_BYTES 6144
+#endif
+constexpr int kStageBytes = GS360_STAGE_BYTES;                         // per wavefront: 24 KiB + 16 KiB of parked coordinates = four workgroups per CU
+#ifndef GS360_STAGE_BYTES_MASKED
+#define GS360_STAGE_BYTES_MASKED 5120   // 20 KiB of slices + 20 KiB of parked entries = four workgroups per CU (6144: three; cfg3 + mask 108 -> 100 us)
+#endif
 // s_waitcnt immediates (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]); issued through the builtin so that the
 // compiler's own wait-count bookkeeping sees them (it does not look into inline assembly)
 #define GS360_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)      /* vmcnt(0) */
@@ -1525,7 +1530,10 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 
 template <bool MASKED>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS360_EQS_WAVES, GS360_EQS_WAVES))) void eq_staged_kernel(const EqLaunch L) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWaves * kStageBytes / 4];
+    constexpr int kSliceBytes = MASKED ? GS360_STAGE_BYTES_MASKED : kStageBytes;   // masked: one more parked entry per pixel
+    constexpr int kSliceRounds = kSliceBytes / 16 / 64;
+    static_assert(kSliceBytes % 1024 == 0, "a slice is whole DMA rounds");
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWaves * kSliceBytes / 4];
     __shared__ __attribute__((aligned(16))) int4 s_park[(MASKED ? 5 : 4) * 64 * kWaves];
     const int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
@@ -1595,20 +1603,20 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
     const int ny_max = ((symax - symin) >> 5) + 3;
     // (pitch <= stride: a box row that starts inside row y ends inside row y + 1 at the latest, and the last row a box may hold is
     // H - 2 -- the copy never leaves the frame)
-    const bool tile_fits = ny_max * pitch <= kStageBytes && (stride & 3u) == 0 && (uint32_t)pitch <= stride && GS360_STAGE_ENABLE;
+    const bool tile_fits = ny_max * pitch <= kSliceBytes && (stride & 3u) == 0 && (uint32_t)pitch <= stride && GS360_STAGE_ENABLE;
     const int nchp = pitch >> 4;                          // 16-byte chunks per box row
     // DMA lane map, fixed for the tile: round k moves chunks 64 k + lane; chunk c = (row c / nchp, piece c % nchp)
-    uint32_t voff[kStageRounds];
+    uint32_t voff[kSliceRounds];
     {
         const float inv = 1.0f / (float)nchp;
 #pragma unroll
-        for (int k = 0; k < kStageRounds; ++k) {
+        for (int k = 0; k < kSliceRounds; ++k) {
             const int c = lane + 64 * k;
             const int row = (int)(((float)c + 0.5f) * inv);          // exact for c < 2^10
             voff[k] = (uint32_t)row * stride + (uint32_t)(c - row * nchp) * 16u;
         }
     }
-    uint32_t* const stage = s_stage + wave * (kStageBytes / 4);
+    uint32_t* const stage = s_stage + wave * (kSliceBytes / 4);
     int4* const park = s_park + threadIdx.x;
     constexpr int kP = 64 * kWaves;
 #pragma unroll
@@ -1663,7 +1671,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
         const int total = ny * nchp;
         const uint8_t* const base = src + (size_t)bx.origin;
 #pragma unroll
-        for (int k = 0; k < kStageRounds; ++k)
+        for (int k = 0; k < kSliceRounds; ++k)
             if (64 * k < total) {                         // wave-uniform
                 if (lane + 64 * k < total)
                     __builtin_amdgcn_global_load_lds((global_void_t*)(base + (size_t)voff[k]), (lds_void_t*)(stage + 256 * k), 16, 0, 0);

@@ -300,7 +300,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--only", default="", help="comma list of: equirect, fisheye, color (default all)")
     ap.add_argument("--secondary", action="store_true", help="print bench.py's compact `secondary` rows instead")
-    ap.add_argument("--eq", default="", help="comma list of equirect rows: cfg1,cfg2,cfg2cubic,cfg2u16,cfg2u16cubic,cfg3,cfg1cubic,cfg3cubic,cfg5,cfg5mask (default all)")
+    ap.add_argument("--eq", default="", help="comma list of equirect rows: cfg1,cfg2,cfg2cubic,cfg2u16,cfg2u16cubic,cfg3,cfg1cubic,cfg3cubic,cfg3mask,cfg5,cfg5mask (default all)")
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=1)
     if args.secondary:
@@ -337,6 +337,8 @@ def main():
                                           interp=gs360.INTERP_CUBIC),
         "cfg5": lambda: equirect_cfg(ctx, "cfg5 7680x3840 -> fisheyelike 10x2048^2 (u8, no fp16/mask fusion)", 7680, 3840,
                                      [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps),
+        "cfg3mask": lambda: equirect_cfg(ctx, "cfg3 + fused keep-mask multiply", 7680, 3840,
+                                         [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360], 4, args.steps, with_mask=True),
         "cfg5mask": lambda: equirect_cfg(ctx, "cfg5 + fused keep-mask multiply (u8 mask, nearest, threshold 128)", 7680, 3840,
                                          [(y, p, HFOV_17MM, HFOV_17MM, 2048, 2048) for y, p in PRESET_FISHEYELIKE], 4, args.steps,
                                          with_mask=True),
