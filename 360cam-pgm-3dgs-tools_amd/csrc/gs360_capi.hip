@@ -1053,6 +1053,7 @@ struct gs360_color_plan16 {
     gs360::Color16Launch L;
     float* d_lut = nullptr;
     float* d_thr = nullptr;
+    void* d_bins = nullptr;
 };
 
 int gs360_color_plan16_create(gs360_ctx* c, const float* lut, int lut_size, const float* domain_min, const float* domain_max,
@@ -1094,14 +1095,22 @@ int gs360_color_plan16_create(gs360_ctx* c, const float* lut, int lut_size, cons
     if (e == hipSuccess) e = hipMemcpy(p->d_lut, lut, n3 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && total) e = hipMalloc((void**)&p->d_thr, (size_t)total * sizeof(float));
     if (e == hipSuccess && total) e = hipMemcpy(p->d_thr, thresholds, (size_t)total * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_pieces) {
+        std::vector<uint8_t> bins(color16_bins_bytes());
+        color16_build_bins(n_pieces, p->L.start, p->L.off, thresholds, bins.data());
+        e = hipMalloc((void**)&p->d_bins, bins.size());
+        if (e == hipSuccess) e = hipMemcpy(p->d_bins, bins.data(), bins.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (p->d_lut) (void)hipFree(p->d_lut);
         if (p->d_thr) (void)hipFree(p->d_thr);
+        if (p->d_bins) (void)hipFree(p->d_bins);
         delete p;
         return fail(GS360_ERR_HIP, "colour plan setup failed: %s", hipGetErrorString(e));
     }
     p->L.lut = p->d_lut;
     p->L.thr = p->d_thr;
+    p->L.bins = p->d_bins;
     *out = p;
     return GS360_OK;
 }
@@ -1113,6 +1122,7 @@ int gs360_color_plan16_destroy(gs360_ctx* c, gs360_color_plan16* p) {
     HIP_TRY(hipDeviceSynchronize());
     if (p->d_lut) HIP_TRY(hipFree(p->d_lut));
     if (p->d_thr) HIP_TRY(hipFree(p->d_thr));
+    if (p->d_bins) HIP_TRY(hipFree(p->d_bins));
     delete p;
     return GS360_OK;
 }

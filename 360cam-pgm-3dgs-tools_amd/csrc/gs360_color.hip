@@ -398,6 +398,7 @@ struct Color16Args {
     uint16_t* dst;
     const float* lut;        // [b][g][r][3]
     const float* thr;        // concatenated per-piece thresholds (sorted within a piece)
+    const void* bins;        // kBins16 entries of Bin16 (color16_build_bins)
     float dmin[3], span[3];
     float start[4];          // piece lower bounds (start[0] unused)
     int32_t base[4], off[5];
@@ -406,22 +407,84 @@ struct Color16Args {
     int64_t src_stride, dst_stride;   // bytes
 };
 
-__device__ __forceinline__ int level16_of(const Color16Args& A, float x) {
-    const float xc = fminf(fmaxf(x, 0.0f), 1.0f);
-    if (A.n_pieces == 0) return (int)__builtin_rintf(xc * 65535.0f);
-    int p = 0;
-    if (A.n_pieces > 1 && xc >= A.start[1]) p = 1;
-    if (A.n_pieces > 2 && xc >= A.start[2]) p = 2;
-    if (A.n_pieces > 3 && xc >= A.start[3]) p = 3;
-    const float* t = A.thr + A.off[p];
-    int lo = 0, hi = A.off[p + 1] - A.off[p];          // count of thresholds <= xc (upper bound)
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (t[mid] <= xc) lo = mid + 1; else hi = mid;
+constexpr int kBins16 = 65536;
+struct __attribute__((aligned(16))) Bin16 {   // answers for x = b / 65536
+    uint32_t kp;                               // piece that holds x << 28 | thresholds of that piece <= x (absolute index)
+    float t[3];                                // the next three thresholds of the piece (+inf behind its end)
+};
+// The three output levels of a pixel.  A value's bin entry (one 16-byte read) counts the thresholds up to the bin's lower edge (<= the
+// value: the scaling by 2^16 and the truncation are exact) and brings the next three along -- enough wherever the encode curve rises by
+// less than three levels per 2^-16; past them the thresholds are counted one by one.  A bin that straddles a piece boundary (at most
+// three do) takes the binary search instead.
+__device__ __forceinline__ void levels16_of(const Color16Args& A, const float (&x)[3], int (&q)[3]) {
+    float xc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xc[c] = fminf(fmaxf(x[c], 0.0f), 1.0f);
+    if (A.n_pieces == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = (int)__builtin_rintf(xc[c] * 65535.0f);
+        return;
     }
-    return A.base[p] + lo;
+    const Bin16* bins = reinterpret_cast<const Bin16*>(A.bins);
+    Bin16 e[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e[c] = bins[min((int)(xc[c] * (float)kBins16), kBins16 - 1)];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int p = 0;
+        if (A.n_pieces > 1 && xc[c] >= A.start[1]) p = 1;
+        if (A.n_pieces > 2 && xc[c] >= A.start[2]) p = 2;
+        if (A.n_pieces > 3 && xc[c] >= A.start[3]) p = 3;
+        const int first = A.off[p], end = A.off[p + 1];
+        int k;
+        if ((int)(e[c].kp >> 28) == p) {
+            k = (int)(e[c].kp & 0x0fffffffu);
+            const int n3 = (e[c].t[0] <= xc[c] ? 1 : 0) + (e[c].t[1] <= xc[c] ? 1 : 0) + (e[c].t[2] <= xc[c] ? 1 : 0);   // sorted
+            k += n3;
+            if (n3 == 3)
+                while (k < end && A.thr[k] <= xc[c]) ++k;
+        } else {
+            const float* t = A.thr + first;
+            int lo = 0, hi = end - first;                  // count of thresholds <= xc (upper bound)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (t[mid] <= xc[c]) lo = mid + 1; else hi = mid;
+            }
+            k = first + lo;
+        }
+        q[c] = A.base[p] + (k - first);
+    }
 }
 
+// one pixel: float01 conversion, domain mapping, cell lookup, the three interpolation stages in the reference's order, output levels
+__device__ __forceinline__ void color16_px(const Color16Args& A, const int (&v)[3], int (&q)[3]) {
+    const int n = A.n, nmax = n - 1;
+    Cell c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float f01 = (float)v[k] / 65535.0f;                                        // DF:609-610
+        const float coord = fminf(fmaxf((f01 - A.dmin[k]) / A.span[k], 0.0f), 1.0f);     // DF:647
+        c[k] = cell_of(coord * (float)nmax, nmax);                                       // DF:648-653
+    }
+    // the eight corners as 12-byte nodes, all requested before the first blend
+    const F3* T = reinterpret_cast<const F3*>(A.lut);
+    auto at = [&](int bi, int gi, int ri) { return T[((uint32_t)bi * (uint32_t)n + (uint32_t)gi) * (uint32_t)n + (uint32_t)ri]; };
+    const F3 n000 = at(c[2].i0, c[1].i0, c[0].i0), n001 = at(c[2].i0, c[1].i0, c[0].i1);
+    const F3 n010 = at(c[2].i0, c[1].i1, c[0].i0), n011 = at(c[2].i0, c[1].i1, c[0].i1);
+    const F3 n100 = at(c[2].i1, c[1].i0, c[0].i0), n101 = at(c[2].i1, c[1].i0, c[0].i1);
+    const F3 n110 = at(c[2].i1, c[1].i1, c[0].i0), n111 = at(c[2].i1, c[1].i1, c[0].i1);
+    auto stage3 = [&](float v000, float v001, float v010, float v011, float v100, float v101, float v110, float v111) {
+        const float c00 = lerp_ref(v000, v001, c[0].f), c10 = lerp_ref(v010, v011, c[0].f);                         // DF:672-675
+        const float c01 = lerp_ref(v100, v101, c[0].f), c11 = lerp_ref(v110, v111, c[0].f);
+        return lerp_ref(lerp_ref(c00, c10, c[1].f), lerp_ref(c01, c11, c[1].f), c[2].f);                            // DF:676-679
+    };
+    const float xs[3] = {stage3(n000.x, n001.x, n010.x, n011.x, n100.x, n101.x, n110.x, n111.x),
+                         stage3(n000.y, n001.y, n010.y, n011.y, n100.y, n101.y, n110.y, n111.y),
+                         stage3(n000.z, n001.z, n010.z, n011.z, n100.z, n101.z, n110.z, n111.z)};
+    levels16_of(A, xs, q);
+}
+
+// Any alignment: one thread per pixel, 16-bit loads and stores.
 template <int C>
 __global__ __launch_bounds__(kColorThreads) void color_lut_u16_kernel(Color16Args A) {
     const int x = blockIdx.x * kColorThreads + threadIdx.x;
@@ -431,27 +494,55 @@ __global__ __launch_bounds__(kColorThreads) void color_lut_u16_kernel(Color16Arg
     const int iR = A.red, iB = 2 - A.red;
     const int v[3] = {sp[iR], sp[1], sp[iB]};
     const int alpha = (C == 4) ? sp[3] : 0;
-    const int n = A.n, nmax = n - 1;
-    Cell c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float f01 = (float)v[k] / 65535.0f;                                        // DF:609-610
-        const float coord = fminf(fmaxf((f01 - A.dmin[k]) / A.span[k], 0.0f), 1.0f);     // DF:647
-        c[k] = cell_of(coord * (float)nmax, nmax);                                       // DF:648-653
-    }
-    const float* T = A.lut;
-    auto at = [&](int bi, int gi, int ri, int ch) { return T[(((size_t)bi * n + gi) * n + ri) * 3 + ch]; };
     int q[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float c00 = lerp_ref(at(c[2].i0, c[1].i0, c[0].i0, ch), at(c[2].i0, c[1].i0, c[0].i1, ch), c[0].f);   // DF:672-675
-        const float c10 = lerp_ref(at(c[2].i0, c[1].i1, c[0].i0, ch), at(c[2].i0, c[1].i1, c[0].i1, ch), c[0].f);
-        const float c01 = lerp_ref(at(c[2].i1, c[1].i0, c[0].i0, ch), at(c[2].i1, c[1].i0, c[0].i1, ch), c[0].f);
-        const float c11 = lerp_ref(at(c[2].i1, c[1].i1, c[0].i0, ch), at(c[2].i1, c[1].i1, c[0].i1, ch), c[0].f);
-        q[ch] = level16_of(A, lerp_ref(lerp_ref(c00, c10, c[1].f), lerp_ref(c01, c11, c[1].f), c[2].f));            // DF:676-679
-    }
+    color16_px(A, v, q);
     dp[iR] = (uint16_t)q[0]; dp[1] = (uint16_t)q[1]; dp[iB] = (uint16_t)q[2];
     if (C == 4) dp[3] = (uint16_t)alpha;
+}
+
+// Rows that start on a dword boundary: one thread per two pixels = C dwords in, C dwords out (the texture path is what bounds this
+// kernel -- 16-bit accesses cost an instruction each, like dwords)
+template <int C>
+__global__ __launch_bounds__(kColorThreads) void color_lut_u16_pair_kernel(Color16Args A) {
+    const int x = (blockIdx.x * kColorThreads + threadIdx.x) * 2;
+    if (x >= A.W) return;
+    const uint8_t* srow = reinterpret_cast<const uint8_t*>(A.src) + (int64_t)blockIdx.y * A.src_stride;
+    uint8_t* drow = reinterpret_cast<uint8_t*>(A.dst) + (int64_t)blockIdx.y * A.dst_stride;
+    const int iR = A.red, iB = 2 - A.red;
+    if (x + 2 > A.W) {                                  // the last pixel of an odd-width row
+        const uint16_t* sp = reinterpret_cast<const uint16_t*>(srow) + (int64_t)x * C;
+        uint16_t* dp = reinterpret_cast<uint16_t*>(drow) + (int64_t)x * C;
+        const int v[3] = {sp[iR], sp[1], sp[iB]};
+        const int alpha = (C == 4) ? sp[3] : 0;
+        int q[3];
+        color16_px(A, v, q);
+        dp[iR] = (uint16_t)q[0]; dp[1] = (uint16_t)q[1]; dp[iB] = (uint16_t)q[2];
+        if (C == 4) dp[3] = (uint16_t)alpha;
+        return;
+    }
+    uint32_t w[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) w[i] = reinterpret_cast<const uint32_t*>(srow + (int64_t)x * C * 2)[i];
+    auto sample = [&](int i) { return (int)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu); };   // 16-bit sample i of the pair
+    uint32_t o[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) o[i] = 0u;
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+        const int m[3] = {sample(px * C), sample(px * C + 1), sample(px * C + 2)};          // memory order
+        const int v[3] = {iR == 0 ? m[0] : m[2], m[1], iR == 0 ? m[2] : m[0]};
+        int q[3];
+        color16_px(A, v, q);
+        const int out3[3] = {iR == 0 ? q[0] : q[2], q[1], iR == 0 ? q[2] : q[0]};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int i = px * C + ch;
+            o[i >> 1] |= (uint32_t)out3[ch] << (16 * (i & 1));
+        }
+        if (C == 4) o[(px * C + 3) >> 1] |= w[(px * C + 3) >> 1] & 0xffff0000u;             // alpha: the high half of dwords 1 and 3
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) reinterpret_cast<uint32_t*>(drow + (int64_t)x * C * 2)[i] = o[i];
 }
 
 template <int C, int FIX>
@@ -487,6 +578,29 @@ int color_build_bins(const float* thr /* 256, [0] unused */, uint8_t* bins /* kB
         if (inside > worst) worst = inside;
     }
     return worst <= 1 ? 1 : (worst == 2 ? 2 : 0);
+}
+
+size_t color16_bins_bytes() { return (size_t)kBins16 * sizeof(Bin16); }
+
+// Host: bin b answers for x = b / 65536 -- the piece that holds x, how many of that piece's thresholds are <= x (as an absolute index
+// into the concatenated threshold array; plan16 creation bounds it by 2^20) and the next three thresholds of the piece.
+void color16_build_bins(int n_pieces, const float* start, const int32_t* off, const float* thr, void* bins_out) {
+    Bin16* bins = static_cast<Bin16*>(bins_out);
+    for (int b = 0; b < kBins16; ++b) {
+        const float edge = (float)b / (float)kBins16;                    // exact
+        int p = 0;
+        for (int q = 1; q < n_pieces; ++q)
+            if (edge >= start[q]) p = q;
+        const float* lo = thr + off[p];
+        const float* const end = thr + off[p + 1];
+        const float* hi = end;
+        while (lo < hi) {                                                // upper bound: first threshold > edge
+            const float* mid = lo + (hi - lo) / 2;
+            if (*mid <= edge) lo = mid + 1; else hi = mid;
+        }
+        bins[b].kp = ((uint32_t)p << 28) | (uint32_t)(lo - thr);
+        for (int j = 0; j < 3; ++j) bins[b].t[j] = lo + j < end ? lo[j] : __builtin_inff();
+    }
 }
 
 hipError_t build_color_rtab(const float* d_lut, const float* d_pos_r, void* d_rtab, int lut_size, hipStream_t s) {
@@ -528,15 +642,22 @@ static hipError_t launch_color_cube(const ColorLaunch& L, int C, hipStream_t s) 
 
 hipError_t launch_color16(const Color16Launch& L, int C, hipStream_t s) {
     Color16Args A;
-    A.src = (const uint16_t*)L.src; A.dst = (uint16_t*)L.dst; A.lut = L.lut; A.thr = L.thr;
+    A.src = (const uint16_t*)L.src; A.dst = (uint16_t*)L.dst; A.lut = L.lut; A.thr = L.thr; A.bins = L.bins;
     for (int k = 0; k < 3; ++k) { A.dmin[k] = L.dmin[k]; A.span[k] = L.span[k]; }
     for (int k = 0; k < 4; ++k) { A.start[k] = L.start[k]; A.base[k] = L.base[k]; }
     for (int k = 0; k < 5; ++k) A.off[k] = L.off[k];
     A.n_pieces = L.n_pieces; A.H = L.H; A.W = L.W; A.n = L.lut_size; A.red = L.red_index;
     A.src_stride = L.src_stride; A.dst_stride = L.dst_stride;
-    dim3 grid((unsigned)((L.W + kColorThreads - 1) / kColorThreads), (unsigned)L.H);
-    if (C == 3) hipLaunchKernelGGL((color_lut_u16_kernel<3>), grid, dim3(kColorThreads), 0, s, A);
-    else hipLaunchKernelGGL((color_lut_u16_kernel<4>), grid, dim3(kColorThreads), 0, s, A);
+    const bool aligned = (((uintptr_t)L.src | (uintptr_t)L.dst | (uint64_t)L.src_stride | (uint64_t)L.dst_stride) & 3u) == 0;
+    if (aligned) {
+        dim3 grid((unsigned)(((L.W + 1) / 2 + kColorThreads - 1) / kColorThreads), (unsigned)L.H);
+        if (C == 3) hipLaunchKernelGGL((color_lut_u16_pair_kernel<3>), grid, dim3(kColorThreads), 0, s, A);
+        else hipLaunchKernelGGL((color_lut_u16_pair_kernel<4>), grid, dim3(kColorThreads), 0, s, A);
+    } else {
+        dim3 grid((unsigned)((L.W + kColorThreads - 1) / kColorThreads), (unsigned)L.H);
+        if (C == 3) hipLaunchKernelGGL((color_lut_u16_kernel<3>), grid, dim3(kColorThreads), 0, s, A);
+        else hipLaunchKernelGGL((color_lut_u16_kernel<4>), grid, dim3(kColorThreads), 0, s, A);
+    }
     return hipGetLastError();
 }
 

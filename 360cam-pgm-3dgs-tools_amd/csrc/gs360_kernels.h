@@ -164,6 +164,7 @@ struct Color16Launch {     // 16-bit images: everything per pixel, output thresh
     void* dst;
     const float* lut;       // device [b][g][r][3]
     const float* thr;       // device, concatenated pieces
+    const void* bins;       // device, color16_bins_bytes() (color16_build_bins); unused when n_pieces == 0
     float dmin[3], span[3];
     float start[4];
     int32_t base[4], off[5];
@@ -171,6 +172,8 @@ struct Color16Launch {     // 16-bit images: everything per pixel, output thresh
     int64_t src_stride, dst_stride;
 };
 hipError_t launch_color16(const Color16Launch& L, int C, hipStream_t s);
+size_t color16_bins_bytes();
+void color16_build_bins(int n_pieces, const float* start, const int32_t* off, const float* thr, void* bins /* host, color16_bins_bytes() */);
 size_t color_rtab_bytes(int lut_size);
 size_t color_tables_floats();
 int color_build_bins(const float* thresholds, uint8_t* bins);

@@ -347,12 +347,13 @@ def test_gpu_u16_matches_reference_vectors_and_oracle(ctx, lut, img, space):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,space", [((37, 101, 3), "srgb"), ((5, 1023, 4), "srgb"), ((64, 256, 3), "passthrough"), ((1, 7, 4), "passthrough"),
-                                          ((400, 1600, 3), "srgb")])
+                                          ((400, 1600, 3), "srgb"), ((33, 102, 3), "srgb"), ((9, 2, 3), "srgb")])
 def test_gpu_u16_shapes_alpha_and_full_range(ctx, shape, space):
     table, dmin, dmax = lut_of("dom9")
     stage = color.ColorStage(color.CubeLUT(9, table, dmin, dmax), space)
     image = np.random.default_rng(shape[1]).integers(0, 65536, shape, dtype=np.uint16)
     image[0, :, 0] = np.linspace(0, 65535, shape[1]).astype(np.uint16)        # sweeps every piece of the quantiser
-    got = stage.apply(ctx, image, red_index=0)
-    assert np.array_equal(got, color_np.color_pipeline(image, table, dmin, dmax, space, red_index=0))
+    for red in (0, 2):    # dword-aligned rows take the two-pixels-per-thread kernel (odd widths: its one-pixel tail), others the 16-bit one
+        got = stage.apply(ctx, image, red_index=red)
+        assert np.array_equal(got, color_np.color_pipeline(image, table, dmin, dmax, space, red_index=red)), red
     stage.close()

@@ -208,7 +208,7 @@ def color_cfg(ctx, steps):
     t0 = time.perf_counter()
     stage._plan(ctx)                               # plan creation: host tables, upload, the 2^24-entry cube (synchronous)
     plan_ms = (time.perf_counter() - t0) * 1e3
-    which = os.environ.get("GS360_BENCH_COLOR_IMAGES", "smooth,noise")     # one kind per run for counter passes
+    which = os.environ.get("GS360_BENCH_COLOR_IMAGES", "smooth,noise,u16")     # one kind per run for counter passes
     images = []
     if "smooth" in which:
         images.append(("smooth+hash image", synth(4000, 4000, 3)))
@@ -229,6 +229,24 @@ def color_cfg(ctx, steps):
                     "MPix_per_s": round(16.0 / ms * 1e3, 0), "algorithmic_MB_per_image": round(algo / 1e6, 1),
                     "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
                     "plan_create_ms": round(plan_ms, 2), "parity_vs_oracle": bool(np.array_equal(got[rows], want))})
+        ctx.free(d_in)
+        ctx.free(d_out)
+    if "u16" in which:
+        img16 = (synth(4000, 4000, 3).astype(np.uint16) << 8) | synth(4000, 4000, 5)        # smooth high byte, busy low byte
+        d_in, d_out = ctx.to_device(img16), ctx.alloc(img16.nbytes)
+        plan16 = stage._plan16(ctx)
+
+        def call16():
+            ctx.color_apply16_dev(plan16, d_in, 4000, 4000, 3, dst=d_out, slot=0)
+        ms = time_steps(ctx, call16, max(3, steps // 4))
+        got = ctx.download(d_out, img16.shape, dtype=np.uint16)
+        rows = np.r_[0:4000:499]
+        want = color_np.color_pipeline(img16[rows], table, stage.lut.domain_min, stage.lut.domain_max, "srgb", red_index=0)
+        algo = 2 * img16.nbytes
+        res.append({"config": "colour stage 4000x4000x3 uint16, 33^3 LUT + Rec.709->sRGB (per-pixel evaluation)", "ms_per_image": round(ms, 4),
+                    "MPix_per_s": round(16.0 / ms * 1e3, 0), "algorithmic_MB_per_image": round(algo / 1e6, 1),
+                    "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
+                    "parity_vs_oracle": bool(np.array_equal(got[rows], want))})
         ctx.free(d_in)
         ctx.free(d_out)
     stage.close()
