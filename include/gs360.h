@@ -258,7 +258,9 @@ int gs360_remap_tables_u16(gs360_ctx *ctx, const gs360_remap_job *jobs, int n_jo
  * step (Rec.709 -> sRGB through NumPy's float32 power) arrives as thresholds in n_pieces <= 4 monotone pieces of clip(x):
  * piece q covers [piece_start[q], piece_start[q+1]) (piece_start[0] is taken as 0), its thresholds are
  * thresholds[piece_off[q] .. piece_off[q+1]) (sorted), and the level is piece_base[q] + the number of them <= clip(x).
- * All pointers are HOST pointers, copied at plan creation.
+ * All pointers are HOST pointers, copied at plan creation (which also derives a 1 MiB index of the thresholds: for each of
+ * 65536 equal steps of clip(x) the count up to the step and the next three thresholds, so that a pixel's level costs one
+ * read per channel; the count itself stays exact).
  */
 typedef struct gs360_color_plan16 gs360_color_plan16;
 int gs360_color_plan16_create(gs360_ctx *ctx, const float *lut, int lut_size, const float *domain_min, const float *domain_max,
