@@ -554,6 +554,8 @@ def main() -> None:
                 drain(list(done))
         if stage is not None:
             stage.close()
+        for r in renderers.values():
+            r.close()
         for ctx in contexts:
             ctx.close()
 

@@ -778,10 +778,34 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
 }  // namespace
 
 // ---- table remap -------------------------------------------------------------------------------
+struct gs360_map_plan {         // float maps packed once (gs360_kernels.hip, map plans)
+    int device = 0;
+    int h = 0, w = 0;
+    int nearest = 0;
+    int has_valid = 0;
+    uint32_t* d_packed = nullptr;
+    uint8_t* d_hi = nullptr;
+};
+
 namespace {
 
-int fill_table_job(gs360_ctx* c, const gs360_remap_job& J, int C, int interp, const double* border_value, TableLaunch* L) {
-    if (!J.src || !J.map_x || !J.map_y || !J.dst) return fail(GS360_ERR_ARG, "NULL argument");
+int check_map_plan(gs360_ctx* c, const gs360_remap_job& J, const gs360_map_plan* plan, int interp) {
+    if (plan->device != c->device) return fail(GS360_ERR_ARG, "map plan belongs to device %d, ctx is device %d", plan->device, c->device);
+    if (plan->h != J.h || plan->w != J.w) return fail(GS360_ERR_ARG, "map plan is %dx%d, the job asks for %dx%d", plan->w, plan->h, J.w, J.h);
+    if (plan->nearest != (interp == GS360_INTERP_NEAREST ? 1 : 0))
+        return fail(GS360_ERR_ARG, "map plan was packed for %s sampling", plan->nearest ? "nearest" : "interpolated");
+    if (J.W > kMapPlanMaxDim || J.H > kMapPlanMaxDim)
+        return fail(GS360_ERR_UNSUPPORTED, "map plans address sources up to %d x %d (got %dx%d): use the float maps", kMapPlanMaxDim,
+                    kMapPlanMaxDim, J.W, J.H);
+    if (J.valid && !plan->has_valid) return fail(GS360_ERR_ARG, "the job asks for a valid fill, the plan was made without a valid map");
+    return 0;
+}
+
+int fill_table_job(gs360_ctx* c, const gs360_remap_job& J, const gs360_map_plan* plan, int C, int interp, const double* border_value,
+                   TableLaunch* L) {
+    if (!J.src || !J.dst || (!plan && (!J.map_x || !J.map_y))) return fail(GS360_ERR_ARG, "NULL argument");
+    if (plan)
+        if (int rc = check_map_plan(c, J, plan, interp)) return rc;
     if (J.H < 1 || J.W < 1 || J.H >= 32767 || J.W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", J.W, J.H);
     if (J.h < 0 || J.w < 0 || J.h >= 32767 || J.w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", J.w, J.h);
     size_t src_stride = J.src_stride ? J.src_stride : (size_t)J.W * C;
@@ -789,6 +813,10 @@ int fill_table_job(gs360_ctx* c, const gs360_remap_job& J, int C, int interp, co
     if (src_stride < (size_t)J.W * C || dst_stride < (size_t)J.w * C) return fail(GS360_ERR_ARG, "stride smaller than a row");
     std::memset(L, 0, sizeof(*L));
     L->src = (const uint8_t*)J.src; L->map_x = J.map_x; L->map_y = J.map_y; L->valid = J.valid; L->dst = (uint8_t*)J.dst;
+    if (plan) {                    // job.valid != NULL asks for the plan's valid bit (the pointer itself is not read)
+        L->packed = plan->d_packed; L->packed_hi = plan->d_hi; L->use_valid = J.valid ? 1 : 0;
+        L->map_x = L->map_y = nullptr; L->valid = nullptr;
+    }
     L->H = J.H; L->W = J.W; L->h = J.h; L->w = J.w;
     L->src_stride = (int64_t)src_stride; L->dst_stride = (int64_t)dst_stride;
     L->interp = interp;
@@ -805,8 +833,57 @@ int fill_table_job(gs360_ctx* c, const gs360_remap_job& J, int C, int interp, co
 
 }  // namespace
 
+int gs360_map_plan_create(gs360_ctx* c, const float* map_x, const float* map_y, const uint8_t* valid, int h, int w,
+                          int nearest, int slot, gs360_map_plan** out) {
+    if (int rc = check_ctx_slot(c, slot)) return rc;
+    if (!map_x || !map_y || !out) return fail(GS360_ERR_ARG, "NULL argument");
+    if (h < 1 || w < 1 || h >= 32767 || w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", w, h);
+    HIP_TRY(hipSetDevice(c->device));
+    gs360_map_plan* p = new (std::nothrow) gs360_map_plan();
+    if (!p) return fail(GS360_ERR_NOMEM, "out of host memory");
+    p->device = c->device; p->h = h; p->w = w; p->nearest = nearest ? 1 : 0; p->has_valid = valid ? 1 : 0;
+    const size_t n = (size_t)h * (size_t)w;
+    hipError_t e = hipMalloc((void**)&p->d_packed, n * sizeof(uint32_t) + kSlack);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_hi, n + kSlack);
+    if (e == hipSuccess) e = launch_map_pack(map_x, map_y, valid, (int64_t)n, p->nearest, p->d_packed, p->d_hi, c->stream[slot]);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream[slot]);      // the caller may release its maps on return
+    if (e != hipSuccess) {
+        if (p->d_packed) (void)hipFree(p->d_packed);
+        if (p->d_hi) (void)hipFree(p->d_hi);
+        delete p;
+        return fail(e == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "map plan setup failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return GS360_OK;
+}
+
+int gs360_map_plan_destroy(gs360_ctx* c, gs360_map_plan* p) {
+    if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
+    if (!p) return GS360_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (p->d_packed) HIP_TRY(hipFree(p->d_packed));
+    if (p->d_hi) HIP_TRY(hipFree(p->d_hi));
+    delete p;
+    return GS360_OK;
+}
+
+static int remap_batches_u8(gs360_ctx* c, const gs360_remap_job* jobs, const gs360_map_plan* const* plans, int n_jobs, int C, int interp,
+                            const double* border_value, int slot);
+
+int gs360_remap_plans_u8(gs360_ctx* c, const gs360_remap_job* jobs, const gs360_map_plan* const* plans, int n_jobs, int C,
+                         int interp, const double* border_value, int slot) {
+    if (n_jobs > 0 && !plans) return fail(GS360_ERR_ARG, "plans is NULL");
+    return remap_batches_u8(c, jobs, plans, n_jobs, C, interp, border_value, slot);
+}
+
 int gs360_remap_tables_u8(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs, int C, int interp,
                           const double* border_value, int slot) {
+    return remap_batches_u8(c, jobs, nullptr, n_jobs, C, interp, border_value, slot);
+}
+
+static int remap_batches_u8(gs360_ctx* c, const gs360_remap_job* jobs, const gs360_map_plan* const* plans, int n_jobs, int C, int interp,
+                            const double* border_value, int slot) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
     if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(GS360_ERR_ARG, "bad job list");
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
@@ -821,7 +898,7 @@ int gs360_remap_tables_u8(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs,
         if (const char* e = std::getenv("GS360_TABLE_PERSIST")) B.persist_blocks = std::atoi(e);   // probes: 0 = one tile per workgroup
         for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
             if (jobs[j].h == 0 || jobs[j].w == 0) continue;
-            if (int rc = fill_table_job(c, jobs[j], C, interp, border_value, &B.job[B.n_jobs])) return rc;
+            if (int rc = fill_table_job(c, jobs[j], plans ? plans[j] : nullptr, C, interp, border_value, &B.job[B.n_jobs])) return rc;
             ++B.n_jobs;
         }
         if (B.n_jobs) HIP_TRY(launch_table_batch(B, C, c->stream[slot]));
@@ -838,8 +915,22 @@ int gs360_remap_table_u8(gs360_ctx* c, const void* src, int H, int W, int C, siz
     return gs360_remap_tables_u8(c, &J, 1, C, interp, border_value, slot);
 }
 
+static int remap_batches_u16(gs360_ctx* c, const gs360_remap_job* jobs, const gs360_map_plan* const* plans, int n_jobs, int C, int interp,
+                             const double* border_value, int slot);
+
 int gs360_remap_tables_u16(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs, int C, int interp,
                            const double* border_value, int slot) {
+    return remap_batches_u16(c, jobs, nullptr, n_jobs, C, interp, border_value, slot);
+}
+
+int gs360_remap_plans_u16(gs360_ctx* c, const gs360_remap_job* jobs, const gs360_map_plan* const* plans, int n_jobs, int C,
+                          int interp, const double* border_value, int slot) {
+    if (n_jobs > 0 && !plans) return fail(GS360_ERR_ARG, "plans is NULL");
+    return remap_batches_u16(c, jobs, plans, n_jobs, C, interp, border_value, slot);
+}
+
+static int remap_batches_u16(gs360_ctx* c, const gs360_remap_job* jobs, const gs360_map_plan* const* plans, int n_jobs, int C, int interp,
+                             const double* border_value, int slot) {
     if (int rc = check_ctx_slot(c, slot)) return rc;
     if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(GS360_ERR_ARG, "bad job list");
     if (C != 1 && C != 3 && C != 4) return fail(GS360_ERR_ARG, "C must be 1, 3 or 4 (got %d)", C);
@@ -858,7 +949,10 @@ int gs360_remap_tables_u16(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs
         B.persist_blocks = 0;
         for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
             const gs360_remap_job& J = jobs[j];
-            if (!J.src || !J.map_x || !J.map_y || !J.dst) return fail(GS360_ERR_ARG, "NULL argument");
+            const gs360_map_plan* plan = plans ? plans[j] : nullptr;
+            if (!J.src || !J.dst || (!plan && (!J.map_x || !J.map_y))) return fail(GS360_ERR_ARG, "NULL argument");
+            if (plan)
+                if (int rc = check_map_plan(c, J, plan, interp)) return rc;
             if (J.H < 1 || J.W < 1 || J.H >= 32767 || J.W >= 32767) return fail(GS360_ERR_ARG, "source size %dx%d outside cv2.remap limits", J.W, J.H);
             if (J.h < 0 || J.w < 0 || J.h >= 32767 || J.w >= 32767) return fail(GS360_ERR_ARG, "bad map size %dx%d", J.w, J.h);
             if (J.h == 0 || J.w == 0) continue;
@@ -873,6 +967,10 @@ int gs360_remap_tables_u16(gs360_ctx* c, const gs360_remap_job* jobs, int n_jobs
             L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
             L.interp = interp;
             L.fill = J.fill_value < 0 ? 0 : (J.fill_value > 65535 ? 65535 : J.fill_value);
+            if (plan) {
+                L.packed = plan->d_packed; L.packed_hi = plan->d_hi; L.use_valid = J.valid ? 1 : 0;
+                L.map_x = L.map_y = nullptr; L.valid = nullptr;
+            }
         }
         if (B.n_jobs) HIP_TRY(launch_table_u16_batch(B, C, c->d_coef1d, cval, c->stream[slot]));
     }

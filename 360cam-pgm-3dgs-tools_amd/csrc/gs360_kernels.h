@@ -80,6 +80,10 @@ struct TableLaunch {
     const float* map_x;
     const float* map_y;
     const uint8_t* valid;  // may be null
+    // a map plan instead of map_x / map_y / valid (map_pack_kernel; null = float maps): 5 bytes per pixel
+    const uint32_t* packed;     // x + 8 (12 bits) | y + 8 (12 bits) | x phase (5 bits) | low 3 bits of the y phase
+    const uint8_t* packed_hi;   // high 2 bits of the y phase | valid << 2
+    int32_t use_valid;          // with a plan: apply its valid bit (the `valid` pointer of the float form)
     uint8_t* dst;
     int32_t H, W, h, w;
     int64_t src_stride, dst_stride;
@@ -202,6 +206,22 @@ hipError_t launch_bswap16(uint16_t* buf, size_t n, hipStream_t s);            //
 hipError_t launch_arith_selftest(uint32_t seed, int blocks, int iters, unsigned long long* d_bad, hipStream_t s);
 hipError_t launch_table_u16_batch(TableBatch& B, int C, const float* coef, const uint16_t cval[4], hipStream_t s);   // all jobs share interp
 hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s);
+// map plan: float maps (+ valid) -> the packed form; `nearest` packs cvRound(map) instead of the 1/32-pixel fixed point
+constexpr int kMapPlanMaxDim = 4079;     // x + 8, y + 8 of any position that still touches the image fit 12 bits
+// a packed position back as the floats k / 32 (or the integer position for nearest): what the samplers' own cvRound(. * 32) maps to k again
+__device__ __forceinline__ void planned_coords(const uint32_t P, const uint32_t hb, const bool nearest, float& mx, float& my) {
+    const int ix = (int)(P & 0xfffu) - 8, iy = (int)((P >> 12) & 0xfffu) - 8;
+    if (nearest) {
+        mx = (float)ix;
+        my = (float)iy;
+        return;
+    }
+    mx = (float)(ix * 32 + (int)((P >> 24) & 31u)) * 0.03125f;
+    my = (float)(iy * 32 + (int)((P >> 29) | ((hb & 3u) << 3))) * 0.03125f;
+}
+
+hipError_t launch_map_pack(const float* map_x, const float* map_y, const uint8_t* valid, int64_t n, int nearest,
+                           uint32_t* packed, uint8_t* packed_hi, hipStream_t s);
 hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s);   // all jobs share C and interp (job[0].interp)
 hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s);
 

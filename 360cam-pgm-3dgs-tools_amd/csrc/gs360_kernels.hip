@@ -1903,6 +1903,34 @@ __device__ __forceinline__ int cv_round(float v) {  // SSE cvtss2si: half-to-eve
 }
 __device__ __forceinline__ int sat_s16(int v) { return min(max(v, -32768), 32767); }
 
+// ---- map plans -------------------------------------------------------------------------------------------------------------------
+// cv2.remap turns its float maps into 1/32-pixel fixed point on every call (cvRound(map * 32), integer part saturated to int16) before
+// any sampling; a plan does that once and keeps the result in 5 bytes per pixel instead of the 9 of two floats and a valid byte.  The
+// integer part is clamped to [-8, 4087]: every position whose widest window (Lanczos-4: x - 3 .. x + 4) still touches a source of up
+// to 4079 x 4079 pixels is kept as it is, and one that is moved had no tap inside the image before and has none after -- the border
+// constant either way.  The samplers take the position back as floats k / 32, exact, whose cvRound(. * 32) is k again.
+__global__ __launch_bounds__(256) void map_pack_kernel(const float* __restrict__ map_x, const float* __restrict__ map_y,
+                                                       const uint8_t* __restrict__ valid, int64_t n, int nearest,
+                                                       uint32_t* __restrict__ packed, uint8_t* __restrict__ packed_hi) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float mx = map_x[i], my = map_y[i];
+    int ix, iy, fx = 0, fy = 0;
+    if (nearest) {
+        ix = sat_s16(cv_round(mx));
+        iy = sat_s16(cv_round(my));
+    } else {
+        const int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
+        fx = sx & 31; fy = sy & 31;
+        ix = sat_s16(sx >> 5);
+        iy = sat_s16(sy >> 5);
+    }
+    ix = min(max(ix, -8), kMapPlanMaxDim + 8) + 8;
+    iy = min(max(iy, -8), kMapPlanMaxDim + 8) + 8;
+    packed[i] = (uint32_t)ix | ((uint32_t)iy << 12) | ((uint32_t)fx << 24) | ((uint32_t)(fy & 7) << 29);
+    packed_hi[i] = (uint8_t)((fy >> 3) | ((!valid || valid[i]) ? 4 : 0));
+}
+
 template <int C>
 __device__ __forceinline__ void cv_sample_linear(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
                                                  float mx, float my, const uint8_t (&cval)[4], uint32_t (&out)[4]) {
@@ -2286,16 +2314,32 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
         const uint8_t* __restrict__ vptr = L.valid ? L.valid : reinterpret_cast<const uint8_t*>(L.map_x);
         const bool has_valid = L.valid != nullptr;
         uint8_t vbyte[kRowsPerWave];
+        if (L.packed) {                       // a map plan (wave-uniform): one dword and one byte per pixel
+            uint32_t pw[kRowsPerWave];
 #pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) {
-            const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
-            mxs[rr] = L.map_x[o];         // (non-temporal map loads were measured: no difference)
-            mys[rr] = L.map_y[o];
-            vbyte[rr] = vptr[o];
+            for (int rr = 0; rr < kRowsPerWave; ++rr) {
+                const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
+                pw[rr] = L.packed[o];
+                vbyte[rr] = L.packed_hi[o];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rr = 0; rr < kRowsPerWave; ++rr) {
+                planned_coords(pw[rr], vbyte[rr], INTERP == GS360_INTERP_NEAREST, mxs[rr], mys[rr]);
+                inval[rr] = (L.use_valid != 0) & ((vbyte[rr] & 4) == 0);
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < kRowsPerWave; ++rr) {
+                const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
+                mxs[rr] = L.map_x[o];         // (non-temporal map loads were measured: no difference)
+                mys[rr] = L.map_y[o];
+                vbyte[rr] = vptr[o];
+            }
+            __builtin_amdgcn_sched_barrier(0);    // all twelve in flight before anything else is scheduled
+#pragma unroll
+            for (int rr = 0; rr < kRowsPerWave; ++rr) inval[rr] = has_valid & (vbyte[rr] == 0);
         }
-        __builtin_amdgcn_sched_barrier(0);    // all twelve in flight before anything else is scheduled
-#pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) inval[rr] = has_valid & (vbyte[rr] == 0);
         uint32_t px[kRowsPerWave][4];
         if constexpr (kFastCubic) {
             cv_cubic_slots_rgb(L.src, L.src_stride, L.W, L.H, mxs, mys, L.cval, L.cubic_tab, s_wtab, px);
@@ -2334,9 +2378,17 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
         const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
         if (y >= L.h) break;
         int64_t o = (int64_t)y * L.w + xc;
-        float mx = L.map_x[o], my = L.map_y[o];      // 256 B per wavefront row, coalesced
+        float mx, my;
+        bool inval;
+        if (L.packed) {
+            const uint32_t hb = L.packed_hi[o];
+            planned_coords(L.packed[o], hb, INTERP == GS360_INTERP_NEAREST, mx, my);
+            inval = L.use_valid && !(hb & 4);
+        } else {
+            mx = L.map_x[o]; my = L.map_y[o];        // 256 B per wavefront row, coalesced
+            inval = L.valid && !L.valid[o];
+        }
         uint32_t px[4];
-        const bool inval = L.valid && !L.valid[o];
         if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
         else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
         else if constexpr (INTERP == GS360_INTERP_LANCZOS4) {
@@ -2683,6 +2735,13 @@ hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s) {
         case 4: launch_table_c<4>(B, grid, block, s); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_map_pack(const float* map_x, const float* map_y, const uint8_t* valid, int64_t n, int nearest,
+                           uint32_t* packed, uint8_t* packed_hi, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(map_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, map_x, map_y, valid, n, nearest, packed, packed_hi);
     return hipGetLastError();
 }
 

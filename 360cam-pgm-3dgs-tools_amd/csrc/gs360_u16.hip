@@ -70,17 +70,34 @@ __global__ __launch_bounds__(64 * kWaves) void table_remap_u16_kernel(const Tabl
     const uint8_t* __restrict__ vptr = vmask ? vmask : reinterpret_cast<const uint8_t*>(map_x);
     const bool has_valid = vmask != nullptr;
     uint8_t vbyte[kRowsPerWave];
+    if (T.packed) {                           // a map plan (wave-uniform): one dword and one byte per pixel, see gs360_kernels.hip
+        uint32_t pw[kRowsPerWave];
 #pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s) {
-        const size_t p = (size_t)min(ybase + s, th - 1) * tw + x;
-        mxs[s] = map_x[p];
-        mys[s] = map_y[p];
-        vbyte[s] = vptr[p];
-        done[s] = false;
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const size_t p = (size_t)min(ybase + s, th - 1) * tw + x;
+            pw[s] = T.packed[p];
+            vbyte[s] = T.packed_hi[p];
+            done[s] = false;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            planned_coords(pw[s], vbyte[s], INTERP == GS360_INTERP_NEAREST, mxs[s], mys[s]);
+            inval[s] = (T.use_valid != 0) & ((vbyte[s] & 4) == 0);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) {
+            const size_t p = (size_t)min(ybase + s, th - 1) * tw + x;
+            mxs[s] = map_x[p];
+            mys[s] = map_y[p];
+            vbyte[s] = vptr[p];
+            done[s] = false;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < kRowsPerWave; ++s) inval[s] = has_valid & (vbyte[s] == 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < kRowsPerWave; ++s) inval[s] = has_valid & (vbyte[s] == 0);
     if constexpr (C == 3) {
         // bilinear, RGB, windows inside the image: the two row reads of ALL four slots (dword-aligned 16-byte reads of the 12 tap
         // bytes) and their weight reads are issued before any is consumed; float32 blend in OpenCV's expression order

@@ -26,7 +26,7 @@ EXPORTS = (
     "gs360_device_info", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
     "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_dev_bswap16", "gs360_sync", "gs360_event_record",
     "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_equirect_views_masked_u8", "gs360_remap_table_u8",
-    "gs360_fisheye_views_u8", "gs360_remap_tables_u8",
+    "gs360_fisheye_views_u8", "gs360_remap_tables_u8", "gs360_map_plan_create", "gs360_map_plan_destroy", "gs360_remap_plans_u8", "gs360_remap_plans_u16",
     "gs360_color_plan_create", "gs360_color_plan_destroy", "gs360_color_apply_u8",
     "gs360_equirect_views_u8_host", "gs360_remap_table_u8_host",
     "gs360_equirect_views_u16", "gs360_remap_table_u16", "gs360_remap_tables_u16", "gs360_equirect_views_u16_host", "gs360_remap_table_u16_host",
@@ -109,6 +109,10 @@ def load_library(path=None):
         L.gs360_fisheye_views_u8.argtypes = [vp, pvp, C.POINTER(Calib), i, sz, C.POINTER(View), i, C.c_double, i, i, i,
                                              pvp, sz, pvp, i]
         L.gs360_remap_tables_u8.argtypes = [vp, C.POINTER(RemapJob), i, i, i, C.POINTER(C.c_double), i]
+        L.gs360_map_plan_create.argtypes = [vp, vp, vp, vp, i, i, i, i, pvp]
+        L.gs360_map_plan_destroy.argtypes = [vp, vp]
+        L.gs360_remap_plans_u8.argtypes = [vp, C.POINTER(RemapJob), pvp, i, i, i, C.POINTER(C.c_double), i]
+        L.gs360_remap_plans_u16.argtypes = L.gs360_remap_plans_u8.argtypes
         L.gs360_color_plan_create.argtypes = [vp, vp, i, vp, vp, pvp]
         L.gs360_color_plan_destroy.argtypes = [vp, vp]
         L.gs360_color_apply_u8.argtypes = [vp, vp, vp, i, i, i, sz, i, vp, sz, i]
@@ -344,6 +348,33 @@ class Context:
         bv = (C.c_double * 4)(*[float(x) for x in border_value])
         fn = self.L.gs360_remap_tables_u16 if np.dtype(dtype) == np.uint16 else self.L.gs360_remap_tables_u8
         _check(fn(self.handle, arr, len(jobs), Cn, interp, bv, slot), self.L)
+
+    # -- map plans: the float maps of a run packed once (include/gs360.h) -------------------------
+    MAP_PLAN_MAX_DIM = 4079
+
+    def map_plan(self, map_x, map_y, valid, h, w, nearest=False, slot=0):
+        """DeviceBuffers holding h x w float32 maps (+ uint8 valid or None) -> plan handle; the buffers may be freed afterwards."""
+        hnd = C.c_void_p()
+        _check(self.L.gs360_map_plan_create(self.handle, map_x.ptr, map_y.ptr, valid.ptr if valid is not None else None, int(h), int(w),
+                                            1 if nearest else 0, slot, C.byref(hnd)), self.L)
+        return hnd
+
+    def map_plan_free(self, plan):
+        if plan:
+            _check(self.L.gs360_map_plan_destroy(self.handle, plan), self.L)
+
+    def remap_plans_dev(self, jobs, Cn, interp=INTERP_LINEAR, border_value=(0, 0, 0, 0), slot=0, dtype=np.uint8):
+        """remap_tables_dev with plans: jobs = iterable of (src, H, W, plan, use_valid, h, w, fill_value, dst)."""
+        n = len(jobs)
+        arr = (RemapJob * n)()
+        pl = (C.c_void_p * n)()
+        for k, (src, H, W, plan, use_valid, h, w, fill, dst) in enumerate(jobs):
+            # valid: any non-NULL value asks for the plan's valid bit; the pointer is not read
+            arr[k] = RemapJob(src.ptr, H, W, 0, None, None, dst.ptr if use_valid else None, h, w, int(fill), dst.ptr, 0)
+            pl[k] = plan
+        bv = (C.c_double * 4)(*[float(x) for x in border_value])
+        fn = self.L.gs360_remap_plans_u16 if np.dtype(dtype) == np.uint16 else self.L.gs360_remap_plans_u8
+        _check(fn(self.handle, arr, pl, n, Cn, interp, bv, slot), self.L)
 
     def fisheye_views_dev(self, lens_bufs, calibs, Cn, views, lens_fov_deg, dsts, valid_outs=None,
                           interp=INTERP_LINEAR, mask_outside=True, mask_value=0, slot=0):

@@ -5,7 +5,13 @@ once per run and shares them between its worker threads, DF:2582-2592, DF:2776-2
 X/Y pair: upload the two lens images once, one table-remap launch per view (cv2.remap semantics + fused
 `out[~valid] = mask_value`), download.  `fused=True` evaluates the map in-kernel instead (FE-SPEC v1, no table
 traffic; <= 0.01 px from the reference tables).
+
+The tables of a run never change, so pairs go through MAP PLANS (include/gs360.h): each table converted once to the fixed
+point cv2.remap derives from it on every call, 5 bytes per pixel instead of 9 -- same results, less to read per pair.  Plans are made
+on first use per (view, sampler class); sources beyond 4079 pixels keep the float tables.  GS360_MAP_PLANS=0
+turns them off (A/B).
 """
+import os
 import threading
 from typing import Dict, List, Optional, Sequence
 
@@ -41,13 +47,34 @@ class PairRenderer:
                 self.dev_tables[vid] = (ctx.to_device(t["map_x"]), ctx.to_device(t["map_y"]),
                                         ctx.to_device(np.ascontiguousarray(t["valid"], np.uint8)))
         self._scratch = None                # grow-only output buffer shared by the per-view launches of a pair
+        self._plans = {}                    # (kind, id, nearest) -> map plan handle
+        self.use_plans = os.environ.get("GS360_MAP_PLANS", "1") not in ("0", "off", "no")
         self.dev_undistort = {}
         for sid, u in (undistort or {}).items():
             self.dev_undistort[sid] = (ctx.to_device(u.map_x), ctx.to_device(u.map_y),
                                        ctx.to_device(np.ascontiguousarray(u.valid_mask, np.uint8)))
 
     # ---------------------------------------------------------------------------------------------
-    def _remap(self, d_src, shape, maps, out_hw, interp, border, valid_fill, dtype=np.uint8):
+    def _plan(self, kind, key, maps, out_hw, interp, shape, dtype):
+        """-> the map plan for these tables and this sampler class, or None where plans do not apply"""
+        H, W = shape[0], shape[1]
+        if not self.use_plans or max(H, W) > self.ctx.MAP_PLAN_MAX_DIM:
+            return None
+        nearest = interp == capi.INTERP_NEAREST
+        k = (kind, key, nearest)
+        if k not in self._plans:
+            self._plans[k] = self.ctx.map_plan(maps[0], maps[1], maps[2], out_hw[0], out_hw[1], nearest=nearest, slot=0)
+        return self._plans[k]
+
+    def close(self):
+        """release the plans (the context's own close releases everything else)"""
+        with self.lock:
+            for plan in self._plans.values():
+                if self.ctx.handle:
+                    self.ctx.map_plan_free(plan)
+            self._plans.clear()
+
+    def _remap(self, d_src, shape, maps, out_hw, interp, border, valid_fill, dtype=np.uint8, plan_key=None):
         H, W, C = shape
         h, w = out_hw
         need = h * w * C * np.dtype(dtype).itemsize
@@ -55,9 +82,14 @@ class PairRenderer:
             if self._scratch is not None:
                 self.ctx.free(self._scratch)
             self._scratch = self.ctx.alloc(need)
-        self.ctx.remap_table_dev(d_src, H, W, C, maps[0], maps[1], maps[2] if valid_fill is not None else None, h, w,
-                                 self._scratch, interp=interp, border_value=border,
-                                 fill_value=valid_fill if valid_fill is not None else 0, slot=0, dtype=dtype)
+        plan = self._plan("undistort", plan_key, maps, out_hw, interp, shape, dtype) if plan_key is not None else None
+        if plan is not None:
+            self.ctx.remap_plans_dev([(d_src, H, W, plan, valid_fill is not None, h, w, valid_fill if valid_fill is not None else 0,
+                                       self._scratch)], C, interp=interp, border_value=border, slot=0, dtype=dtype)
+        else:
+            self.ctx.remap_table_dev(d_src, H, W, C, maps[0], maps[1], maps[2] if valid_fill is not None else None, h, w,
+                                     self._scratch, interp=interp, border_value=border,
+                                     fill_value=valid_fill if valid_fill is not None else 0, slot=0, dtype=dtype)
         return self.ctx.download(self._scratch, (h, w, C), dtype=dtype, slot=0)
 
     def _remap_views(self, dev, imgs, dmask, interp, border, valid_fill):
@@ -69,7 +101,7 @@ class PairRenderer:
                 raise RuntimeError("the two lens images differ in bit depth")
             dtype = np.uint16                 # CV_16U samplers, the same batched launch (gs360_remap_tables_u16)
         esz = np.dtype(dtype).itemsize
-        jobs, shapes, bufs = [], [], []
+        jobs, shapes, bufs, planned = [], [], [], []
         for spec in self.specs:
             vid = str(spec["view_id"])
             key = self.tables[vid]["lens_key"]
@@ -85,12 +117,18 @@ class PairRenderer:
             mx, my, va = self.dev_tables[vid]
             jobs.append((d_src, H, W, mx, my, va if valid_fill is not None else None, h, w,
                          valid_fill if valid_fill is not None else 0, d_dst))
+            plan = self._plan("view", vid, (mx, my, va), (h, w), interp, (H, W, C), dtype)
+            planned.append(None if plan is None else (d_src, H, W, plan, valid_fill is not None, h, w,
+                                                      valid_fill if valid_fill is not None else 0, d_dst))
             shapes.append((vid, (h, w, C)))
         try:
             channels = {s[1][2] for s in shapes}
             if len(channels) != 1:
                 raise RuntimeError("the two lens images differ in channel count")
-            self.ctx.remap_tables_dev(jobs, channels.pop(), interp=interp, border_value=border, slot=0, dtype=dtype)
+            if all(p is not None for p in planned):
+                self.ctx.remap_plans_dev(planned, channels.pop(), interp=interp, border_value=border, slot=0, dtype=dtype)
+            else:
+                self.ctx.remap_tables_dev(jobs, channels.pop(), interp=interp, border_value=border, slot=0, dtype=dtype)
             return {vid: self.ctx.download(b, shape, dtype=dtype, slot=0) for (vid, shape), b in zip(shapes, bufs)}
         finally:
             for b in bufs:
@@ -137,7 +175,7 @@ class PairRenderer:
                             raise RuntimeError("Resolution mismatch for {} lens: got {}x{}, expected {}x{}".format(
                                 key, imgs[key].shape[1], imgs[key].shape[0], c.width, c.height))
                         out["fisheye"][key] = self._remap(dev[key], imgs[key].shape, self.dev_undistort[sid],
-                                                          (c.height, c.width), interp, border, fill, dtype=imgs[key].dtype)
+                                                          (c.height, c.width), interp, border, fill, dtype=imgs[key].dtype, plan_key=sid)
                 if want_perspective:
                     if self.fused and imgs["X"].dtype == np.uint16:
                         raise RuntimeError("16-bit lens images need table mode (the fused-map kernel is 8-bit)")

@@ -182,6 +182,28 @@ int gs360_remap_tables_u8(gs360_ctx *ctx, const gs360_remap_job *jobs, int n_job
                           const double *border_value, int slot);
 
 /*
+ * Map plans.  cv2.remap converts its float maps to 1/32-pixel fixed point on every call before it samples; the dual-fisheye
+ * tool applies the SAME maps to every image pair of a run (DF:2582-2592).  A plan does the conversion once and keeps the result
+ * in 5 bytes per output pixel (position, phases, valid bit) instead of two floats and a valid byte: less to read per call, no
+ * conversion per pixel, identical results (integer positions are clamped to [-8, 4087], which leaves every position whose
+ * Lanczos-4 window still touches a source of up to 4079 x 4079 pixels untouched; larger sources are refused with
+ * GS360_ERR_UNSUPPORTED -- use the float maps).  map_x / map_y / valid are DEVICE pointers (h x w, valid may be NULL) and may be
+ * released when the call returns.  `nearest` != 0 packs cvRound(map) for GS360_INTERP_NEAREST (mask cutting, DF:2031-2043);
+ * a plan serves either nearest or the interpolating samplers (linear, cubic, Lanczos-4), 8- and 16-bit sources alike.
+ * gs360_remap_plans_u8 = gs360_remap_tables_u8 with plans[j] in place of jobs[j].map_x / map_y (ignored); jobs[j].valid != NULL
+ * asks for the plan's valid bit (fill_value where it is 0), the pointer itself is not read.
+ */
+typedef struct gs360_map_plan gs360_map_plan;
+int gs360_map_plan_create(gs360_ctx *ctx, const float *map_x, const float *map_y, const uint8_t *valid, int h, int w,
+                          int nearest, int slot, gs360_map_plan **out);
+int gs360_map_plan_destroy(gs360_ctx *ctx, gs360_map_plan *plan);
+int gs360_remap_plans_u8(gs360_ctx *ctx, const gs360_remap_job *jobs, const gs360_map_plan *const *plans, int n_jobs, int C,
+                         int interp, const double *border_value, int slot);
+/* the same on CV_16U sources (OpenCV converts the maps the same way for every depth): gs360_remap_tables_u16 with plans */
+int gs360_remap_plans_u16(gs360_ctx *ctx, const gs360_remap_job *jobs, const gs360_map_plan *const *plans, int n_jobs, int C,
+                          int interp, const double *border_value, int slot);
+
+/*
  * Dual-fisheye -> perspective views with the map evaluated in-kernel (FE-SPEC v1).  View k samples
  * src_lens[k] (H x W x C of calibs[k]) with views[k].yaw_deg measured RELATIVE to that lens
  * (DF:1883).  Pixels outside the lens model / sensor get mask_value on all channels when

@@ -262,6 +262,60 @@ def test_table_remap_random_maps(ctx, orc, channels, interp):
     _assert_same([got.reshape(h, w, channels)], [want.reshape(h, w, channels)], f"table C={channels} interp={interp}")
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("channels", [1, 3, 4])
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
+def test_table_remap_map_plans(ctx, orc, channels, interp, dtype):
+    """map plans (the float maps packed once: clamped 1/32-pixel fixed point + valid bit, 5 bytes per pixel) give cv2.remap's results:
+    random maps reaching 40 pixels outside the source, NaN / inf / huge values, exact ties, with and without the valid fill, two
+    jobs in one launch; plus what a plan refuses"""
+    H, W = 97, 131
+    src = rand_image(H, W, c=channels, seed=31)
+    if dtype == np.uint16:
+        src = (src.astype(np.uint16) << 8) | rand_image(H, W, c=channels, seed=30)
+    esz = np.dtype(dtype).itemsize
+    oracle_remap = orc.remap_u16 if dtype == np.uint16 else orc.remap_u8
+    d_src = ctx.to_device(src)
+    bv = (37.0, 0.0, 0.0, 0.0)
+    jobs, plans, wants, bufs = [], [], [], []
+    for k, (h, w, use_valid) in enumerate([(75, 108, True), (33, 200, False)]):
+        mx, my = _rand_maps(h, w, H, W, seed=32 + k, spread=40.0)
+        mx[3, 5] = np.nan
+        my[4, 6] = np.inf
+        mx[5, 7] = -3e9
+        my[6, 8] = 1e30
+        mx[7, :8] = np.array([-8.0, -8.03125, -9.0, W + 7.96875, W + 8.0, W + 9.0, 4087.0, 4088.5], np.float32)   # around the clamp
+        valid = np.random.default_rng(40 + k).random((h, w)) > 0.1
+        d = [ctx.to_device(mx), ctx.to_device(my), ctx.to_device(valid.astype(np.uint8))]
+        plan = ctx.map_plan(d[0], d[1], d[2], h, w, nearest=(interp == 0))
+        for b in d:
+            ctx.free(b)                                    # a plan keeps nothing of its inputs
+        dst = ctx.alloc(h * w * channels * esz)
+        bufs.append(dst)
+        plans.append(plan)
+        jobs.append((d_src, H, W, plan, use_valid, h, w, 200, dst))
+        want = oracle_remap(src, mx, my, interp=interp, border_value=bv)
+        wants.append(orc.valid_fill(want.copy(), valid, 200) if use_valid else want)
+    ctx.remap_plans_dev(jobs, channels, interp=interp, border_value=bv, dtype=dtype)
+    for k, (job, want) in enumerate(zip(jobs, wants)):
+        got = ctx.download(job[8], (job[5], job[6], channels), dtype=dtype)
+        _assert_same([got], [want.reshape(got.shape)], f"map plan job {k} C={channels} interp={interp} {np.dtype(dtype).name}")
+    # refusals: a plan packed for the other sampler class, another map size, a source too large for the packed positions
+    other = 1 if interp == 0 else 0
+    with pytest.raises(gs360.Gs360Error):
+        ctx.remap_plans_dev(jobs[:1], channels, interp=other, border_value=bv, dtype=dtype)
+    with pytest.raises(gs360.Gs360Error):
+        ctx.remap_plans_dev([(d_src, H, W, plans[0], False, 74, 108, 0, bufs[0])], channels, interp=interp, border_value=bv, dtype=dtype)
+    with pytest.raises(gs360.Gs360Error) as exc:
+        ctx.remap_plans_dev([(d_src, 2, 4080, plans[0], False, 75, 108, 0, bufs[0])], channels, interp=interp, border_value=bv, dtype=dtype)
+    assert exc.value.code == -4
+    for pl in plans:
+        ctx.map_plan_free(pl)
+    for b in bufs:
+        ctx.free(b)
+    ctx.free(d_src)
+
+
 @pytest.mark.parametrize("persist", ["0", "8", "24"])
 def test_bicubic_persistent_workgroups_walk_every_tile(ctx, orc, persist, monkeypatch):
     """The bicubic RGB kernels (table + fused fisheye) cap their grid and let each workgroup walk tiles b, b + gridDim.x, ...;

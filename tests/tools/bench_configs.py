@@ -153,22 +153,51 @@ def fisheye_cfg(ctx, steps):
                 "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_table / 1e6, 1),
                 "achieved_GB_per_s": round(algo_table / ms / 1e6, 0), "frac_of_8TBps": round(algo_table / ms / 1e6 / 8000, 3),
                 "parity_vs_oracle": bool(np.array_equal(got, want))})
+    # the same launch through MAP PLANS: the float tables packed once (5 bytes per pixel instead of 9), as the drop-in CLI runs 8-bit pairs
+    plans = {s["view_id"]: {nearest: None for nearest in (False, True)} for s in specs}
+    for interp, label in ((1, "linear"), (2, "cubic")):
+        for s in specs:
+            if plans[s["view_id"]][False] is None:
+                plans[s["view_id"]][False] = ctx.map_plan(*d_tab[s["view_id"]], 1750, 1750, nearest=False)
+        pjobs = [(dev[tables[s["view_id"]]["lens_key"]], 4000, 4000, plans[s["view_id"]][False], True, 1750, 1750, 0, d_out[s["view_id"]])
+                 for s in specs]
+
+        def plan_call():
+            ctx.remap_plans_dev(pjobs, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0)
+        ms = time_steps(ctx, plan_call, steps)
+        got = ctx.download(d_out[v0], (1750, 1750, 3))
+        want_i = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=interp, threads=0), t["valid"], 0)
+        algo_plan = px * (3 + 4 + 1) + uv * 3
+        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, TABLE mode through map plans, {label}", "ms_per_pair": round(ms, 4),
+                    "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_plan / 1e6, 1),
+                    "achieved_GB_per_s": round(algo_plan / ms / 1e6, 0), "frac_of_8TBps": round(algo_plan / ms / 1e6 / 8000, 3),
+                    "frac_on_float_map_bytes": round(algo_table / ms / 1e6 / 8000, 3),
+                    "parity_vs_oracle": bool(np.array_equal(got, want_i))})
     # the same pair as 16-bit images: CV_16U samplers, all six views in one batched launch (gs360_remap_tables_u16)
     imgs16 = {k: (v.astype(np.uint16) * 257) ^ np.uint16(3) for k, v in imgs.items()}
     dev16 = {k: ctx.to_device(v) for k, v in imgs16.items()}
     d_out16 = {s["view_id"]: ctx.alloc(1750 * 1750 * 6) for s in specs}
     jobs16 = [(dev16[tables[s["view_id"]]["lens_key"]], 4000, 4000) + tuple(d_tab[s["view_id"]]) + (1750, 1750, 0, d_out16[s["view_id"]])
               for s in specs]
+    pjobs16 = [(dev16[tables[s["view_id"]]["lens_key"]], 4000, 4000, plans[s["view_id"]][False], True, 1750, 1750, 0, d_out16[s["view_id"]])
+               for s in specs]
     timed16 = []
-    for interp, label in ((1, "linear"), (2, "cubic")):     # time both first: the oracle's OpenMP team spins on the host afterwards
-        def u16_call():
-            ctx.remap_tables_dev(jobs16, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0, dtype=np.uint16)
-        ms16 = time_steps(ctx, u16_call, steps)
-        timed16.append((interp, label, ms16, ctx.download(d_out16[specs[-1]["view_id"]], (1750, 1750, 3), dtype=np.uint16)))
-    for interp, label, ms16, got16 in timed16:
+    for planned in (False, True):
+        for interp, label in ((1, "linear"), (2, "cubic")):     # time all first: the oracle's OpenMP team spins on the host afterwards
+            def u16_call():
+                if planned:
+                    ctx.remap_plans_dev(pjobs16, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0, dtype=np.uint16)
+                else:
+                    ctx.remap_tables_dev(jobs16, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0, dtype=np.uint16)
+            ms16 = time_steps(ctx, u16_call, steps)
+            timed16.append((interp, label + (", map plans" if planned else ""), ms16, 4 if planned else 8,
+                            ctx.download(d_out16[specs[-1]["view_id"]], (1750, 1750, 3), dtype=np.uint16)))
+    for s in specs:
+        ctx.map_plan_free(plans[s["view_id"]][False])
+    for interp, label, ms16, map_bytes, got16 in timed16:
         t_last = tables[specs[-1]["view_id"]]
         want16 = orc.valid_fill(orc.remap_u16(imgs16[t_last["lens_key"]], t_last["map_x"], t_last["map_y"], interp=interp, threads=0), t_last["valid"], 0)
-        algo16 = px * (6 + 8 + 1) + uv * 6
+        algo16 = px * (6 + map_bytes + 1) + uv * 6
         res.append({"config": f"cfg4 shape on 16-bit lens images, TABLE mode, CV_16U {label}, one batched launch", "ms_per_pair": round(ms16, 4),
                     "MPix_per_s": round(px / ms16 / 1e3, 0), "algorithmic_MB_per_pair": round(algo16 / 1e6, 1),
                     "achieved_GB_per_s": round(algo16 / ms16 / 1e6, 0), "frac_of_8TBps": round(algo16 / ms16 / 1e6 / 8000, 3),
@@ -271,16 +300,24 @@ def cfg4_rows(ctx, steps, interps=((1, "linear"), (2, "cubic"))):
     algo = px * (3 + 8 + 1) + uv * 3
     v0 = specs[1]["view_id"]
     t = tables[v0]
+    # the tables as map plans (packed once, 5 bytes per pixel instead of 9: how the drop-in CLI applies them to every pair of a run)
+    plans = {s["view_id"]: ctx.map_plan(*d_tab[s["view_id"]], 1750, 1750, nearest=False) for s in specs}
+    pjobs = [(dev[tables[s["view_id"]]["lens_key"]], 4000, 4000, plans[s["view_id"]], True, 1750, 1750, 0, d_out[s["view_id"]]) for s in specs]
+    algo_plan = px * (3 + 4 + 1) + uv * 3
     timed = []
     for interp, label in interps:           # time everything first: the oracle's OpenMP team spins on the host afterwards
         ms = time_steps(ctx, lambda: ctx.remap_tables_dev(jobs, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0), steps)
-        timed.append((interp, label, ms, ctx.download(d_out[v0], (1750, 1750, 3))))
+        timed.append((interp, label, ms, algo, ctx.download(d_out[v0], (1750, 1750, 3))))
+        ms = time_steps(ctx, lambda: ctx.remap_plans_dev(pjobs, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0), steps)
+        timed.append((interp, label + ", map plans", ms, algo_plan, ctx.download(d_out[v0], (1750, 1750, 3))))
     res = []
-    for interp, label, ms, got in timed:
+    for interp, label, ms, ab, got in timed:
         want = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=interp, threads=0), t["valid"], 0)
-        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, table mode, {label}", "ms_per_pair": round(ms, 4),
-                    "algorithmic_MB_per_pair": round(algo / 1e6, 1), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
+        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, table mode, {label}", "key": label.replace(", map plans", "-plans"),
+                    "ms_per_pair": round(ms, 4), "algorithmic_MB_per_pair": round(ab / 1e6, 1), "frac_of_8TBps": round(ab / ms / 1e6 / 8000, 3),
                     "parity_vs_oracle": bool(np.array_equal(got, want))})
+    for pl in plans.values():
+        ctx.map_plan_free(pl)
     for b in list(dev.values()) + [x for tup in d_tab.values() for x in tup] + list(d_out.values()):
         ctx.free(b)
     return res
@@ -307,7 +344,7 @@ def secondary_rows(ctx, steps=20):
         out.append({"config": key, "workload": name, "unit": "frame", "us_per_unit": r["us_per_frame"], "frac": r["frac_of_8TBps"],
                     "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "parity_vs_oracle": r["parity_vs_oracle"]})
     for r in cfg4_rows(ctx, steps):
-        out.append({"config": "cfg4-" + r["config"].rsplit(", ", 1)[1], "workload": r["config"], "unit": "lens pair",
+        out.append({"config": "cfg4-" + r["key"], "workload": r["config"], "unit": "lens pair",
                     "us_per_unit": round(r["ms_per_pair"] * 1e3, 1), "frac": r["frac_of_8TBps"],
                     "algorithmic_MB_per_unit": r["algorithmic_MB_per_pair"], "parity_vs_oracle": r["parity_vs_oracle"]})
     return out
