@@ -138,15 +138,37 @@ def fuzz_table(ctx, rng, case):
     bv = tuple(float(v) for v in rng.integers(0, 256, 4))
     valid = (rng.random((h, w)) > 0.2) if rng.random() < 0.5 else None
     fill = int(rng.integers(0, 256))
-    got = ctx.remap(src, mx, my, interpolation=interp, border_value=bv, valid=valid, fill_value=fill)
+    planned = rng.random() < 0.5       # half of the cases through a map plan (the tables packed once; gs360_remap_plans_u8)
+    if planned:
+        got = _remap_planned(ctx, src, mx, my, valid, interp, bv, fill, np.uint8)
+    else:
+        got = ctx.remap(src, mx, my, interpolation=interp, border_value=bv, valid=valid, fill_value=fill)
     want = orc.remap_u8(src, mx, my, interp=interp, border_value=bv, threads=0)
     if valid is not None:
         want = orc.valid_fill(want.copy(), valid, fill)
     if not np.array_equal(got.reshape(want.shape), want):
         bad = np.argwhere(got.reshape(want.shape) != want)
-        print(f"[table] case {case}: src {W}x{H}x{c} map {w}x{h} kind={kind} interp={interp}: {len(bad)} bytes differ, first at {bad[0].tolist()}")
+        print(f"[table] case {case}: src {W}x{H}x{c} map {w}x{h} kind={kind} interp={interp} planned={planned}: {len(bad)} bytes differ, "
+              f"first at {bad[0].tolist()}")
         return False
     return True
+
+
+def _remap_planned(ctx, src, mx, my, valid, interp, bv, fill, dtype):
+    H, W, c = src.shape
+    h, w = mx.shape
+    d = [ctx.to_device(np.ascontiguousarray(src)), ctx.to_device(np.ascontiguousarray(mx)), ctx.to_device(np.ascontiguousarray(my)),
+         ctx.to_device(np.ascontiguousarray(valid, dtype=np.uint8)) if valid is not None else None,
+         ctx.alloc(h * w * c * np.dtype(dtype).itemsize)]
+    plan = ctx.map_plan(d[1], d[2], d[3], h, w, nearest=(interp == 0))
+    try:
+        ctx.remap_plans_dev([(d[0], H, W, plan, valid is not None, h, w, fill, d[4])], c, interp=interp, border_value=bv, dtype=dtype)
+        return ctx.download(d[4], (h, w, c), dtype=dtype)
+    finally:
+        ctx.map_plan_free(plan)
+        for b in d:
+            if b is not None:
+                ctx.free(b)
 
 
 def fuzz_fisheye(ctx, rng, case):
@@ -256,7 +278,10 @@ def fuzz_u16(ctx, rng, case):
         bv = tuple(float(v) for v in rng.integers(0, 70000, 4))
         valid = (rng.random((h, w)) > 0.2) if rng.random() < 0.5 else None
         fill = int(rng.integers(0, 65536))
-        got = ctx.remap(src, mx, my, interpolation=interp, border_value=bv, valid=valid, fill_value=fill)
+        if rng.random() < 0.5:
+            got = _remap_planned(ctx, src, mx, my, valid, interp, bv, fill, np.uint16)
+        else:
+            got = ctx.remap(src, mx, my, interpolation=interp, border_value=bv, valid=valid, fill_value=fill)
         want = orc.remap_u16(src, mx, my, interp=interp, border_value=bv, threads=0)
         if valid is not None:
             want = orc.valid_fill(want.copy(), valid, fill)
