@@ -84,6 +84,7 @@ struct TableLaunch {
     const uint32_t* packed;     // x + 8 (12 bits) | y + 8 (12 bits) | x phase (5 bits) | low 3 bits of the y phase
     const uint8_t* packed_hi;   // high 2 bits of the y phase | valid << 2
     int32_t use_valid;          // with a plan: apply its valid bit (the `valid` pointer of the float form)
+    int32_t flat;               // row slots take spans of the flat output instead of row segments (table_remap_tile)
     uint8_t* dst;
     int32_t H, W, h, w;
     int64_t src_stride, dst_stride;

@@ -2302,6 +2302,21 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
     const int n_px = min(kTileW, L.w - x0);
     const int xc = min(x0 + lane, L.w - 1);
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
+    // FLAT form (L.flat, set on the host for a tight, dword-aligned output whose rows are not whole dwords -- the tool's default 1750-pixel
+    // views have 5250-byte rows, and a row that starts off a dword boundary leaves as three byte stores per pixel).  The output is
+    // then addressed by the flat pixel number p = y w + x, as the maps, valid flags and plans are anyway, and "row y" becomes the span
+    // [r(y), r(y + 1)) with r(y) = y w rounded up to a multiple of four (r(h) = h w): up to three pixels at the start of a row belong
+    // to the span above.  Every span, and every 64-pixel tile cut from it, starts on a 12-byte = dword boundary of the tight output
+    // whatever the width; a span is at most w + 3 pixels long (the host adds that to the tile count).  h w < 2^30: 32-bit indices.
+    const bool flat = uniform_here(L.flat) != 0;
+    const int n_flat = uniform_here(L.h * L.w);
+    auto slot_span = [&](const int y, int& first, int& n) {           // first flat pixel of lane 0 and the pixels to store, for row slot y
+        const int yc = min(y, L.h - 1);
+        const int r0 = (yc * L.w + 3) & ~3;
+        const int r1 = yc + 1 < L.h ? ((yc + 1) * L.w + 3) & ~3 : n_flat;
+        first = r0 + x0;
+        n = y < L.h ? max(0, min(kTileW, r1 - first)) : 0;
+    };
     constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
     if ((INTERP == GS360_INTERP_LINEAR || INTERP == GS360_INTERP_NEAREST || kFastCubic) && L.pipelined) {
         // maps of the wavefront's 4 rows -> all gathers in flight -> blend -> border/valid fix-ups -> packed stores
@@ -2314,11 +2329,24 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
         const uint8_t* __restrict__ vptr = L.valid ? L.valid : reinterpret_cast<const uint8_t*>(L.map_x);
         const bool has_valid = L.valid != nullptr;
         uint8_t vbyte[kRowsPerWave];
+        int first[kRowsPerWave], n_st[kRowsPerWave];      // flat form: the slot's first pixel and its pixel count (wave-uniform)
+        uint32_t idx[kRowsPerWave];                       // this lane's map entry (clamped to a readable one)
+#pragma unroll
+        for (int rr = 0; rr < kRowsPerWave; ++rr) {
+            if (flat) {
+                slot_span(ybase + rr, first[rr], n_st[rr]);
+                idx[rr] = (uint32_t)min(first[rr] + lane, n_flat - 1);
+            } else {
+                first[rr] = 0;
+                n_st[rr] = 0;
+                idx[rr] = (uint32_t)(min(ybase + rr, L.h - 1) * L.w + xc);
+            }
+        }
         if (L.packed) {                       // a map plan (wave-uniform): one dword and one byte per pixel
             uint32_t pw[kRowsPerWave];
 #pragma unroll
             for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
+                const uint32_t o = idx[rr];
                 pw[rr] = L.packed[o];
                 vbyte[rr] = L.packed_hi[o];
             }
@@ -2331,7 +2359,7 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
         } else {
 #pragma unroll
             for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                const int64_t o = (int64_t)min(ybase + rr, L.h - 1) * L.w + xc;
+                const uint32_t o = idx[rr];
                 mxs[rr] = L.map_x[o];         // (non-temporal map loads were measured: no difference)
                 mys[rr] = L.map_y[o];
                 vbyte[rr] = vptr[o];
@@ -2370,14 +2398,23 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
                 for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.fill;
             }
             const int y = ybase + rr;
-            if (y < L.h) store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
+            if (flat) {
+                if (n_st[rr] > 0) store_row<C>(L.dst + (size_t)(uint32_t)(first[rr] * C), px[rr], n_st[rr], true, rp);
+            } else if (y < L.h) {
+                store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
+            }
         }
         return;
     }
     for (int rr = 0; rr < kRowsPerWave; ++rr) {
         const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
         if (y >= L.h) break;
-        int64_t o = (int64_t)y * L.w + xc;
+        int first = 0, n_st = 0;
+        if (flat) {
+            slot_span(y, first, n_st);
+            if (n_st == 0) continue;
+        }
+        int64_t o = flat ? (int64_t)min(first + lane, n_flat - 1) : (int64_t)y * L.w + xc;
         float mx, my;
         bool inval;
         if (L.packed) {
@@ -2406,7 +2443,8 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
 #pragma unroll
             for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.fill;
         }
-        store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4, rp);
+        if (flat) store_row<C>(L.dst + (size_t)(uint32_t)(first * C), px, n_st, true, rp);
+        else store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4, rp);
     }
 }
 
@@ -2717,7 +2755,7 @@ hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s) {
     int base = 0;
     for (int j = 0; j < B.n_jobs; ++j) {
         TableLaunch& L = B.job[j];
-        L.tiles_x = (L.w + kTileW - 1) / kTileW;
+        L.tiles_x = (L.w + (L.flat ? 3 : 0) + kTileW - 1) / kTileW;      // (flat form: a row's span may be three pixels longer)
         L.tile_base = base;
         base += L.tiles_x * ((L.h + kTileH - 1) / kTileH);
     }

@@ -278,13 +278,15 @@ def test_table_remap_map_plans(ctx, orc, channels, interp, dtype):
     d_src = ctx.to_device(src)
     bv = (37.0, 0.0, 0.0, 0.0)
     jobs, plans, wants, bufs = [], [], [], []
-    for k, (h, w, use_valid) in enumerate([(75, 108, True), (33, 200, False)]):
+    # (widths that are / are not multiples of four, a last group of 1-3 pixels, a map narrower than one group of four pixels)
+    for k, (h, w, use_valid) in enumerate([(75, 108, True), (33, 200, False), (41, 77, True), (23, 254, True), (9, 3, False)]):
         mx, my = _rand_maps(h, w, H, W, seed=32 + k, spread=40.0)
-        mx[3, 5] = np.nan
-        my[4, 6] = np.inf
-        mx[5, 7] = -3e9
-        my[6, 8] = 1e30
-        mx[7, :8] = np.array([-8.0, -8.03125, -9.0, W + 7.96875, W + 8.0, W + 9.0, 4087.0, 4088.5], np.float32)   # around the clamp
+        if w > 8:
+            mx[3, 5] = np.nan
+            my[4, 6] = np.inf
+            mx[5, 7] = -3e9
+            my[6, 8] = 1e30
+            mx[7, :8] = np.array([-8.0, -8.03125, -9.0, W + 7.96875, W + 8.0, W + 9.0, 4087.0, 4088.5], np.float32)   # around the clamp
         valid = np.random.default_rng(40 + k).random((h, w)) > 0.1
         d = [ctx.to_device(mx), ctx.to_device(my), ctx.to_device(valid.astype(np.uint8))]
         plan = ctx.map_plan(d[0], d[1], d[2], h, w, nearest=(interp == 0))
