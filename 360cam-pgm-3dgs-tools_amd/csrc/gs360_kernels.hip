@@ -2183,19 +2183,19 @@ struct CvTaps {
     bool fast;
 };
 
+// (sx, sy: the 1/32-pixel fixed point cv2.remap derives from the maps, cvRound(map * 32); a map plan holds them ready-made)
 template <int C>
-__device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                                     float mx, float my) {
-    const int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
+__device__ __forceinline__ CvTaps<C> cv_fetch_linear_fx(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
+                                                        const int sx, const int sy) {
     const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
     constexpr int kBack = (C == 3) ? 5 : 2;
     CvTaps<C> t;
     t.fx = sx & 31;
     t.fy = sy & 31;
-    t.fast = ix >= 0 && iy >= 0 && ix <= W - kBack && iy < H - 1;
-    const int xa = min(max(ix, 0), W - kBack), ya = min(max(iy, 0), H - 1), yb = min(ya + 1, H - 1);
-    const uint32_t col = (uint32_t)xa * C;
-    const uint32_t o0 = __umul24((uint32_t)ya, (uint32_t)stride) + col, o1 = __umul24((uint32_t)yb, (uint32_t)stride) + col;
+    t.fast = (uint32_t)ix <= (uint32_t)(W - kBack) && (uint32_t)iy < (uint32_t)(H - 1);       // both >= 0 and inside (W >= 8)
+    // a window that is not `fast` is redone by the border sampler: its reads only have to be readable -- the image's first bytes
+    const uint32_t o0 = t.fast ? __umul24((uint32_t)iy, (uint32_t)stride) + (uint32_t)ix * C : 0u;
+    const uint32_t o1 = o0 + (t.fast ? (uint32_t)stride : 0u);
     const uint8_t* r0 = src + o0;
     const uint8_t* r1 = src + o1;
     if constexpr (C == 1) {
@@ -2211,6 +2211,10 @@ __device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__
         t.t1 = ld_u64(r1);
     }
     return t;
+}
+template <int C>
+__device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__ src, int64_t stride, int W, int H, float mx, float my) {
+    return cv_fetch_linear_fx<C>(src, stride, W, H, cv_round(mx * 32.0f), cv_round(my * 32.0f));
 }
 
 template <int C>
@@ -2329,6 +2333,7 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
         const uint8_t* __restrict__ vptr = L.valid ? L.valid : reinterpret_cast<const uint8_t*>(L.map_x);
         const bool has_valid = L.valid != nullptr;
         uint8_t vbyte[kRowsPerWave];
+        int sxi[kRowsPerWave] = {0, 0, 0, 0}, syi[kRowsPerWave] = {0, 0, 0, 0};   // bilinear: the positions in 1/32-pixel fixed point
         int first[kRowsPerWave], n_st[kRowsPerWave];      // flat form: the slot's first pixel and its pixel count (wave-uniform)
         uint32_t idx[kRowsPerWave];                       // this lane's map entry (clamped to a readable one)
 #pragma unroll
@@ -2355,6 +2360,9 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
             for (int rr = 0; rr < kRowsPerWave; ++rr) {
                 planned_coords(pw[rr], vbyte[rr], INTERP == GS360_INTERP_NEAREST, mxs[rr], mys[rr]);
                 inval[rr] = (L.use_valid != 0) & ((vbyte[rr] & 4) == 0);
+                // the bilinear fetch takes the fixed point as it is packed (the floats are for the border / bicubic paths)
+                sxi[rr] = ((int)(pw[rr] & 0xfffu) - 8) * 32 + (int)((pw[rr] >> 24) & 31u);
+                syi[rr] = ((int)((pw[rr] >> 12) & 0xfffu) - 8) * 32 + (int)((pw[rr] >> 29) | ((vbyte[rr] & 3u) << 3));
             }
         } else {
 #pragma unroll
@@ -2366,7 +2374,13 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
             }
             __builtin_amdgcn_sched_barrier(0);    // all twelve in flight before anything else is scheduled
 #pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) inval[rr] = has_valid & (vbyte[rr] == 0);
+            for (int rr = 0; rr < kRowsPerWave; ++rr) {
+                inval[rr] = has_valid & (vbyte[rr] == 0);
+                if constexpr (INTERP == GS360_INTERP_LINEAR) {
+                    sxi[rr] = cv_round(mxs[rr] * 32.0f);
+                    syi[rr] = cv_round(mys[rr] * 32.0f);
+                }
+            }
         }
         uint32_t px[kRowsPerWave][4];
         if constexpr (kFastCubic) {
@@ -2379,7 +2393,7 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
             bool any_slow = false;
 #pragma unroll
             for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                taps[rr] = cv_fetch_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr]);
+                taps[rr] = cv_fetch_linear_fx<C>(L.src, L.src_stride, L.W, L.H, sxi[rr], syi[rr]);
                 any_slow |= !taps[rr].fast;
             }
             __builtin_amdgcn_sched_barrier(0);    // every gather of the wavefront's four rows in flight before the first is consumed
