@@ -629,7 +629,9 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[k].width;
             const double px = (double)views[k].width * (double)views[k].height;
             px_all += px;
-            if (!ev[k].level && !ev[k].fish && step >= 1.75) px_win += px;
+            // (views whose rows are not whole dwords: the staged kernel would write them byte by byte, the gather kernels have a dword path)
+            const size_t row_bytes = dst_stride ? dst_stride : (size_t)views[k].width * 3;
+            if (!ev[k].level && !ev[k].fish && step >= 1.75 && (row_bytes & 3) == 0 && (views[k].width & 3) == 0) px_win += px;
         }
         if (can && (mode == 1 || 2.0 * px_win > px_all))
             for (int k = 0; k < n_views; ++k) {

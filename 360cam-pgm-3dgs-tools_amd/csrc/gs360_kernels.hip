@@ -189,7 +189,8 @@ __device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s
 // row leaves as 4-byte stores (lane j writes bytes 4j..4j+3 = tail of pixel 4j/3 + head of the next one).
 // skip_first drops position 0 (the centre column of an odd-width view, which is its own mirror); the caller then
 // passes aligned4 = false and the per-lane byte path below handles it.
-template <int C>
+// SHIFTED = false leaves the off-boundary dword path out (the bicubic equirect kernels sit at their register limit).
+template <int C, bool SHIFTED = true>
 __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4, const RowPack& rp,
                                           bool reversed = false, bool skip_first = false) {
     const int lane = rp.lane;
@@ -205,6 +206,24 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
             if (lane < full && !((GS360_PROBE & 2) && dw != 0x12345678u)) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
             if (lane == full && rem)
                 for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
+            return;
+        }
+        if (SHIFTED && !skip_first) {
+            // a segment that starts off a dword boundary (widths that are not multiples of four): the same two shuffles, the segment's
+            // byte stream re-sliced at its own misalignment -- lanes 0..47 write the aligned dwords inside it, lanes 48..50 its 0-3 head
+            // bytes, lanes 52..54 its 0-3 tail bytes (one dword store + one byte store instead of three byte stores per pixel)
+            const uint32_t packed = px[0] | (px[1] << 8) | (px[2] << 16);
+            const int n_bytes = 3 * n_px;
+            const int dh = (int)((0u - (uint32_t)reinterpret_cast<uintptr_t>(row)) & 3u);      // head bytes
+            const int nf = (n_bytes - dh) >> 2, tl = (n_bytes - dh) & 3, k = lane & 3;
+            const int sj = lane < 48 ? 4 * lane + dh : (lane < 52 ? k : dh + 4 * nf + k);     // first stream byte of this lane's piece
+            const int a = (sj * 21846) >> 16, b = sj - 3 * a;                                 // pixel, byte in it
+            const int qa = min(a, n_px - 1), qb = min(a + 1, n_px - 1);
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (reversed ? n_px - 1 - qa : qa), (int)packed);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (reversed ? n_px - 1 - qb : qb), (int)packed);
+            const uint32_t dw = __builtin_amdgcn_perm(pb, pa, b == 0 ? 0x04020100u : (b == 1 ? 0x05040201u : 0x06050402u));
+            if (lane < nf) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(__builtin_assume_aligned(row + sj, 4)));
+            else if ((lane >= 48 && lane < 52 && k < dh) || (lane >= 52 && lane < 56 && k < tl)) row[sj] = (uint8_t)dw;
             return;
         }
     }
@@ -586,7 +605,7 @@ __device__ __forceinline__ uint32_t eq_mask_at(const EqSrc& L, const uint8_t* __
 // Hand the wavefront's pixels to memory: blocked patches (store_patch_rgb) or one row per slot (store_row).
 // MODE (compile time; the kernel switches once per tile, outside the ring-member loop, so that each loop body carries only
 // its own lane map's invariants): 0 = one row per slot, 1 = blocked patches of a general view, 2 = blocked level view.
-template <int C, int MODE>
+template <int C, int MODE, bool SHIFTED = true>
 __device__ __forceinline__ void eq_store(uint8_t* dst, int64_t dstride, const uint32_t (&px)[kRowsPerWave][4],
                                          const int (&ys)[kRowsPerWave], const bool (&row_ok)[kRowsPerWave],
                                          int col0, int n_px, bool reversed, bool aligned4, bool skip_first,
@@ -610,7 +629,7 @@ __device__ __forceinline__ void eq_store(uint8_t* dst, int64_t dstride, const ui
     }
 #pragma unroll
     for (int s = 0; s < kRowsPerWave; ++s)
-        if (row_ok[s]) store_row<C>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, rp, reversed, skip_first);
+        if (row_ok[s]) store_row<C, SHIFTED>(dst + (int64_t)ys[s] * dstride + (int64_t)col0 * C, px[s], n_px, aligned4, rp, reversed, skip_first);
 }
 
 // The bilinear pass in two steps, so that the ring-member loop can put the NEXT pass's gathers in flight before the current
@@ -687,7 +706,7 @@ __device__ __forceinline__ void eq_pass(const EqSrc& L, const uint8_t* __restric
             for (int s = 0; s < kRowsPerWave; ++s)
                 if (!(eq_mask_at(L, mask, sxs[s], sys[s]) & 1u)) px[s][0] = px[s][1] = px[s][2] = px[s][3] = 0;
         }
-        eq_store<C, MODE>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, blk, rp);
+        eq_store<C, MODE, false>(dst, dstride, px, ys, row_ok, col0, n_px, reversed, aligned4, skip_first, blk, rp);
         return;
     }
     EqPassTaps<C, MASKED> T;
@@ -1318,6 +1337,7 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
             }
         };
         const int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
+        const bool ofs32_ok = (uint64_t)out_h * (uint64_t)dstride < 0xffffffffull;      // row offsets of the shifted store path are 32-bit
         auto store_pass = [&](const uint32_t (&pk)[kRowsPerWave], uint8_t* const d, const bool flip, const bool mirror) {
             if (mirror && !has_mirror) return;
             const bool aligned = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(d) & 3) == 0) &&
@@ -1348,6 +1368,37 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                     if (lane < full && !((GS360_PROBE & 2) && dw[s] != 0x12345678u)) __builtin_nontemporal_store(dw[s], reinterpret_cast<uint32_t*>(row + (size_t)off));
                     if (rem && lane == full)
                         for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw[s] >> (8 * k));
+                }
+                return;
+            }
+            if (!(mirror && centre_dup) && ofs32_ok) {
+                // Row segments that start off a dword boundary (widths that are not multiples of four: 5250-byte rows of a 1750-pixel
+                // view): the same two shuffles per slot, with the byte stream of the segment re-sliced at the row's own misalignment.
+                // Lanes 0..47 write the aligned dwords inside the segment, lanes 48..50 its 0-3 head bytes, lanes 52..54 its 0-3 tail
+                // bytes -- one dword store and one byte store per slot instead of three byte stores per pixel (+61 % per frame).
+                uint32_t dwv[kRowsPerWave], adr[kRowsPerWave];
+                bool as_dword[kRowsPerWave], as_byte[kRowsPerWave];
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s) {
+                    const uint32_t rofs = (uint32_t)(flip ? out_h - 1 - ys[s] : ys[s]) * (uint32_t)dstride;          // (ofs32_ok)
+                    const int dh = (int)((0u - ((uint32_t)reinterpret_cast<uintptr_t>(d0) + rofs)) & 3u);             // head bytes of this row's segment
+                    const int nf = (n_bytes - dh) >> 2, tl = (n_bytes - dh) & 3;
+                    const int k = lane & 3;
+                    const int sj = lane < 48 ? 4 * lane + dh : (lane < 52 ? k : dh + 4 * nf + k);                   // first stream byte of this lane's piece
+                    as_dword[s] = lane < nf;
+                    as_byte[s] = (lane >= 48 && lane < 52 && k < dh) || (lane >= 52 && lane < 56 && k < tl);
+                    const int a = (sj * 21846) >> 16, b = sj - 3 * a;                                               // pixel, byte in it
+                    const int qa = min(a, n_px - 1), qb = min(a + 1, n_px - 1);
+                    const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (mirror ? n_px - 1 - qa : qa), (int)pk[s]);
+                    const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (mirror ? n_px - 1 - qb : qb), (int)pk[s]);
+                    dwv[s] = __builtin_amdgcn_perm(pb, pa, b == 0 ? 0x04020100u : (b == 1 ? 0x05040201u : 0x06050402u));
+                    adr[s] = rofs + (uint32_t)sj;
+                }
+#pragma unroll
+                for (int s = 0; s < kRowsPerWave; ++s) {
+                    if (!row_ok[s]) continue;
+                    if (as_dword[s]) __builtin_nontemporal_store(dwv[s], reinterpret_cast<uint32_t*>(__builtin_assume_aligned(d0 + (size_t)adr[s], 4)));
+                    else if (as_byte[s]) d0[(size_t)adr[s]] = (uint8_t)dwv[s];
                 }
                 return;
             }
@@ -2305,6 +2356,8 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
     const int x0 = tile_x * kTileW;
     const int n_px = min(kTileW, L.w - x0);
     const int xc = min(x0 + lane, L.w - 1);
+    // (rows off a dword boundary take the byte stores here -- store_row<C, false>: the re-sliced dword path that pays in the equirect
+    // kernels costs these kernels 12-15 %, cfg4 through plans 51 -> 59 us per pair)
     const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
     // FLAT form (L.flat, set on the host for a tight, dword-aligned output whose rows are not whole dwords -- the tool's default 1750-pixel
     // views have 5250-byte rows, and a row that starts off a dword boundary leaves as three byte stores per pixel).  The output is
@@ -2415,7 +2468,7 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
             if (flat) {
                 if (n_st[rr] > 0) store_row<C>(L.dst + (size_t)(uint32_t)(first[rr] * C), px[rr], n_st[rr], true, rp);
             } else if (y < L.h) {
-                store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
+                store_row<C, false>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
             }
         }
         return;
@@ -2458,7 +2511,7 @@ __device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int 
             for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.fill;
         }
         if (flat) store_row<C>(L.dst + (size_t)(uint32_t)(first * C), px, n_st, true, rp);
-        else store_row<C>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4, rp);
+        else store_row<C, false>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4, rp);
     }
 }
 
@@ -2603,7 +2656,7 @@ __device__ __forceinline__ void fe_views_tile(const FeBatch& B, const int b, con
 #pragma unroll
             for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.mask_value;
         }
-        store_row<C>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
+        store_row<C, false>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
         if (V.valid_out && lane < n_px) V.valid_out[(int64_t)y * V.out_w + x0 + lane] = oks[rr] ? 1 : 0;
     }
 }
