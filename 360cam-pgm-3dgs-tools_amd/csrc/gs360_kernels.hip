@@ -122,6 +122,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_PAIRED_FETCH
 #define GS360_PAIRED_FETCH 1
 #endif
+#ifndef GS360_SHIFTED_STORE
+#define GS360_SHIFTED_STORE 1   // dword stores for row segments that start off a dword boundary (0: byte stores, A/B reference)
+#endif
 #ifndef GS360_EQ_LEAN
 #define GS360_EQ_LEAN 1      // bilinear RGB row-per-slot views: the lean, software-pipelined member loop (0: the round-3 loop, A/B reference)
 #endif
@@ -208,7 +211,7 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
                 for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
             return;
         }
-        if (SHIFTED && !skip_first) {
+        if (SHIFTED && GS360_SHIFTED_STORE && !skip_first) {
             // a segment that starts off a dword boundary (widths that are not multiples of four): the same two shuffles, the segment's
             // byte stream re-sliced at its own misalignment -- lanes 0..47 write the aligned dwords inside it, lanes 48..50 its 0-3 head
             // bytes, lanes 52..54 its 0-3 tail bytes (one dword store + one byte store instead of three byte stores per pixel)
@@ -1371,7 +1374,7 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                 }
                 return;
             }
-            if (!(mirror && centre_dup) && ofs32_ok) {
+            if (GS360_SHIFTED_STORE && !(mirror && centre_dup) && ofs32_ok) {
                 // Row segments that start off a dword boundary (widths that are not multiples of four: 5250-byte rows of a 1750-pixel
                 // view): the same two shuffles per slot, with the byte stream of the segment re-sliced at the row's own misalignment.
                 // Lanes 0..47 write the aligned dwords inside the segment, lanes 48..50 its 0-3 head bytes, lanes 52..54 its 0-3 tail
