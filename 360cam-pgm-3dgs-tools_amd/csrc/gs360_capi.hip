@@ -622,25 +622,23 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         int mode = -1;                                    // auto
         if (const char* e = std::getenv("GS360_STAGE")) mode = std::atoi(e) != 0 ? 1 : 0;
         bool can = mode != 0 && C == 3 && esize == 1 && interp == GS360_INTERP_LINEAR && (src_stride & 3) == 0;
-        for (int k = 0; k < n_views && can; ++k) can = ev[k].blocked == 0;
-        // Per view (the kernel takes staged and gather rings in one launch): pitched views whose gather form is bound by the
-        // texture-address path -- >= 1.75 source texels per output pixel; with keep-masks, whose four extra reads per pass weigh on the
-        // same path, from 1.2 on (cfg5's pitched views at 1.25: 67.6 -> 58.7 us per frame).  Level views stay in the gather form: their
-        // horizon sharing is worth more (profiles/r04/stage_sweep.txt, stage_mixed_ab.txt).  GS360_STAGE=1: every view.
-        double thr = mask_frames ? 1.2 : 1.75;
-        if (const char* e = std::getenv("GS360_STAGE_STEP")) thr = std::atof(e);      // (probes)
+        double px_all = 0.0, px_win = 0.0;
         for (int k = 0; k < n_views && can; ++k) {
+            can = ev[k].blocked == 0;
             const double hf = clampd(views[k].hfov_deg, 1e-3, 179.9) * kPi / 180.0;
             const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[k].width;
-            // (views whose rows are not whole dwords: the staged form would write them byte by byte, the gather form has a dword path)
+            const double px = (double)views[k].width * (double)views[k].height;
+            px_all += px;
+            // (views whose rows are not whole dwords: the staged kernel would write them byte by byte, the gather kernels have a dword path)
             const size_t row_bytes = dst_stride ? dst_stride : (size_t)views[k].width * 3;
-            const bool win = !ev[k].level && !ev[k].fish && step >= thr && (row_bytes & 3) == 0 && (views[k].width & 3) == 0;
-            if (mode == 1 || win) {
+            if (!ev[k].level && !ev[k].fish && step >= 1.75 && (row_bytes & 3) == 0 && (views[k].width & 3) == 0) px_win += px;
+        }
+        if (can && (mode == 1 || 2.0 * px_win > px_all))
+            for (int k = 0; k < n_views; ++k) {
                 ev[k].blocked = 2;
                 ev[k].level = 0;
                 ev[k].tiles_y = (ev[k].out_h + kTileH - 1) / kTileH;
             }
-        }
     }
     // Ring size: unlimited for the row-per-slot lane map (arithmetic-bound views: cfg3 119 -> 99 -> 95 -> 93 us per frame for
     // rings of 1 / 2 / 3 / 4-8 views).  Views on the blocked lane map are memory-bound and gain nothing from shared arithmetic,
@@ -687,16 +685,13 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // latitude-dependent row offsets once per change of sign (results do not depend on the order)
     for (auto& r : rings) std::stable_partition(r.begin(), r.end(), [&](int k) { return ev[k].flip == 0; });
     std::stable_partition(rings.begin(), rings.end(), [&](const std::vector<int>& r) { return ev[r[0]].blocked != 2; });   // gather rings, then staged ones
-    // a call with staged rings goes to the staged kernel as a whole: it takes the other rings (all on the row-per-slot map then) in
-    // the gather form (two launches lose more in tails than the staged rings win: cfg3 95.8 us against 84.4 / 78.4)
-    bool any_staged = false;
-    for (const auto& r : rings) any_staged = any_staged || ev[r[0]].blocked == 2;
     size_t r0 = 0;
     while (r0 < rings.size()) {
         size_t r1 = r0;
         int nv = 0;
-        const bool staged = any_staged;
-        while (r1 < rings.size() && nv + (int)rings[r1].size() <= GS360_MAX_VIEWS) nv += (int)rings[r1++].size();
+        const bool staged = ev[rings[r0][0]].blocked == 2;          // staged rings and gather rings never share a launch
+        while (r1 < rings.size() && nv + (int)rings[r1].size() <= GS360_MAX_VIEWS && (ev[rings[r1][0]].blocked == 2) == staged)
+            nv += (int)rings[r1++].size();
         for (int f0 = 0; f0 < n_frames; f0 += GS360_MAX_FRAMES) {
             int nf = n_frames - f0 < GS360_MAX_FRAMES ? n_frames - f0 : GS360_MAX_FRAMES;
             EqLaunch L;

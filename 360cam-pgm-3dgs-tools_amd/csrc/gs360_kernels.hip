@@ -1587,12 +1587,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
     constexpr int kSliceBytes = MASKED ? GS360_STAGE_BYTES_MASKED : kStageBytes;   // masked: one more parked entry per pixel
     constexpr int kSliceRounds = kSliceBytes / 16 / 64;
     static_assert(kSliceBytes % 1024 == 0, "a slice is whole DMA rounds");
-    // one LDS block for both forms: the staged form's slices + parked entries, or the gather form's parked entries (a workgroup runs one)
-    constexpr int kStageDw = kWaves * kSliceBytes / 4, kParkDw = (MASKED ? 5 : 4) * 64 * kWaves * 4;
-    constexpr int kLeanDw = EqLds<3, false, 1, true, MASKED>::kDwords;
-    __shared__ __attribute__((aligned(16))) uint32_t s_all[(kStageDw + kParkDw) > kLeanDw ? (kStageDw + kParkDw) : kLeanDw];
-    uint32_t* const s_stage = s_all;
-    int4* const s_park = reinterpret_cast<int4*>(s_all + kStageDw);
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWaves * kSliceBytes / 4];
+    __shared__ __attribute__((aligned(16))) int4 s_park[(MASKED ? 5 : 4) * 64 * kWaves];
     const int b = blockIdx.x;
     int t = (b & 7) * L.chunk + (b >> 3);
     if (L.xcd_group_log2 >= 0) {
@@ -1606,10 +1602,6 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
     while (g + 1 < L.n_rings && r >= L.view[L.ring_first[g + 1]].tile_base) ++g;
     const int k0 = L.ring_first[g], n_members = L.ring_count[g];
     const EqView& V = L.view[k0];
-    if (V.blocked != 2) {       // a ring the host left in the gather form (level views: their horizon sharing is worth more than the staging)
-        eq_views_tile<3, false, MASKED, 1, true>(L, b, reinterpret_cast<const int16_t*>(s_all), s_all);
-        return;
-    }
     r -= V.tile_base;
     const int tile_y = r / V.tiles_x, tile_x = r - tile_y * V.tiles_x;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
