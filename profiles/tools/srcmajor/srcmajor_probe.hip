@@ -1,0 +1,458 @@
+// Round-5 study harness for the source-major equirect kernel: a workgroup streams ONE source tile into LDS (global_load_lds_dwordx4)
+// and renders every output pixel of every view whose tap pair starts inside it, from a static plan (make_plan.py).
+// MODE 0: full kernel; 1: replay (DMA + LDS reads + stores, no blend arithmetic); 2: DMA only; 3: no DMA (plan + LDS + blend + stores)
+// build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o srcmajor_probe srcmajor_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_void_t;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kMaxFrames = 16, kMaxViews = 16;
+struct SmTile { int32_t x0, y0, nrows, wch, ebeg, ecnt, pad0, pad1; };
+struct SmLaunch {
+    const uint8_t* src[kMaxFrames];
+    uint8_t* dst[kMaxFrames * kMaxViews];
+    const SmTile* tiles;
+    const uint2* entries;
+    int32_t W, H, N, w, h, PB, n_tiles, n_frames;
+    int32_t per_frame, total, chunk;
+    int32_t qmap[kMaxViews];      // ring position q -> view index of the call
+    int64_t src_stride, dst_stride;
+};
+
+__device__ __forceinline__ int dot2_i16(uint32_t taps, uint32_t weights, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, taps), __builtin_bit_cast(s16x2, weights), acc, false);
+}
+#define PAIR(lo, hi) (0x0c000c00u | ((uint32_t)(hi) << 16) | (uint32_t)(lo))
+
+template <int MODE>
+__global__ __launch_bounds__(256) void srcmajor_kernel(const SmLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    __shared__ uint8_t* s_dst[kMaxViews];
+    const int b = blockIdx.x;
+    const int t = (b & 7) * L.chunk + (b >> 3);
+    if (t >= L.total) return;
+    const int f = t / L.per_frame;
+    int r = t - f * L.per_frame;
+    const int n_img = 2 * L.N;
+    const int ti = r / n_img, img = r - ti * n_img;
+    const int k = img >> 1;
+    const bool flip = img & 1;
+    const SmTile T = L.tiles[ti];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < L.N) {
+        int q = tid + k; if (q >= L.N) q -= L.N;
+        s_dst[tid] = L.dst[f * L.N + L.qmap[q]];
+    }
+    const uint8_t* __restrict__ src = L.src[f];
+    const int rowbytes = 3 * L.W;
+    // ---- stage the tile: chunk c = (row, col) -> LDS byte 16 c
+    if (MODE != 3) {
+        const int total = T.nrows * T.wch;
+        int xk = T.x0 + k * L.PB;
+        for (int c0 = wave * 64; c0 < total; c0 += 256) {
+            const int c = c0 + lane;
+            if (c < total) {
+                const int row = c / T.wch, col = c - row * T.wch;
+                int y = flip ? L.H - 1 - (T.y0 + row) : T.y0 + row;
+                y = min(max(y, 0), L.H - 1);
+                int x = xk + col * 16;
+                if (x >= rowbytes) x -= rowbytes;
+                if (x >= rowbytes) x -= rowbytes;
+                const uint8_t* g = src + (size_t)y * L.src_stride + x;
+                __builtin_amdgcn_global_load_lds((global_void_t*)g, (lds_void_t*)(s_tile + (size_t)c0 * 16), 16, 0, 0);
+            }
+        }
+    }
+    if (MODE == 2) { __builtin_amdgcn_s_waitcnt(0x0F70); return; }
+    const uint2* __restrict__ ent = L.entries + T.ebeg;
+    uint2 e = make_uint2(0, 0);
+    if (tid < T.ecnt) e = ent[tid];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    const int pitch = T.wch * 16;
+    const int k4 = lane & 3;
+    const uint32_t sel = k4 == 0 ? 0x04020100u : (k4 == 1 ? 0x05040201u : 0x06050402u);
+    const int rowpx = L.w;
+    for (int i0 = 0; i0 < T.ecnt; i0 += 256) {
+        const uint2 cur = e;
+        if (i0 + 256 + tid < T.ecnt) e = ent[i0 + 256 + tid];
+        const bool valid = (cur.x >> 28) & 1u, full = (cur.x >> 29) & 1u, noflip = (cur.x >> 30) & 1u;
+        const uint32_t o0 = cur.y & 0x1ffffu, o1 = o0 + (uint32_t)pitch;
+        const int fx = (cur.y >> 17) & 31, fy = (cur.y >> 22) & 31;
+        const uint32_t* qa = reinterpret_cast<const uint32_t*>(s_tile + (o0 & ~3u));
+        const uint32_t* qb = reinterpret_cast<const uint32_t*>(s_tile + (o1 & ~3u));
+        const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+        uint32_t pk;
+        if (MODE == 1) {
+            pk = (a0 ^ a1 ^ a2 ^ b0 ^ b1 ^ b2) & 0xffffffu;
+        } else {
+            const uint32_t t0x = __builtin_amdgcn_alignbyte(a1, a0, o0), t0y = __builtin_amdgcn_alignbyte(a2, a1, o0);
+            const uint32_t t1x = __builtin_amdgcn_alignbyte(b1, b0, o1), t1y = __builtin_amdgcn_alignbyte(b2, b1, o1);
+            const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);
+            const uint32_t wr0 = __umul24(ah, (uint32_t)(32 - fy)), wr1 = __umul24(ah, (uint32_t)fy);
+            const uint32_t c0 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1x, t1x, PAIR(0, 3)), wr1, dot2_i16(__builtin_amdgcn_perm(t0x, t0x, PAIR(0, 3)), wr0, 512)) >> 10;
+            const uint32_t c1 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(1, 4)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(1, 4)), wr0, 512)) >> 10;
+            const uint32_t c2 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(2, 5)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(2, 5)), wr0, 512)) >> 10;
+            pk = c0 | (c1 << 8) | (c2 << 16);
+        }
+        const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+        const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
+        const int i = cur.x & 0xfff, j = (cur.x >> 12) & 0xfff, vrel = (cur.x >> 24) & 15;
+        const int jj = flip ? L.h - 1 - j : j;
+        uint8_t* const d = s_dst[vrel];
+        const bool live = valid && !(flip && noflip);
+        const uint32_t off = (uint32_t)(jj * rowpx + i) * 3u;
+        if (live) {
+            if (full) {
+                if (k4 < 3) *reinterpret_cast<uint32_t*>(d + off + k4) = dw;
+            } else {
+                d[off] = (uint8_t)pk; d[off + 1] = (uint8_t)(pk >> 8); d[off + 2] = (uint8_t)(pk >> 16);
+            }
+        }
+    }
+}
+
+
+// v2: one LOADER wavefront streams the G images of a canonical tile into two alternating LDS buffers while four CONSUMER
+// wavefronts render from the buffer that has landed (the consumers' own vmcnt queue never holds a DMA: their plan-entry waits
+// do not wait for the next tile).  Entries are padded to whole wavefronts with copies of real quads: no predicate, one dword store
+// per pixel slot, straight-line loop body (the compiler counts vmcnt exactly).
+struct SmLaunch2 { SmLaunch L; int32_t G, groups_per_tile, groups_per_frame, total_groups, gchunk, buf_bytes; };
+
+template <int MODE, int LDSRD>
+__global__ __launch_bounds__(320) void srcmajor2_kernel(const SmLaunch2 P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    __shared__ uint8_t* s_dst[12 * kMaxViews];
+    const SmLaunch& L = P.L;
+    const int b = blockIdx.x;
+    const int t = (b & 7) * P.gchunk + (b >> 3);
+    if (t >= P.total_groups) return;
+    const int f = t / P.groups_per_frame;
+    const int r = t - f * P.groups_per_frame;
+    const int ti = r / P.groups_per_tile, g0 = (r - ti * P.groups_per_tile) * P.G;
+    const SmTile T = L.tiles[ti];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = P.G;
+    if (tid < G * L.N) {
+        const int g = tid / L.N, v = tid - g * L.N;
+        int q = v + ((g0 + g) >> 1); if (q >= L.N) q -= L.N;
+        s_dst[g * kMaxViews + v] = L.dst[f * L.N + L.qmap[q]];
+    }
+    const uint8_t* __restrict__ src = L.src[f];
+    const int rowbytes = 3 * L.W;
+    const int total = T.nrows * T.wch;
+    auto dma = [&](const int img, uint8_t* const buf) {
+        const int k = img >> 1;
+        const bool flip = img & 1;
+        const int xk = T.x0 + k * L.PB;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < total) {
+                const int row = c / T.wch, col = c - row * T.wch;
+                int y = flip ? L.H - 1 - (T.y0 + row) : T.y0 + row;
+                y = min(max(y, 0), L.H - 1);
+                int x = xk + col * 16;
+                if (x >= rowbytes) x -= rowbytes;
+                if (x >= rowbytes) x -= rowbytes;
+                const uint8_t* gp = src + (size_t)y * L.src_stride + x;
+                __builtin_amdgcn_global_load_lds((global_void_t*)gp, (lds_void_t*)(buf + (size_t)c0 * 16), 16, 0, 0);
+            }
+        }
+    };
+    if (wave == 0) {
+        if (MODE != 3) dma(g0, s_tile);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    const int pitch = T.wch * 16;
+    const int k4 = lane & 3;
+    const uint32_t sel = k4 == 0 ? 0x04020100u : (k4 == 1 ? 0x05040201u : 0x06050402u);
+    const uint2* __restrict__ ent = L.entries + T.ebeg;
+    for (int g = 0; g < G; ++g) {
+        uint8_t* const cur_buf = s_tile + (g & 1) * P.buf_bytes;
+        if (wave == 0) {
+            if (g + 1 < G && MODE != 3) dma(g0 + g + 1, s_tile + ((g + 1) & 1) * P.buf_bytes);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else if (MODE != 2) {
+            const bool flip = (g0 + g) & 1;
+            int i0 = (wave - 1) * 64;
+            uint2 e = ent[i0 + lane];
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // nothing pending at loop entry: the waits inside the loop then count exactly
+            for (; i0 < T.ecnt; i0 += 256) {
+                const uint2 cur = e;
+                e = ent[i0 + 256 + lane];
+                const uint32_t o0 = cur.y & 0x1ffffu, o1 = o0 + (uint32_t)pitch;
+                const int fx = (cur.y >> 17) & 31, fy = (cur.y >> 22) & 31;
+                uint32_t t0x, t0y, t1x, t1y;
+                if (LDSRD == 0) {
+                    const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (o0 & ~3u));
+                    const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (o1 & ~3u));
+                    const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+                    t0x = __builtin_amdgcn_alignbyte(a1, a0, o0); t0y = __builtin_amdgcn_alignbyte(a2, a1, o0);
+                    t1x = __builtin_amdgcn_alignbyte(b1, b0, o1); t1y = __builtin_amdgcn_alignbyte(b2, b1, o1);
+                } else {
+                    const uint2* qa = reinterpret_cast<const uint2*>(cur_buf + (o0 & ~7u));
+                    const uint2* qb = reinterpret_cast<const uint2*>(cur_buf + (o1 & ~7u));
+                    const uint2 a01 = qa[0], a23 = qa[1], b01 = qb[0], b23 = qb[1];
+                    const bool ha = o0 & 4u, hb = o1 & 4u;
+                    const uint32_t a0 = ha ? a01.y : a01.x, a1 = ha ? a23.x : a01.y, a2 = ha ? a23.y : a23.x;
+                    const uint32_t b0 = hb ? b01.y : b01.x, b1 = hb ? b23.x : b01.y, b2 = hb ? b23.y : b23.x;
+                    t0x = __builtin_amdgcn_alignbyte(a1, a0, o0); t0y = __builtin_amdgcn_alignbyte(a2, a1, o0);
+                    t1x = __builtin_amdgcn_alignbyte(b1, b0, o1); t1y = __builtin_amdgcn_alignbyte(b2, b1, o1);
+                }
+                uint32_t pk;
+                if (MODE == 1) {
+                    pk = (t0x ^ t0y ^ t1x ^ t1y) & 0xffffffu;
+                } else {
+                    const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);
+                    const uint32_t wr0 = __umul24(ah, (uint32_t)(32 - fy)), wr1 = __umul24(ah, (uint32_t)fy);
+                    const uint32_t c0 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1x, t1x, PAIR(0, 3)), wr1, dot2_i16(__builtin_amdgcn_perm(t0x, t0x, PAIR(0, 3)), wr0, 512)) >> 10;
+                    const uint32_t c1 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(1, 4)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(1, 4)), wr0, 512)) >> 10;
+                    const uint32_t c2 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(2, 5)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(2, 5)), wr0, 512)) >> 10;
+                    pk = c0 | (c1 << 8) | (c2 << 16);
+                }
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+                const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
+                const int i = cur.x & 0xfff, j = (cur.x >> 12) & 0xfff, vrel = (cur.x >> 24) & 15;
+                const int jj = flip ? L.h - 1 - j : j;
+                uint8_t* const d = s_dst[g * kMaxViews + vrel];
+                // lane 3 of a quad has no dword of its own: it repeats lane 2's store (same value, same address) so that the store is
+                // unconditional and the loop body stays straight-line
+                const uint32_t off = (uint32_t)(jj * L.w + i) * 3u + (uint32_t)k4;
+                const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw, 0xA4, 0xf, 0xf, false);    // quad_perm [0,1,2,2]
+                const uint32_t ofq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0xA4, 0xf, 0xf, false);
+                *(__attribute__((address_space(1))) uint32_t*)((uintptr_t)d + ofq) = dwq;    // a GLOBAL store: a flat one (pointer from LDS) cannot be counted
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// v3: pixel ownership (56 MB of tiles per frame), per tile a list of full output quads (one dword store per slot) and a list of single
+// pixels (three byte stores), both padded to whole wavefronts with copies; one loader wavefront with scalar row bases (no per-lane
+// address arithmetic per DMA instruction) + NCW consumer wavefronts; two alternating LDS buffers.
+template <int MODE, int NCW>
+__global__ __launch_bounds__(64 * (NCW + 1)) void srcmajor3_kernel(const SmLaunch2 P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    __shared__ uint8_t* s_dst[12 * kMaxViews];
+    const SmLaunch& L = P.L;
+    const int b = blockIdx.x;
+    const int t = (b & 7) * P.gchunk + (b >> 3);
+    if (t >= P.total_groups) return;
+    const int f = t / P.groups_per_frame;
+    const int r = t - f * P.groups_per_frame;
+    const int ti = r / P.groups_per_tile, g0 = (r - ti * P.groups_per_tile) * P.G;
+    const SmTile T = L.tiles[ti];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = P.G;
+    if (tid < G * L.N) {
+        const int g = tid / L.N, v = tid - g * L.N;
+        int q = v + ((g0 + g) >> 1); if (q >= L.N) q -= L.N;
+        s_dst[g * kMaxViews + v] = L.dst[f * L.N + L.qmap[q]];
+    }
+    const uint8_t* __restrict__ src = L.src[f];
+    const int rowbytes = 3 * L.W;
+    const int pitch = T.wch * 16;
+    auto dma = [&](const int img, uint8_t* const buf) {          // loader wavefront: one instruction per (row, block of 64 chunks)
+        const int k = img >> 1;
+        const bool flip = img & 1;
+        for (int cb = 0; cb < T.wch; cb += 64) {
+            int x = T.x0 + k * L.PB + (cb + lane) * 16;
+            if (x >= rowbytes) x -= rowbytes;
+            if (x >= rowbytes) x -= rowbytes;
+            if (cb + lane < T.wch) {
+                for (int row = 0; row < T.nrows; ++row) {
+                    int y = flip ? L.H - 1 - (T.y0 + row) : T.y0 + row;
+                    y = min(max(y, 0), L.H - 1);
+                    const uint8_t* rowp = src + (size_t)y * L.src_stride;
+                    __builtin_amdgcn_global_load_lds((global_void_t*)(rowp + (uint32_t)x), (lds_void_t*)(buf + row * pitch + cb * 16), 16, 0, 0);
+                }
+            }
+        }
+    };
+    if (wave == 0) {
+        if (MODE != 3) dma(g0, s_tile);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    const int k4 = lane & 3;
+    const uint32_t sel = k4 == 0 ? 0x04020100u : (k4 == 1 ? 0x05040201u : 0x06050402u);
+    const uint2* __restrict__ entq = L.entries + T.ebeg;
+    const uint2* __restrict__ ents = L.entries + T.pad0;
+    const int qcnt = T.ecnt, scnt = T.pad1;
+    // every image of the tile replays the same lists: a consumer wavefront keeps its first two chunks of each in registers for the whole
+    // workgroup (an image then starts without a memory round trip) and prefetches two turns ahead inside the loops
+    uint2 q0 = make_uint2(0, 0), q1 = q0, z0 = q0, z1 = q0;
+    if (wave > 0) {
+        const int i0 = (wave - 1) * 64 + lane;
+        q0 = entq[i0]; q1 = entq[i0 + 64 * NCW]; z0 = ents[i0]; z1 = ents[i0 + 64 * NCW];
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    for (int g = 0; g < G; ++g) {
+        uint8_t* const cur_buf = s_tile + (g & 1) * P.buf_bytes;
+        if (wave == 0) {
+            if (g + 1 < G && MODE != 3) dma(g0 + g + 1, s_tile + ((g + 1) & 1) * P.buf_bytes);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else if (MODE != 2) {
+            const bool flip = (g0 + g) & 1;
+            auto sample = [&](const uint2 cur, uint32_t& off, uint8_t*& d) -> uint32_t {
+                const uint32_t o0 = cur.y & 0x1ffffu, o1 = o0 + (uint32_t)pitch;
+                const int fx = (cur.y >> 17) & 31, fy = (cur.y >> 22) & 31;
+                const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (o0 & ~3u));
+                const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (o1 & ~3u));
+                const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+                const int i = cur.x & 0xfff, j = (cur.x >> 12) & 0xfff, vrel = (cur.x >> 24) & 15;
+                const int jj = flip ? L.h - 1 - j : j;
+                d = s_dst[g * kMaxViews + vrel];
+                off = (uint32_t)(jj * L.w + i) * 3u;
+                const uint32_t t0x = __builtin_amdgcn_alignbyte(a1, a0, o0), t0y = __builtin_amdgcn_alignbyte(a2, a1, o0);
+                const uint32_t t1x = __builtin_amdgcn_alignbyte(b1, b0, o1), t1y = __builtin_amdgcn_alignbyte(b2, b1, o1);
+                if (MODE == 1) return (t0x ^ t0y ^ t1x ^ t1y) & 0xffffffu;
+                const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);
+                const uint32_t wr0 = __umul24(ah, (uint32_t)(32 - fy)), wr1 = __umul24(ah, (uint32_t)fy);
+                const uint32_t c0 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1x, t1x, PAIR(0, 3)), wr1, dot2_i16(__builtin_amdgcn_perm(t0x, t0x, PAIR(0, 3)), wr0, 512)) >> 10;
+                const uint32_t c1 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(1, 4)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(1, 4)), wr0, 512)) >> 10;
+                const uint32_t c2 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(2, 5)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(2, 5)), wr0, 512)) >> 10;
+                return c0 | (c1 << 8) | (c2 << 16);
+            };
+            {   // full quads: lanes 4m..4m+3 hold pixels 4q..4q+3 of one output row; lanes 0..2 of the quad write its three dwords
+                int i0 = (wave - 1) * 64;
+                if (i0 < qcnt) {
+                    uint2 ea = q0, eb = q1;
+                    auto quad_turn = [&](const uint2 cur) {
+                        uint32_t off; uint8_t* d;
+                        const uint32_t pk = sample(cur, off, d);
+                        const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+                        const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
+                        off += (uint32_t)k4;
+                        const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw, 0xA4, 0xf, 0xf, false);    // quad_perm [0,1,2,2]
+                        const uint32_t ofq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0xA4, 0xf, 0xf, false);
+                        *(__attribute__((address_space(1))) uint32_t*)((uintptr_t)d + ofq) = dwq;
+                    };
+                    // two turns per trip, each register pair reloaded right after its use: entries arrive two turns ahead, no copies
+                    for (; i0 < qcnt; i0 += 128 * NCW) {
+                        const uint2 ca = ea;
+                        ea = entq[i0 + 128 * NCW + lane];
+                        quad_turn(ca);
+                        if (i0 + 64 * NCW < qcnt) {
+                            const uint2 cb = eb;
+                            eb = entq[i0 + 192 * NCW + lane];
+                            quad_turn(cb);
+                        }
+                    }
+                }
+            }
+            {   // single pixels (quads cut by a tile boundary): three byte stores
+                int i0 = (wave - 1) * 64;
+                if (i0 < scnt) {
+                    uint2 e = z0, e1 = z1;
+                    for (; i0 < scnt; i0 += 64 * NCW) {
+                        const uint2 cur = e;
+                        e = e1;
+                        e1 = ents[i0 + 128 * NCW + lane];
+                        uint32_t off; uint8_t* d;
+                        const uint32_t pk = sample(cur, off, d);
+                        __attribute__((address_space(1))) uint8_t* q = (__attribute__((address_space(1))) uint8_t*)((uintptr_t)d + off);
+                        q[0] = (uint8_t)pk; q[1] = (uint8_t)(pk >> 8); q[2] = (uint8_t)(pk >> 16);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+static uint8_t frame_byte(uint32_t f, uint32_t p) {      // reproducible in numpy (uint32 arithmetic)
+    uint32_t x = p * 2654435761u + f * 40503u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    return (uint8_t)(x >> 8);
+}
+__global__ void fill_kernel(uint8_t* d, uint32_t f, size_t n) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) { uint32_t x = (uint32_t)p * 2654435761u + f * 40503u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; d[p] = (uint8_t)(x >> 8); }
+}
+
+int main(int argc, char** argv) {
+    const char* plan = argc > 1 ? argv[1] : "plan.bin";
+    const int mode_only = argc > 2 ? atoi(argv[2]) : -1;
+    const char* dump = (argc > 3 && argv[3][0]) ? argv[3] : nullptr;
+    FILE* fp = fopen(plan, "rb");
+    if (!fp) { printf("no plan %s\n", plan); return 1; }
+    int32_t hdr[16];
+    if (fread(hdr, 4, 16, fp) != 16) return 1;
+    const int W = hdr[0], H = hdr[1], N = hdr[2], w = hdr[3], h = hdr[4], PB = hdr[5], n_tiles = hdr[8], n_ent = hdr[9], max_lds = hdr[10];
+    std::vector<SmTile> tiles(n_tiles);
+    std::vector<uint2> ents(n_ent);
+    if (fread(tiles.data(), sizeof(SmTile), n_tiles, fp) != (size_t)n_tiles) return 1;
+    if (fread(ents.data(), 8, n_ent, fp) != (size_t)n_ent) return 1;
+    fclose(fp);
+    printf("plan %s: W %d H %d N %d w %d h %d PB %d Bx %d R %d tiles %d entries %d max_lds %d\n", plan, W, H, N, w, h, PB, hdr[6], hdr[7], n_tiles, n_ent, max_lds);
+    const int F = 16;
+    const size_t fbytes = (size_t)W * H * 3, vbytes = (size_t)w * h * 3;
+    SmLaunch L; memset(&L, 0, sizeof L);
+    for (int f = 0; f < F; ++f) {
+        uint8_t* d; CK(hipMalloc((void**)&d, fbytes + 256));
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((fbytes + 255) / 256)), dim3(256), 0, 0, d, (uint32_t)f, fbytes);
+        L.src[f] = d;
+        for (int v = 0; v < N; ++v) { uint8_t* o; CK(hipMalloc((void**)&o, vbytes + 256)); CK(hipMemset(o, 0xEE, vbytes)); L.dst[f * N + v] = o; }
+    }
+    SmTile* dt; uint2* de;
+    CK(hipMalloc((void**)&dt, n_tiles * sizeof(SmTile))); CK(hipMemcpy(dt, tiles.data(), n_tiles * sizeof(SmTile), hipMemcpyHostToDevice));
+    CK(hipMalloc((void**)&de, (size_t)n_ent * 8 + 65536)); CK(hipMemcpy(de, ents.data(), (size_t)n_ent * 8, hipMemcpyHostToDevice));
+    L.tiles = dt; L.entries = de; L.W = W; L.H = H; L.N = N; L.w = w; L.h = h; L.PB = PB; L.n_tiles = n_tiles; L.n_frames = F;
+    L.per_frame = n_tiles * 2 * N; L.total = L.per_frame * F; L.chunk = (L.total + 7) / 8;
+    for (int q = 0; q < N; ++q) L.qmap[q] = q;
+    L.src_stride = 3 * W; L.dst_stride = 3 * w;
+    const int grid = L.chunk * 8;
+    const size_t lds = (size_t)max_lds + 64;
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int G = argc > 4 ? atoi(argv[4]) : 6;
+    const int ldsrd = argc > 5 ? atoi(argv[5]) : 1;
+    SmLaunch2 P; P.L = L; P.G = G; P.groups_per_tile = 2 * N / G; P.groups_per_frame = n_tiles * P.groups_per_tile;
+    P.total_groups = P.groups_per_frame * F; P.gchunk = (P.total_groups + 7) / 8; P.buf_bytes = (max_lds + 63) & ~63;
+    const int grid2 = P.gchunk * 8;
+    const size_t lds2 = 2 * (size_t)P.buf_bytes + 64;
+    const int ncw = argc > 6 ? atoi(argv[6]) : 0;
+    auto launch2 = [&](int mode) {
+#define L3(M, C) { CK(hipFuncSetAttribute((const void*)srcmajor3_kernel<M, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); hipLaunchKernelGGL((srcmajor3_kernel<M, C>), dim3(grid2), dim3(64 * (C + 1)), lds2, 0, P); }
+        if (ncw == 4) { if (mode == 0) L3(0, 4) if (mode == 1) L3(1, 4) if (mode == 2) L3(2, 4) if (mode == 3) L3(3, 4) return; }
+        if (ncw == 8) { if (mode == 0) L3(0, 8) if (mode == 1) L3(1, 8) if (mode == 2) L3(2, 8) if (mode == 3) L3(3, 8) return; }
+#define L2(M, R) { CK(hipFuncSetAttribute((const void*)srcmajor2_kernel<M, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); hipLaunchKernelGGL((srcmajor2_kernel<M, R>), dim3(grid2), dim3(320), lds2, 0, P); }
+        if (ldsrd == 0) { if (mode == 0) L2(0, 0) if (mode == 1) L2(1, 0) if (mode == 2) L2(2, 0) if (mode == 3) L2(3, 0) }
+        else { if (mode == 0) L2(0, 1) if (mode == 1) L2(1, 1) if (mode == 2) L2(2, 1) if (mode == 3) L2(3, 1) }
+    };
+    for (int mode = 0; mode < 4; ++mode) {
+        if (mode_only >= 0 && mode != mode_only) continue;
+        for (int i = 0; i < 400; ++i) launch2(mode);
+        CK(hipDeviceSynchronize());
+        const int NIT = 100;
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < NIT; ++i) launch2(mode);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= NIT;
+        printf("v%d ncw %d G %d ldsrd %d mode %d: %.1f us/launch = %.2f us/frame (grid %d, lds %zu)\n", ncw ? 3 : 2, ncw, G, ldsrd, mode, ms * 1e3, ms * 1e3 / F, grid2, lds2);
+    }
+    if (dump) {
+        // full kernel once more on clean outputs, dump frames 0 and F-1
+        for (int i = 0; i < F * N; ++i) CK(hipMemset(L.dst[i], 0xEE, vbytes));
+        launch2(0);
+        CK(hipDeviceSynchronize());
+        FILE* fo = fopen(dump, "wb");
+        std::vector<uint8_t> hb(vbytes);
+        for (int f : {0, F - 1})
+            for (int v = 0; v < N; ++v) { CK(hipMemcpy(hb.data(), L.dst[f * N + v], vbytes, hipMemcpyDeviceToHost)); fwrite(hb.data(), 1, vbytes, fo); }
+        fclose(fo);
+        printf("dumped %s\n", dump);
+    }
+    (void)frame_byte;
+    return 0;
+}

@@ -1,8 +1,15 @@
-"""Pins EQ-SPEC v1 (oracle side) against a float64 evaluation of the reference's own convention
-(gs360_GUI.py:377-395 direction_from_uv, :419-424 lonlat_to_xy).  Parity is UNPINNED against ffmpeg v360
-(absent, unpinned third-party binary); what is pinned is the geometry convention and the quantisation error."""
+"""Pins EQ-SPEC v1 (oracle side) on the reference's own convention: `tests/golden/eq_convention_goldens.npz` holds the outputs of
+the reference GUI's direction_from_uv / rotate_pitch / rotate_yaw / lonlat_to_xy (gs360_GUI.py:342-424, lifted with `ast` and RUN
+by tests/golden/make_eq_convention_goldens.py in the build container) for every view of the presets; a float64 re-statement of the
+same formulas covers the poles and odd yaws on dense grids.  Parity is UNPINNED against ffmpeg v360's sampler (absent, unpinned
+third-party binary); what is pinned is the geometry convention and the quantisation error."""
+import json
+import pathlib
+
 import numpy as np
 import pytest
+
+GOLD = pathlib.Path(__file__).resolve().parent / "golden"
 
 from util import HFOV_12MM, PRESET_FULL360, HFOV_14MM, rand_image, ring_views
 
@@ -28,6 +35,37 @@ def truth_xy(spec, W, H):
     lon = np.arctan2(x2, z2)
     lat = np.arcsin(np.clip(y1, -1, 1))
     return (lon / (2 * np.pi) + 0.5) * W - 0.5, (0.5 - lat / np.pi) * H - 0.5, lat
+
+
+def _convention_views():
+    meta = json.loads((GOLD / "eq_convention_goldens.json").read_text())
+    return meta["views"]
+
+
+@pytest.mark.parametrize("view", _convention_views(), ids=lambda v: v["key"])
+def test_quantised_map_matches_reference_gui_functions(orc, view):
+    """oracle sx/32, sy/32 == round(32 (x - 1/2)) / 32 of the REFERENCE's lonlat_to_xy(direction_from_uv(...)) at pixel centres
+    (same tolerances as the float64 re-statement below): every view of default / fisheyelike / full360coverage / --count 6
+    --size 800, 8K and 5.7K panoramas."""
+    g = np.load(GOLD / "eq_convention_goldens.npz")[view["key"]]
+    W, H = view["W"], view["H"]
+    sx, sy = orc.equirect_map(orc.make_view(view["yaw_deg"], view["pitch_deg"], view["hfov_deg"], view["vfov_deg"],
+                                            view["width"], view["height"]), W, H)
+    i, j = g[:, 0].astype(int), g[:, 1].astype(int)
+    lat, X, Y = g[:, 3], g[:, 4] - 0.5, g[:, 5] - 0.5          # texel centres sit at half-integers of the GUI's pixel coordinates
+    qx, qy = sx[j, i], sy[j, i]
+    assert qx.min() >= 0 and qx.max() < 32 * W
+    dx = (qx / 32.0 - X + W / 2) % W - W / 2
+    dy = qy / 32.0 - Y
+    cosl = np.maximum(np.cos(lat), 1e-3)
+    assert np.abs(dy).max() <= 1 / 64 + 2e-4
+    assert (np.abs(dx) * cosl).max() <= 1 / 64 + 3e-4
+    # the quantised value IS the rounded reference coordinate except within 2e-4 px (on the sphere) of a bucket edge
+    wrong_x = (np.rint(32 * X).astype(np.int64) % (32 * W)) != qx
+    wrong_y = np.rint(32 * Y).astype(np.int64) != qy
+    fx = np.abs((32 * X) % 1 - 0.5); fy = np.abs((32 * Y) % 1 - 0.5)
+    assert (fx[wrong_x] * cosl[wrong_x] <= 32 * 3e-4 + 1e-9).all() and (fy[wrong_y] <= 32 * 2e-4 + 1e-9).all()
+    assert wrong_x.mean() + wrong_y.mean() < 0.02
 
 
 CASES = [(0, 0), (60, 0), (180, 0), (-120, 0), (45, 30), (135, -30), (-45, -30), (0, 90), (0, -90), (17.3, -62.1),
