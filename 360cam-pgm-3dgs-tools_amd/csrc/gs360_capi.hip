@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -28,6 +29,9 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+constexpr size_t kSmPlanCap = 4;
+constexpr size_t kSmLdsPerGroup = 80 * 1024;   // two workgroups of the source-major kernel per CU (160 KiB of LDS)
+
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -39,6 +43,25 @@ constexpr int kMaxSlots = 16;
 constexpr int kEventsPerSlot = 8;
 constexpr size_t kSlack = 64;
 constexpr double kPi = 3.14159265358979323846;
+
+// context options: name, default, range, environment seed (user switches only)
+enum Opt { kOptLanemap, kOptStage, kOptRing, kOptXcdGroup, kOptEqPersist, kOptTablePersist, kOptLanczosTable, kOptTableRows, kOptColorCube,
+           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptCount };
+struct OptDesc { const char* key; int def, lo, hi; const char* env; };
+const OptDesc kOpts[kOptCount] = {
+    {"lanemap", -1, -1, 1, "GS360_LANEMAP"},          // -1 auto (per view, by minification), 0 rows, 1 blocked       (env: rows | blocked)
+    {"stage", -1, -1, 1, "GS360_STAGE"},              // LDS-staged kernel: -1 auto, 0 never, 1 every call that can
+    {"ring", 0, 0, GS360_MAX_VIEWS, nullptr},         // 0 auto; n: at most n views share a coordinate evaluation
+    {"xcd_group", -2, -2, 12, nullptr},               // -2 auto; -1 contiguous chunks; g: runs of 2^g tiles
+    {"eq_persist", 0, 0, 1 << 20, nullptr},           // grid cap of the cubic equirect kernels (0: one tile per workgroup)
+    {"table_persist", -1, -1, 1 << 20, nullptr},      // -1 auto; grid cap of the bicubic table / fisheye kernels
+    {"lanczos_table", 0, 0, 1, nullptr},              // 1: read the 128 KiB Lanczos-4 table instead of rebuilding weights per pixel
+    {"table_rows", 0, 0, 1, nullptr},                 // 1: table kernel in row form even for tight outputs (A/B of the flat spans)
+    {"color_cube", -1, -1, 1, "GS360_COLOR_CUBE"},    // -1 / 1: tabulate the 8-bit colour stage (64 MiB per plan); 0: evaluate per pixel
+    {"srcmajor", -1, -1, 1, "GS360_SRCMAJOR"},        // source-major kernel: -1 auto (strongly minified level rings), 0 never, 1 whenever eligible
+    {"srcmajor_bx", 768, 256, 4032, nullptr},         // its tile: bytes per box row (multiple of 16) ...
+    {"srcmajor_rows", 32, 8, 128, nullptr},           // ... and source rows
+};
 
 struct Staging {  // per-slot device staging used by the *_host conveniences
     void* d_src = nullptr; size_t src_cap = 0;
@@ -61,6 +84,12 @@ struct gs360_ctx {
     float* d_coef1d = nullptr;    // 448 float32 1-D phase coefficients for the 16-bit (float-weight) samplers
     uint32_t* d_lz_cen = nullptr; // 1024 x 2 dwords: the patched block of every Lanczos4 2-D phase (TableLaunch::lz_cen)
     bool lz_rebuild = false;      // the per-pixel weight rebuild reproduces d_lanczos (checked at context creation)
+    // Options (gs360_ctx_set_option; seeded ONCE from the environment by gs360_ctx_create for the documented user switches).  The hot
+    // path reads these atomics, never the environment: getenv racing a host thread's putenv is undefined behaviour.
+    std::atomic<int> opt[kOptCount];
+    // source-major plans of this context (gs360_srcmajor.hip), most recent calls' geometries
+    std::mutex sm_mutex;
+    std::vector<gs360::SmPlan*> sm_plans;
 };
 
 namespace {
@@ -85,7 +114,7 @@ int ensure(gs360_ctx* ctx, void** p, size_t* cap, size_t need) {
 double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // EQ-SPEC v1 per-view constants.  Convention: gs360_GUI.py:377-395 / :419-424 of the reference.
-void make_eq_view(const gs360_view& v, int W, bool fisheye_out, EqView* o) {
+void make_eq_view(const gs360_view& v, int W, bool fisheye_out, int lanemap, EqView* o) {
     double hf = clampd(v.hfov_deg, 1e-3, 179.9) * kPi / 180.0;
     double vf = clampd(v.vfov_deg, 1e-3, 179.9) * kPi / 180.0;
     o->sxu = (float)(std::tan(hf * 0.5) / (double)v.width);
@@ -112,10 +141,7 @@ void make_eq_view(const gs360_view& v, int W, bool fisheye_out, EqView* o) {
     // cfg3 2.0, cfg5 1.25: blocked would cost 7-19 %).  GS360_LANEMAP=rows|blocked overrides (tests, probes).
     const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)v.width;
     o->blocked = step >= 3.0 ? 1 : 0;
-    if (const char* e = std::getenv("GS360_LANEMAP")) {
-        if (!std::strcmp(e, "rows")) o->blocked = 0;
-        else if (!std::strcmp(e, "blocked")) o->blocked = 1;
-    }
+    if (lanemap >= 0) o->blocked = lanemap;           // option "lanemap": tests, probes
     o->fish = 0;
     if (fisheye_out) {   // image-plane radius 1 <-> 90 degrees off axis; hfov/vfov = full field of view of the fisheye image
         o->fish = 1;
@@ -291,6 +317,15 @@ int gs360_ctx_create(int device, int n_slots, gs360_ctx** out) {
     if (!c) return fail(GS360_ERR_NOMEM, "out of host memory");
     c->device = device;
     c->n_slots = n_slots;
+    for (int k = 0; k < kOptCount; ++k) {
+        int v = kOpts[k].def;
+        if (kOpts[k].env)
+            if (const char* e = std::getenv(kOpts[k].env)) {       // the ONLY place the library reads its switches from the environment
+                if (k == kOptLanemap) v = !std::strcmp(e, "rows") ? 0 : (!std::strcmp(e, "blocked") ? 1 : -1);
+                else v = std::atoi(e) != 0 ? 1 : 0;
+            }
+        c->opt[k].store(v, std::memory_order_relaxed);
+    }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device);
     for (int s = 0; s < n_slots && e == hipSuccess; ++s) {
@@ -383,8 +418,32 @@ int gs360_ctx_destroy(gs360_ctx* c) {
     if (c->d_lanczos) (void)hipFree(c->d_lanczos);
     if (c->d_coef1d) (void)hipFree(c->d_coef1d);
     if (c->d_lz_cen) (void)hipFree(c->d_lz_cen);
+    for (gs360::SmPlan* p : c->sm_plans) gs360::sm_plan_free(p);
     delete c;
     return GS360_OK;
+}
+
+int gs360_ctx_set_option(gs360_ctx* c, const char* key, int value) {
+    if (!c || !key) return fail(GS360_ERR_ARG, "NULL argument");
+    for (int k = 0; k < kOptCount; ++k)
+        if (!std::strcmp(key, kOpts[k].key)) {
+            if (value < kOpts[k].lo || value > kOpts[k].hi)
+                return fail(GS360_ERR_ARG, "option %s: %d outside [%d, %d]", key, value, kOpts[k].lo, kOpts[k].hi);
+            if (k == kOptSrcMajorBx && value % 16) return fail(GS360_ERR_ARG, "option srcmajor_bx must be a multiple of 16");
+            c->opt[k].store(value, std::memory_order_relaxed);
+            return GS360_OK;
+        }
+    return fail(GS360_ERR_ARG, "unknown option '%s'", key);
+}
+
+int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
+    if (!c || !key || !value) return fail(GS360_ERR_ARG, "NULL argument");
+    for (int k = 0; k < kOptCount; ++k)
+        if (!std::strcmp(key, kOpts[k].key)) {
+            *value = c->opt[k].load(std::memory_order_relaxed);
+            return GS360_OK;
+        }
+    return fail(GS360_ERR_ARG, "unknown option '%s'", key);
 }
 
 int gs360_device_info(gs360_ctx* c, char* name, size_t n, int32_t* cu_count, uint64_t* hbm_bytes) {
@@ -602,12 +661,59 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // so the grouping can never change a result.
     static_assert(sizeof(EqLaunch) <= 4096, "EqLaunch travels as a kernel argument");
     const bool fish = (flags & GS360_EQ_FISHEYE_OUT) != 0;
+    const int opt_lanemap = c->opt[kOptLanemap].load(std::memory_order_relaxed), opt_stage = c->opt[kOptStage].load(std::memory_order_relaxed);
+    const int opt_ring = c->opt[kOptRing].load(std::memory_order_relaxed), opt_xcd = c->opt[kOptXcdGroup].load(std::memory_order_relaxed);
+    const int opt_srcmajor = c->opt[kOptSrcMajor].load(std::memory_order_relaxed);
     try {
     std::vector<EqView> ev((size_t)n_views);
     for (int k = 0; k < n_views; ++k) {
-        make_eq_view(views[k], W, fish, &ev[k]);
+        make_eq_view(views[k], W, fish, opt_lanemap, &ev[k]);
         ev[k].flip = 0;
         if (esize == 2) ev[k].blocked = 0;   // 16-bit samples: row-per-slot lane map only
+    }
+    // Source-major kernel (gs360_srcmajor.hip): a call that is ONE level yaw ring filling its circle (`--count N`, PC:794) at strong
+    // minification -- the shape where neighbouring views share half their source lines -- streams every source tile once for all views
+    // instead of gathering per view (cfg2: 18.7 -> ~14.5 us per frame).  Taken when the gather kernels would use the blocked lane map
+    // (>= 3 texels per pixel); option "srcmajor": 0 never, 1 whenever the geometry fits (tests, probes).  Decided before the ring grouping
+    // below (which keeps blocked views apart); a geometry that does not fit the plan format falls through to the gather kernels.
+    if (opt_srcmajor != 0 && !mask_frames && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 &&
+        n_views <= GS360_MAX_VIEWS) {
+        bool ring = ev[0].level != 0;
+        for (int k = 0; k < n_views && ring; ++k)
+            ring = ev[k].sxu == ev[0].sxu && ev[k].syv == ev[0].syv && ev[k].sp == ev[0].sp && ev[k].cp == ev[0].cp && ev[k].x0f32 == ev[0].x0f32 &&
+                   ev[k].out_w == ev[0].out_w && ev[k].out_h == ev[0].out_h && ev[k].level && (opt_srcmajor == 1 || ev[k].blocked == 1);
+        std::vector<EqLaunch> Ls;
+        for (int f0 = 0; f0 < n_frames && ring; f0 += GS360_MAX_FRAMES) {
+            const int nf = n_frames - f0 < GS360_MAX_FRAMES ? n_frames - f0 : GS360_MAX_FRAMES;
+            EqLaunch L;
+            std::memset(&L, 0, sizeof(L));
+            for (int k = 0; k < n_views; ++k) L.view[k] = ev[k];
+            L.n_rings = 1; L.ring_first[0] = 0; L.ring_count[0] = n_views;
+            for (int f = 0; f < nf; ++f) {
+                L.src[f] = (const uint8_t*)src_frames[f0 + f];
+                for (int k = 0; k < n_views; ++k) L.dst[f * n_views + k] = (uint8_t*)dst[(size_t)(f0 + f) * n_views + k];
+            }
+            L.kx32 = (float)(32.0 * (double)W / (2.0 * kPi));
+            L.ky32 = (float)(32.0 * (double)H / kPi);
+            L.W = W; L.H = H; L.y0i32 = 16 * H - 16;
+            L.n_views = n_views; L.n_frames = nf;
+            L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
+            ring = sm_eligible(L, C, esize, interp, false);
+            Ls.push_back(L);
+        }
+        for (size_t i = 0; i < Ls.size() && ring; ++i) {
+            hipError_t he = hipSuccess;
+            int rc;
+            {
+                std::lock_guard<std::mutex> lock(c->sm_mutex);
+                rc = sm_launch(Ls[i], c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
+                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), kSmLdsPerGroup, c->stream[slot], &he);
+            }
+            if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));
+            if (rc == 1 && i == 0) ring = false;         // the geometry does not fit the plan format (decided by the first chunk: nothing launched yet)
+            else if (rc == 1) return fail(GS360_ERR_HIP, "source-major plan vanished between frame chunks");
+        }
+        if (ring) return GS360_OK;
     }
     // LDS-staged kernel (eq_staged_kernel, north_star's "LDS-staged source texels"): bilinear RGB u8 views whose row stride keeps dword
     // alignment from row to row; its wavefront tiles are 16 x 16 pixels of the general (non-level) tiling.  When it is taken
@@ -619,8 +725,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // gathered and 78.4 all staged), so the CALL is staged as a whole when such views write most of its pixels.
     // GS360_STAGE=0: never; GS360_STAGE=1: every call that can (tests, probes).
     {
-        int mode = -1;                                    // auto
-        if (const char* e = std::getenv("GS360_STAGE")) mode = std::atoi(e) != 0 ? 1 : 0;
+        const int mode = opt_stage;                       // -1 auto
         bool can = mode != 0 && C == 3 && esize == 1 && interp == GS360_INTERP_LINEAR && (src_stride & 3) == 0;
         double px_all = 0.0, px_win = 0.0;
         for (int k = 0; k < n_views && can; ++k) {
@@ -644,12 +749,9 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // rings of 1 / 2 / 3 / 4-8 views).  Views on the blocked lane map are memory-bound and gain nothing from shared arithmetic,
     // while a workgroup that walks six views in a row lengthens the launch's tail (cfg2 20.3 -> 22.6 us per frame): no sharing.
     int ring_max = GS360_MAX_VIEWS, ring_max_blocked = 1;
-    if (const char* e = std::getenv("GS360_RING")) {       // tests / probes: 1 = no sharing anywhere, n = at most n views per ring
-        int v = std::atoi(e);
-        if (v >= 1) ring_max = ring_max_blocked = v < GS360_MAX_VIEWS ? v : GS360_MAX_VIEWS;
-    }
+    if (opt_ring >= 1) ring_max = ring_max_blocked = opt_ring;      // option "ring" (tests / probes): 1 = no sharing anywhere, n = at most n views per ring
     std::vector<std::vector<int>> rings;
-    const bool ring_forced = std::getenv("GS360_RING") != nullptr;
+    const bool ring_forced = opt_ring >= 1;
     for (;;) {
         rings.clear();
         for (int k = 0; k < n_views; ++k) {
@@ -714,17 +816,13 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             L.xcd_group_log2 = -1;
             for (size_t r = r0; r < r1; ++r)
                 if (rings[r].size() != rings[r0].size()) L.xcd_group_log2 = 5;
-            if (const char* e = std::getenv("GS360_XCD_GROUP")) {   // probes: -1 = chunks, g = runs of 2^g tiles
-                int v = std::atoi(e);
-                if (v >= -1 && v <= 12) L.xcd_group_log2 = v;
-            }
+            if (opt_xcd >= -1) L.xcd_group_log2 = opt_xcd;          // option "xcd_group" (probes): -1 = chunks, g = runs of 2^g tiles
             // Persistent workgroups for the cubic variants (one LDS weight-table fill per workgroup instead of per tile) are OFF:
             // an equirect tile already spreads the fill over its mirrored halves and ring members (2048-32768 pixels), and the
             // static walk costs more in balance than the fill saves (cfg2 / cfg1 / cfg3 cubic: 33.4 / 86.5 / 161.5 us per frame
             // with one tile per workgroup, 35.5 / 90.2 / 177.5 with 2048 persistent ones; profiles/r03/persistent_cubic_ab.txt).
             // The cv2 table kernel, 1024 pixels per tile, gains 12 % from it (launch_table_batch).
-            L.persist_blocks = 0;
-            if (const char* e = std::getenv("GS360_EQ_PERSIST")) L.persist_blocks = std::atoi(e);   // probes: grid cap
+            L.persist_blocks = c->opt[kOptEqPersist].load(std::memory_order_relaxed);      // option "eq_persist" (probes): grid cap
             // keep-masks: thresholded once per launch into bit images (the kernels only test `< 128`), behind the caller's upload
             // on the launch stream: a streaming pass over W x H bytes per frame, ~7 us for an 8K mask
             const int pitch_dw = (W + 1 + 31) / 32;
@@ -825,14 +923,14 @@ int fill_table_job(gs360_ctx* c, const gs360_remap_job& J, const gs360_map_plan*
     L->fill = J.fill_value < 0 ? 0 : (J.fill_value > 255 ? 255 : J.fill_value);
     for (int k = 0; k < 4; ++k) L->cval[k] = sat_u8(border_value ? border_value[k] : 0.0);
     L->cubic_tab = interp == GS360_INTERP_LANCZOS4 ? c->d_lanczos : c->d_cubic;
-    if (interp == GS360_INTERP_LANCZOS4 && c->lz_rebuild && !std::getenv("GS360_LANCZOS_TABLE")) {   // (env: probes / A-B runs)
+    if (interp == GS360_INTERP_LANCZOS4 && c->lz_rebuild && !c->opt[kOptLanczosTable].load(std::memory_order_relaxed)) {   // (option "lanczos_table": probes / A-B runs)
         L->lz_c1 = c->d_coef1d + 192;
         L->lz_cen = c->d_lz_cen;
     }
     L->pipelined = (J.W >= 8 && src_stride < ((size_t)1 << 24) && (uint64_t)src_stride * (uint64_t)J.H < ((uint64_t)1 << 32)) ? 1 : 0;
     // a tight output whose rows are not whole dwords (the default 1750-pixel views), float maps: spans of the flat output, dword stores
     // (cfg4 70.4-72.8 -> 54.9-57.4 us per pair; with a map plan the byte stores of the row form are as fast: 52.7 vs 54.8, so plans keep it)
-    static const bool rows_only = std::getenv("GS360_TABLE_ROWS") != nullptr;      // (A/B)
+    const bool rows_only = c->opt[kOptTableRows].load(std::memory_order_relaxed) != 0;      // (option "table_rows": A/B)
     L->flat = (!plan && dst_stride == (size_t)J.w * C && (dst_stride & 3) != 0 && (reinterpret_cast<uintptr_t>(J.dst) & 3) == 0 &&
                !rows_only) ? 1 : 0;
     return 0;
@@ -902,7 +1000,7 @@ static int remap_batches_u8(gs360_ctx* c, const gs360_remap_job* jobs, const gs3
         TableBatch B;
         B.n_jobs = 0;
         B.persist_blocks = c->prop.multiProcessorCount * 8;      // two rounds of the four workgroups a CU holds (bicubic RGB)
-        if (const char* e = std::getenv("GS360_TABLE_PERSIST")) B.persist_blocks = std::atoi(e);   // probes: 0 = one tile per workgroup
+        if (const int v = c->opt[kOptTablePersist].load(std::memory_order_relaxed); v >= 0) B.persist_blocks = v;   // option "table_persist" (probes): 0 = one tile per workgroup
         for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
             if (jobs[j].h == 0 || jobs[j].w == 0) continue;
             if (int rc = fill_table_job(c, jobs[j], plans ? plans[j] : nullptr, C, interp, border_value, &B.job[B.n_jobs])) return rc;
@@ -1045,7 +1143,7 @@ int gs360_fisheye_views_u8(gs360_ctx* c, const void* const* src_lens, const gs36
             if (calibs[v0 + k].width < 8 || (uint64_t)L.src_stride * (uint64_t)calibs[v0 + k].height >= ((uint64_t)1 << 32)) L.pipelined = 0;
         if ((uint64_t)L.src_stride >= ((uint64_t)1 << 24)) L.pipelined = 0;
         L.persist_blocks = c->prop.multiProcessorCount * 8;
-        if (const char* e = std::getenv("GS360_TABLE_PERSIST")) L.persist_blocks = std::atoi(e);
+        if (const int v = c->opt[kOptTablePersist].load(std::memory_order_relaxed); v >= 0) L.persist_blocks = v;
         HIP_TRY(launch_fisheye(L, C, c->stream[slot]));
     }
     return GS360_OK;
@@ -1092,11 +1190,14 @@ int gs360_color_plan_create(gs360_ctx* c, const float* lut, int lut_size, const 
     if (e == hipSuccess) e = hipMemcpy(d_lut, lut, n3 * 3 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_tables, tables.data(), tables.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = build_color_rtab(d_lut, p->d_tables /* red positions come first */, p->d_rtab, lut_size, c->stream[0]);
-    bool want_cube = true;
-    if (const char* env = std::getenv("GS360_COLOR_CUBE")) want_cube = std::atoi(env) != 0;
+    const bool want_cube = c->opt[kOptColorCube].load(std::memory_order_relaxed) != 0;      // option "color_cube" (-1 / 1: yes)
     if (e == hipSuccess && want_cube) {
         e = hipMalloc(&p->d_cube, color_cube_bytes());
-        if (e == hipSuccess) {
+        if (e == hipErrorOutOfMemory) {          // a crowded device: the per-pixel evaluation gives the same results from the 18 MB it already has
+            (void)hipGetLastError();
+            p->d_cube = nullptr;
+            e = hipSuccess;
+        } else if (e == hipSuccess) {
             ColorLaunch B{};
             B.rtab = p->d_rtab; B.tables = p->d_tables; B.lut_size = lut_size; B.fixups = p->fixups;
             e = build_color_cube(B, p->d_cube, c->stream[0]);

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/gs360.h"
 
 namespace gs360 {
@@ -199,6 +201,12 @@ hipError_t launch_mask_pack(const MaskPack& P, hipStream_t s);
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s);
 hipError_t launch_equirect_staged(const EqLaunch& L, hipStream_t s);   // bilinear RGB u8, every view with blocked == 2 (LDS-staged 16x16 wavefront tiles)
 hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);
+// source-major kernel (gs360_srcmajor.hip): one launch = one level yaw ring that fills its circle
+struct SmTile { int32_t x0, y0, nrows, wch, eoff, nq, pad0, pad1; };   // box of a plan tile: first byte (in the period) / row, rows, 16-byte chunks per row; entries
+struct SmPlan;
+void sm_plan_free(SmPlan* p);
+bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked);
+int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, hipStream_t s, hipError_t* herr);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 void build_coef1d(float* out);             // host: the float32 1-D phase tables (linear, cubic, lanczos4) of the CV_16U samplers, 448

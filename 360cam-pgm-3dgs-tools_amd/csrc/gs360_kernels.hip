@@ -27,6 +27,7 @@
 
 #include "gs360_kernels.h"
 #include "gs360_eqspec.h"
+#include "gs360_blend.h"
 #include "gs360_rowstore.h"
 
 namespace gs360 {
@@ -360,21 +361,7 @@ __device__ __forceinline__ void eq_taps_finish(EqTaps<C>& t) {
     if constexpr (C == 3) ld_rows_rgb_finish(t.raw, t.t0, t.t1);
 }
 
-// Integer multiply-adds as v_dot2_i32_i16: v_perm_b32 gathers two tap bytes into a zero-extended 16-bit pair and one
-// dot instruction multiplies both by a packed pair of weights and accumulates.  Exact integer arithmetic.
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int dot2_i16(uint32_t taps, uint32_t weights, int acc) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, taps), __builtin_bit_cast(s16x2, weights), acc, false);
-}
-// First multiply-add of a chain: the start value (rounding constant) rides in a SCALAR register as the VOP3P form's third operand.
-// Left to the compiler a constant start becomes v_mov + the accumulate-in-place VOP2 form -- one more vector instruction per chain.
-__device__ __forceinline__ int dot2_i16_from(uint32_t taps, uint32_t weights, int start_uniform) {
-    int r;
-    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(taps), "v"(weights), "s"(start_uniform));
-    return r;
-}
-// v_perm_b32(a, b, sel) selector: result = (0, hi, 0, lo) where lo / hi index the bytes of {a (4..7), b (0..3)}
-#define GS360_PAIR(lo, hi) (0x0c000c00u | ((uint32_t)(hi) << 16) | (uint32_t)(lo))
+// (dot2_i16, dot2_i16_from, GS360_PAIR and the RGB row blend: gs360_blend.h, shared with gs360_srcmajor.hip)
 
 template <int C>
 __device__ __forceinline__ void eq_blend_f(const EqTaps<C>& t, const int fx, const int fy, uint32_t (&out)[4]);
@@ -389,12 +376,9 @@ __device__ __forceinline__ void eq_blend_f(const EqTaps<C>& t, const int fx, con
     const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);             // < 2^22
     const uint32_t wr0 = __umul24(ah, (uint32_t)(32 - fy)), wr1 = __umul24(ah, (uint32_t)fy);
     if constexpr (C == 3) {          // row bytes: r0 g0 b0 r1 | g1 b1 . .
-        out[0] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.x, t.t1.x, GS360_PAIR(0, 3)), wr1,
-                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 3)), wr0, 512)) >> 10;
-        out[1] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(1, 4)), wr1,
-                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(1, 4)), wr0, 512)) >> 10;
-        out[2] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(2, 5)), wr1,
-                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(2, 5)), wr0, 512)) >> 10;
+        uint32_t px[3];
+        blend_rgb_rows(t.t0, t.t1, fx, fy, px);
+        out[0] = px[0]; out[1] = px[1]; out[2] = px[2];
     } else if constexpr (C == 4) {   // row bytes: r0 g0 b0 a0 | r1 g1 b1 a1
 #pragma unroll
         for (int c = 0; c < 4; ++c)

@@ -1,0 +1,396 @@
+// gs360_srcmajor.hip -- source-major equirect kernel for strongly minified level yaw rings (BASELINE cfg2: 8K -> 6 x 800^2).
+//
+// The gather kernels (gs360_kernels.hip) fetch, per view, every 128-byte source line a view's taps touch: at 4.6 source texels per
+// output pixel that is 718 k lines per 8K frame for six views whose UNION is 413 k lines (a view uses 6 of every 14 bytes of a line and
+// neighbouring views of a ring overlap by half their field).  Here the work is cut along the SOURCE instead: a workgroup owns a tile of
+// the panorama (a box of ~768 bytes x ~32 rows), streams it ONCE into LDS with global_load_lds_dwordx4 and renders, for every view that
+// looks at it, the output pixels whose tap pair starts inside it -- from a static plan.  Replaces the same call sites as the gather
+// kernel (one `ffmpeg -vf v360` process per (frame, view), gs360_360PerspCut.py:310-314; the yaw ring of PC:794 is what makes views
+// overlap), results bit-identical: coordinates come from the EQ-SPEC functions themselves (eq_plan_coords_kernel), the blend is the
+// gather kernels' blend.
+//
+// What makes one plan serve a whole call:
+//   * a level ring of N equally spaced views is periodic in the source: member q sees what member 0 sees, d = W / N texels further
+//     (x0i32 differs by whole multiples of 32 d, everything else is equal), so the plan lists only period 0 -- source bytes [0, 3 d) of
+//     every row -- with the view index relative to the period; period k renders view (rel + k) mod N;
+//   * the lower half of a level view is the upper half upside down, exactly (sy' = 32 H - 32 - sy: rint is odd, no additive constant
+//     inside it): the same plan with the tile's rows copied in reverse order and the output row mirrored.
+// A tile therefore has 2 N images; a workgroup walks G of them (two alternating LDS buffers: one loader wavefront copies image g + 1
+// while eight consumer wavefronts render image g), with the tile's plan entries LDS-resident for all of them.
+//
+// Ownership is per output QUAD (four pixels = 12 bytes = three dwords, all rendered by the tile that holds the first pixel's taps), so
+// every store is a dword store and no output byte is written twice.  Plan entry: per quad a header (column | row << 12 | view << 24), per
+// pixel (LDS byte offset of the top-left tap | fx << 17 | fy << 22).
+//
+// Measured on MI355X (profiles/r05/srcmajor/): what bounds it is bytes moved -- tiles (64 MB per frame incl. the boxes' halos) + stores
+// -- at the ~5.5 TB/s the memory system sustains for this mix; arithmetic, LDS and the texture-address path all hide under the stream.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gs360_blend.h"
+#include "gs360_eqspec.h"
+#include "gs360_kernels.h"
+
+namespace gs360 {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_void_t;
+
+constexpr int kSmConsumers = 8;                         // consumer wavefronts per workgroup (+ one loader)
+constexpr int kSmMaxImages = 12;                        // images of a tile one workgroup walks (G)
+
+// ---- plan coordinates: EQ-SPEC v1 for the upper half of the ring's first member, every column by the general formula ----------------
+__global__ __launch_bounds__(256) void eq_plan_coords_kernel(const EqLaunch L, int2* __restrict__ out, int rows) {
+    const EqView& V = L.view[0];
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    const int ic = min(i, V.out_w - 1);                  // (every lane evaluates: eq_sqrt's fallback branch is wave-uniform)
+    const float x = (float)(2 * ic + 1 - V.out_w) * V.sxu;
+    const float yv = (float)(2 * j + 1 - V.out_h) * V.syv;
+    const float bz = __builtin_fmaf(V.sp, yv, V.cp);
+    const float cy = __builtin_fmaf(-V.cp, yv, V.sp);
+    const float h = eq_sqrt(__builtin_fmaf(x, x, bz * bz));
+    int Kl, Kt;
+    const float rl = eq_atan2_red(x, bz, Kl);
+    const float rt = eq_atan2_red<true>(cy, h, Kt);
+    const int sx = eq_quant_lon(rl, Kl, L, V);
+    const int sy = L.y0i32 - Kt * 8 * L.H - (int)__builtin_rintf(rt * L.ky32);
+    if (i < V.out_w && j < rows) out[(size_t)j * V.out_w + i] = make_int2(sx, sy);
+}
+
+struct SmArgs {
+    const uint8_t* src[GS360_MAX_FRAMES];
+    uint8_t* dst[GS360_MAX_FRAMES * GS360_MAX_VIEWS];
+    const SmTile* tiles;
+    const uint32_t* entries;
+    int32_t W, H, N, w, h, PB;
+    int32_t G, groups_per_tile, groups_per_frame, total_groups, gchunk;
+    int32_t buf_bytes, ent_bytes;
+    int32_t qmap[GS360_MAX_VIEWS];        // ring position -> view index of the call
+    int64_t src_stride, dst_stride;
+};
+static_assert(sizeof(SmArgs) <= 4096, "SmArgs travels as a kernel argument");
+
+__global__ __launch_bounds__(64 * (kSmConsumers + 1)) void eq_srcmajor_kernel(const SmArgs P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+    __shared__ uint8_t* s_dst[kSmMaxImages * GS360_MAX_VIEWS];
+    // XCD-aware order: XCD x (= block % 8) walks a contiguous chunk of the (frame, tile, image group) order, so the images of a tile,
+    // the neighbouring tiles (whose boxes share halo lines) and the tiles that complete each other's output lines meet in one L2
+    const int b = blockIdx.x;
+    const int t = (b & 7) * P.gchunk + (b >> 3);
+    if (t >= P.total_groups) return;
+    const int f = t / P.groups_per_frame;
+    const int r = t - f * P.groups_per_frame;
+    const int ti = r / P.groups_per_tile, g0 = (r - ti * P.groups_per_tile) * P.G;
+    const SmTile T = P.tiles[ti];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = P.G;
+    uint8_t* const s_ent = s_lds;                        // [headers: nq dwords][pixel words: 4 nq dwords]
+    uint8_t* const s_tile = s_lds + P.ent_bytes;         // two tile buffers of buf_bytes
+    if (tid < G * P.N) {                                 // destination of (image, relative view): period k renders view (rel + k) mod N
+        const int g = tid / P.N, v = tid - g * P.N;
+        int q = v + ((g0 + g) >> 1);
+        if (q >= P.N) q -= P.N;
+        s_dst[g * GS360_MAX_VIEWS + v] = P.dst[f * P.N + P.qmap[q]];
+    }
+    const uint8_t* __restrict__ src = P.src[f];
+    const int rowbytes = 3 * P.W;
+    const int pitch = T.wch * 16;
+    const int nq = T.nq;
+    // image = period * 2 + flip.  One copy instruction per (box row, block of 64 chunks); the exec mask is set ONCE per block of chunks:
+    // a mask that changes from row to row makes the wavefront wait for each copy's address phase (measured: 2-3x the issue time).
+    auto dma = [&](const int img, uint8_t* const buf) {
+        const int k = img >> 1;
+        const bool flip = img & 1;
+        const int xk = T.x0 + k * P.PB;                  // < rowbytes
+        for (int cb = 0; cb < T.wch; cb += 64) {
+            int x = xk + (cb + lane) * 16;               // the box may run across the 360-degree seam
+            if (x >= rowbytes) x -= rowbytes;
+            if (cb + lane < T.wch) {
+                int y = flip ? P.H - 1 - T.y0 : T.y0;    // a flipped image takes the mirrored rows in reverse order
+                const int ystep = flip ? -1 : 1;
+                for (int row = 0; row < T.nrows; ++row, y += ystep) {
+                    const int yc = min(max(y, 0), P.H - 1);                 // EQ-SPEC clamps tap rows to [0, H - 1]
+                    const uint8_t* rowp = src + (size_t)yc * P.src_stride;
+                    __builtin_amdgcn_global_load_lds((global_void_t*)(rowp + (uint32_t)x), (lds_void_t*)(buf + row * pitch + cb * 16), 16, 0, 0);
+                }
+            }
+        }
+    };
+    if (wave == 0) {
+        const uint8_t* ge = reinterpret_cast<const uint8_t*>(P.entries + T.eoff);
+        const int eb = 20 * nq;                          // a multiple of 64 bytes (nq % 16 == 0)
+        for (int o = 0; o < eb; o += 1024)
+            if (o + lane * 16 < eb)
+                __builtin_amdgcn_global_load_lds((global_void_t*)(ge + o + lane * 16), (lds_void_t*)(s_ent + o), 16, 0, 0);
+        dma(g0, s_tile);
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): entries and first image have landed
+    }
+    __builtin_amdgcn_s_barrier();
+    const int k4 = lane & 3;
+    const uint32_t sel = k4 == 0 ? 0x04020100u : (k4 == 1 ? 0x05040201u : 0x06050402u);
+    const uint32_t* const e_hdr = reinterpret_cast<const uint32_t*>(s_ent);
+    const uint32_t* const e_px = e_hdr + nq;
+    const int npx = 4 * nq;
+    const int dstride = (int)P.dst_stride;               // bytes per output row (a multiple of 4)
+    for (int g = 0; g < G; ++g) {
+        uint8_t* const cur_buf = s_tile + (g & 1) * P.buf_bytes;
+        if (wave == 0) {
+            if (g + 1 < G) dma(g0 + g + 1, s_tile + ((g + 1) & 1) * P.buf_bytes);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else {
+            // Consumers: a pixel per lane (neighbouring lanes' tap windows are 14 bytes apart: a quad per lane would scatter them 55 bytes
+            // apart, 4-way bank conflicts), no memory reads at all -- plan entries and taps come from LDS -- so nothing in this loop ever
+            // waits for the memory queue the copies sit in; the only memory instruction is the store.
+            const bool flip = (g0 + g) & 1;
+            const int jbase = flip ? P.h - 1 : 0, jsgn = flip ? -1 : 1;
+            for (int i0 = (wave - 1) * 64; i0 < npx; i0 += 64 * kSmConsumers) {
+                const uint32_t pw = e_px[i0 + lane];
+                const uint32_t hd = e_hdr[(i0 + lane) >> 2];
+                const uint32_t o0 = pw & 0x1ffffu, o1 = o0 + (uint32_t)pitch;
+                const int fx = (pw >> 17) & 31, fy = (pw >> 22) & 31;
+                const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (o0 & ~3u));
+                const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (o1 & ~3u));
+                const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+                uint2 t0, t1;                            // rows iy, iy + 1: bytes r0 g0 b0 r1 | g1 b1 . .
+                t0.x = __builtin_amdgcn_alignbyte(a1, a0, o0); t0.y = __builtin_amdgcn_alignbyte(a2, a1, o0);
+                t1.x = __builtin_amdgcn_alignbyte(b1, b0, o1); t1.y = __builtin_amdgcn_alignbyte(b2, b1, o1);
+                uint32_t px[3];
+                blend_rgb_rows(t0, t1, fx, fy, px);
+                const uint32_t pk = px[0] | (px[1] << 8) | (px[2] << 16);
+                // lanes 4m .. 4m + 3 hold a quad: lane k cuts dword k of its 12 bytes out of pixels k and k + 1
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+                const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
+                const int i = hd & 0xfff, j = (hd >> 12) & 0xfff, vrel = (hd >> 24) & 15;    // the quad's first column, its row, relative view
+                const int jj = jbase + jsgn * j;
+                uint8_t* const d = s_dst[g * GS360_MAX_VIEWS + vrel];
+                // lane 3 repeats lane 2's store (same dword, same address): an UNCONDITIONAL store keeps the loop body straight-line
+                const uint32_t off = (uint32_t)(jj * dstride + i * 3) + 4u * (uint32_t)min(k4, 2);
+                const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw, 0xA4, 0xf, 0xf, false);    // quad_perm [0,1,2,2]
+                *(__attribute__((address_space(1))) uint32_t*)((uintptr_t)d + off) = dwq;      // (a global, not a flat store: the pointer came from LDS)
+            }
+        }
+        __builtin_amdgcn_s_barrier();                    // image g + 1 has landed AND every consumer is done with image g's buffer
+    }
+}
+
+}  // namespace
+
+// ---- host side: the plan ------------------------------------------------------------------------------------------------------------
+struct SmPlan {
+    // key
+    int W = 0, H = 0, N = 0, w = 0, h = 0, Bx = 0, R = 0;
+    uint32_t sxu = 0, syv = 0, x0f = 0;    // float bits
+    int x0i = 0;
+    // contents
+    SmTile* d_tiles = nullptr;
+    uint32_t* d_entries = nullptr;
+    int n_tiles = 0, buf_bytes = 0, ent_bytes = 0, PB = 0;
+    uint64_t stamp = 0;
+};
+
+void sm_plan_free(SmPlan* p) {
+    if (!p) return;
+    if (p->d_tiles) (void)hipFree(p->d_tiles);
+    if (p->d_entries) (void)hipFree(p->d_entries);
+    delete p;
+}
+
+namespace {
+
+uint32_t fbits(float v) { uint32_t b; std::memcpy(&b, &v, 4); return b; }
+
+struct Quad { int32_t tid, vrel, j, i0; int32_t xr[4], iy[4], ph[4]; };
+
+// 0: plan built; 1: this geometry does not fit the kernel (caller falls back to the gather kernels); < 0: HIP error in *herr
+int sm_build_plan(const EqLaunch& L0, int N, int Bx, int R, size_t lds_limit, hipStream_t s, SmPlan** out, hipError_t* herr) {
+    const EqView& V = L0.view[0];
+    const int W = L0.W, w = V.out_w, h = V.out_h;
+    const int hh = (h + 1) / 2;
+    const int PB = 3 * (W / N), rowbytes = 3 * W;
+    int2* d_xy = nullptr;
+    std::vector<int2> xy((size_t)hh * w);
+    if ((*herr = hipMalloc((void**)&d_xy, xy.size() * sizeof(int2))) != hipSuccess) return -1;
+    hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, hh), dim3(256), 0, s, L0, d_xy, hh);
+    *herr = hipGetLastError();
+    if (*herr == hipSuccess) *herr = hipMemcpyAsync(xy.data(), d_xy, xy.size() * sizeof(int2), hipMemcpyDeviceToHost, s);
+    if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
+    (void)hipFree(d_xy);
+    if (*herr != hipSuccess) return -1;
+
+    int ytop = 1 << 30;
+    for (const int2& q : xy) ytop = std::min(ytop, q.y >> 5);
+    if (ytop < 0) return 1;                              // a view that reaches the pole row: the gather kernels' clamp path
+    const int ntx = (PB + Bx - 1) / Bx;
+    const int nqx = w / 4;
+    std::vector<Quad> quads((size_t)hh * nqx);
+    for (int j = 0; j < hh; ++j)
+        for (int qx = 0; qx < nqx; ++qx) {
+            Quad& Q = quads[(size_t)j * nqx + qx];
+            const int2* p = &xy[(size_t)j * w + 4 * qx];
+            const int xb0 = 3 * (p[0].x >> 5);
+            const int p0 = xb0 / PB;
+            Q.vrel = (N - p0 % N) % N;
+            Q.j = j; Q.i0 = 4 * qx;
+            for (int k = 0; k < 4; ++k) {
+                int dx = 3 * (p[k].x >> 5) - xb0;        // longitude grows with the column; unwrap across the seam
+                if (dx < 0) dx += rowbytes;
+                if (dx > rowbytes / 2) return 1;         // (not a monotone quad: cannot happen for fov < 180, refuse rather than trust)
+                Q.xr[k] = xb0 - p0 * PB + dx;            // relative to the QUAD's period (may run past its end: the copy wraps)
+                Q.iy[k] = p[k].y >> 5;
+                Q.ph[k] = (p[k].x & 31) | ((p[k].y & 31) << 5);
+            }
+            Q.tid = ((Q.iy[0] - ytop) / R) * ntx + Q.xr[0] / Bx;
+        }
+    std::sort(quads.begin(), quads.end(), [](const Quad& a, const Quad& b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        if (a.vrel != b.vrel) return a.vrel < b.vrel;
+        if (a.j != b.j) return a.j < b.j;
+        return a.i0 < b.i0;
+    });
+    std::vector<SmTile> tiles;
+    std::vector<uint32_t> ent;
+    int buf_bytes = 0, ent_bytes = 0;
+    for (size_t a = 0; a < quads.size();) {
+        size_t b = a;
+        int xmin = 1 << 30, xmax = 0, ymin = 1 << 30, ymax = 0;
+        while (b < quads.size() && quads[b].tid == quads[a].tid) {
+            for (int k = 0; k < 4; ++k) {
+                xmin = std::min(xmin, quads[b].xr[k]); xmax = std::max(xmax, quads[b].xr[k]);
+                ymin = std::min(ymin, quads[b].iy[k]); ymax = std::max(ymax, quads[b].iy[k]);
+            }
+            ++b;
+        }
+        SmTile T;
+        T.x0 = xmin & ~15;
+        T.wch = (xmax + 6 - T.x0 + 15) / 16;
+        T.y0 = ymin;
+        T.nrows = ymax - ymin + 2;
+        const int nq = (int)(b - a), nqp = (nq + 15) / 16 * 16;
+        T.eoff = (int32_t)ent.size();
+        T.nq = nqp;
+        T.pad0 = T.pad1 = 0;
+        const int pitch = T.wch * 16;
+        if ((size_t)T.nrows * pitch >= (1u << 17) || T.x0 >= PB || T.wch * 16 > rowbytes) return 1;
+        ent.resize(ent.size() + 5 * (size_t)nqp);
+        uint32_t* hdr = ent.data() + T.eoff;
+        uint32_t* px = hdr + nqp;
+        for (int q = 0; q < nqp; ++q) {
+            const Quad& Q = quads[a + std::min(q, nq - 1)];         // padding repeats the last quad: same values to the same addresses
+            hdr[q] = (uint32_t)Q.i0 | ((uint32_t)Q.j << 12) | ((uint32_t)Q.vrel << 24);
+            for (int k = 0; k < 4; ++k)
+                px[4 * q + k] = (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0)) | ((uint32_t)Q.ph[k] << 17);
+        }
+        buf_bytes = std::max(buf_bytes, T.nrows * pitch);
+        ent_bytes = std::max(ent_bytes, 20 * nqp);
+        tiles.push_back(T);
+        a = b;
+    }
+    buf_bytes = (buf_bytes + 63) & ~63;
+    ent_bytes = (ent_bytes + 63) & ~63;
+    if ((size_t)ent_bytes + 2 * (size_t)buf_bytes > lds_limit) return 1;
+    SmPlan* p = new (std::nothrow) SmPlan();
+    if (!p) { *herr = hipErrorOutOfMemory; return -1; }
+    p->n_tiles = (int)tiles.size(); p->buf_bytes = buf_bytes; p->ent_bytes = ent_bytes; p->PB = PB;
+    *herr = hipMalloc((void**)&p->d_tiles, tiles.size() * sizeof(SmTile));
+    if (*herr == hipSuccess) *herr = hipMalloc((void**)&p->d_entries, ent.size() * 4 + 1024);      // (slack: the entry copy reads whole 16-byte chunks)
+    if (*herr == hipSuccess) *herr = hipMemcpyAsync(p->d_tiles, tiles.data(), tiles.size() * sizeof(SmTile), hipMemcpyHostToDevice, s);
+    if (*herr == hipSuccess) *herr = hipMemcpyAsync(p->d_entries, ent.data(), ent.size() * 4, hipMemcpyHostToDevice, s);
+    if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);     // the host vectors go out of scope
+    if (*herr != hipSuccess) { sm_plan_free(p); return -1; }
+    *out = p;
+    return 0;
+}
+
+}  // namespace
+
+// Can this launch (one ring, already grouped by the caller) take the source-major kernel?  Checks only; builds nothing.
+bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked) {
+    if (C != 3 || esize != 1 || interp != GS360_INTERP_LINEAR || masked) return false;
+    if (L.n_rings != 1 || L.ring_count[0] != L.n_views) return false;
+    const int N = L.n_views;
+    const EqView& V = L.view[0];
+    if (N < 2 || N > GS360_MAX_VIEWS || !V.level || V.fish) return false;
+    if (L.W % N || (3 * L.W) % 16 || (3 * (L.W / N)) % 16) return false;
+    if (V.out_w % 4 || V.out_w >= 4096 || V.out_h >= 4096 || V.out_w < 8 || V.out_h < 2) return false;
+    if (L.src_stride % 16) return false;
+    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
+    if (dstride % 4 || dstride * V.out_h >= ((int64_t)1 << 31)) return false;
+    for (int f = 0; f < L.n_frames; ++f)
+        if ((uintptr_t)L.src[f] & 15) return false;
+    for (int i = 0; i < L.n_frames * N; ++i)
+        if ((uintptr_t)L.dst[i] & 3) return false;
+    // every ring position taken exactly once: member offsets are distinct whole multiples of d = W / N texels
+    const int d32 = 32 * (L.W / N);
+    int seen = 0;
+    for (int k = 0; k < N; ++k) {
+        if (L.view[k].flip) return false;
+        int off = L.view[k].x0i32 - V.x0i32;
+        if (off < 0) off += 32 * L.W;
+        if (off % d32) return false;
+        seen |= 1 << (off / d32);
+    }
+    return seen == (1 << N) - 1;
+}
+
+// Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
+// Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
+int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, hipStream_t s, hipError_t* herr) {
+    static uint64_t clock = 0;
+    const EqView& V = L.view[0];
+    const int N = L.n_views;
+    *herr = hipSuccess;
+    SmPlan* plan = nullptr;
+    for (SmPlan* p : cache)
+        if (p->W == L.W && p->H == L.H && p->N == N && p->w == V.out_w && p->h == V.out_h && p->Bx == Bx && p->R == R && p->sxu == fbits(V.sxu) &&
+            p->syv == fbits(V.syv) && p->x0f == fbits(V.x0f32) && p->x0i == V.x0i32) { plan = p; break; }
+    if (!plan) {
+        int rr = R, rc = 1;
+        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2)) rc = sm_build_plan(L, N, Bx, rr, lds_limit, s, &plan, herr);
+        if (rc != 0) return rc;
+        plan->W = L.W; plan->H = L.H; plan->N = N; plan->w = V.out_w; plan->h = V.out_h; plan->Bx = Bx; plan->R = R;
+        plan->sxu = fbits(V.sxu); plan->syv = fbits(V.syv); plan->x0f = fbits(V.x0f32); plan->x0i = V.x0i32;
+        if (cache.size() >= cap) {                       // evict the least recently used plan (its last launch is ordered before this free by hipFree's sync)
+            size_t lru = 0;
+            for (size_t i = 1; i < cache.size(); ++i) if (cache[i]->stamp < cache[lru]->stamp) lru = i;
+            sm_plan_free(cache[lru]);
+            cache.erase(cache.begin() + (long)lru);
+        }
+        cache.push_back(plan);
+    }
+    plan->stamp = ++clock;
+    SmArgs P;
+    std::memset(&P, 0, sizeof(P));
+    for (int f = 0; f < L.n_frames; ++f) P.src[f] = L.src[f];
+    for (int i = 0; i < L.n_frames * N; ++i) P.dst[i] = L.dst[i];
+    P.tiles = plan->d_tiles; P.entries = plan->d_entries;
+    P.W = L.W; P.H = L.H; P.N = N; P.w = V.out_w; P.h = V.out_h; P.PB = plan->PB;
+    int G = 1;
+    for (int g = 1; g <= kSmMaxImages; ++g) if ((2 * N) % g == 0) G = g;
+    P.G = G; P.groups_per_tile = 2 * N / G; P.groups_per_frame = plan->n_tiles * P.groups_per_tile;
+    P.total_groups = P.groups_per_frame * L.n_frames; P.gchunk = (P.total_groups + 7) / 8;
+    P.buf_bytes = plan->buf_bytes; P.ent_bytes = plan->ent_bytes;
+    const int d32 = 32 * (L.W / N);
+    for (int k = 0; k < N; ++k) {
+        int off = L.view[k].x0i32 - V.x0i32;
+        if (off < 0) off += 32 * L.W;
+        P.qmap[off / d32] = k;
+    }
+    P.src_stride = L.src_stride;
+    P.dst_stride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
+    const size_t lds = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes;
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        *herr = hipFuncSetAttribute((const void*)eq_srcmajor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);
+        if (*herr != hipSuccess) return -1;
+        lds_attr = lds_limit;
+    }
+    hipLaunchKernelGGL(eq_srcmajor_kernel, dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
+    *herr = hipGetLastError();
+    return *herr == hipSuccess ? 0 : -1;
+}
+
+}  // namespace gs360

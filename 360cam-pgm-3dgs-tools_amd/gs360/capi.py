@@ -23,7 +23,7 @@ MAX_FRAMES = 16
 
 EXPORTS = (
     "gs360_abi_version", "gs360_device_count", "gs360_last_error", "gs360_ctx_create", "gs360_ctx_destroy",
-    "gs360_device_info", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
+    "gs360_device_info", "gs360_ctx_set_option", "gs360_ctx_get_option", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
     "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_dev_bswap16", "gs360_sync", "gs360_event_record",
     "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_equirect_views_masked_u8", "gs360_remap_table_u8",
     "gs360_fisheye_views_u8", "gs360_remap_tables_u8", "gs360_map_plan_create", "gs360_map_plan_destroy", "gs360_remap_plans_u8", "gs360_remap_plans_u16",
@@ -92,6 +92,8 @@ def load_library(path=None):
         L.gs360_ctx_create.argtypes = [i, i, pvp]
         L.gs360_ctx_destroy.argtypes = [vp]
         L.gs360_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.gs360_ctx_set_option.argtypes = [vp, C.c_char_p, i]
+        L.gs360_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.gs360_dev_alloc.argtypes = [vp, sz, pvp]
         L.gs360_dev_free.argtypes = [vp, vp]
         L.gs360_host_alloc.argtypes = [vp, sz, pvp]
@@ -274,6 +276,32 @@ class Context:
 
     def sync(self, slot=-1):
         _check(self.L.gs360_sync(self.handle, slot), self.L)
+
+    def set_option(self, key, value):
+        """kernel-selection switch of this context (include/gs360.h: gs360_ctx_set_option); results never depend on it"""
+        _check(self.L.gs360_ctx_set_option(self.handle, key.encode(), int(value)), self.L)
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        _check(self.L.gs360_ctx_get_option(self.handle, key.encode(), C.byref(v)), self.L)
+        return int(v.value)
+
+    def options(self, **kw):
+        """context manager: set options, restore the previous values on exit (tests)"""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.old = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_inner, *exc):
+                for k, v in self_inner.old.items():
+                    ctx.set_option(k, v)
+                return False
+        return _Scope()
 
     def event_record(self, slot, idx):
         _check(self.L.gs360_event_record(self.handle, slot, idx), self.L)

@@ -88,6 +88,22 @@ int gs360_last_error(char *buf, size_t buf_len);
 int gs360_ctx_create(int device, int n_slots, gs360_ctx **out);
 int gs360_ctx_destroy(gs360_ctx *ctx);
 int gs360_device_info(gs360_ctx *ctx, char *name, size_t name_len, int32_t *cu_count, uint64_t *hbm_bytes);
+/* Context options: kernel-selection switches for tests, probes and A/B runs (the defaults are the measured optima; results never depend
+ * on them).  The reference has no counterpart (it shells out to ffmpeg / calls cv2.remap: PC:310-314, DF:2001); a binding needs them
+ * only to pin a kernel variant.  gs360_ctx_create seeds the documented user switches ONCE from the environment (GS360_STAGE,
+ * GS360_LANEMAP, GS360_SRCMAJOR, GS360_COLOR_CUBE); after that the library never reads the environment -- set options here instead.
+ *   "lanemap"        -1 auto | 0 rows | 1 blocked       gather kernels' lane map
+ *   "stage"          -1 auto | 0 never | 1 always       LDS-staged equirect kernel
+ *   "srcmajor"       -1 auto | 0 never | 1 always       source-major equirect kernel (level yaw rings); "srcmajor_bx" (bytes per tile row,
+ *                                                       multiple of 16), "srcmajor_rows" (source rows per tile)
+ *   "ring"           0 auto | n                         at most n views share one coordinate evaluation
+ *   "xcd_group"      -2 auto | -1 chunks | g            tile order across the XCDs
+ *   "eq_persist", "table_persist"                       grid caps of the persistent kernels (table_persist: -1 auto)
+ *   "lanczos_table", "table_rows"                       0 | 1: A/B references of the Lanczos-4 weight rebuild and the flat spans
+ *   "color_cube"     -1 / 1 tabulate | 0 per pixel      8-bit colour stage (read by gs360_color_plan_create)
+ * Unknown keys and out-of-range values are GS360_ERR_ARG.  Thread-safe; a change applies to calls that start after it. */
+int gs360_ctx_set_option(gs360_ctx *ctx, const char *key, int value);
+int gs360_ctx_get_option(gs360_ctx *ctx, const char *key, int *value);
 
 /* ---- memory (device buffers carry 64 B of readable slack after the requested size) ---------
  * Images handed to the hot-path entry points must come with that slack (the aligned 12- / 16-byte tap reads of the last

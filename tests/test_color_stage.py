@@ -252,9 +252,9 @@ def test_gpu_full_size_lens_image_33_cube(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("space", ["srgb", "passthrough"])
-def test_gpu_cube_equals_per_pixel_evaluation_on_every_colour(ctx, space, monkeypatch):
+def test_gpu_cube_equals_per_pixel_evaluation_on_every_colour(ctx, space):
     """the 2^24-entry cube a plan applies is the per-pixel evaluation of every 8-bit colour: one 4096x4096 image that holds each
-    colour once goes through a plan with the cube and through one without (GS360_COLOR_CUBE=0), RGB and BGR, and a strided sample
+    colour once goes through a plan with the cube and through one without (context option "color_cube" = 0), RGB and BGR, and a strided sample
     of rows through the oracle"""
     table, dmin, dmax = lut_of("dom9")
     v = np.arange(1 << 24, dtype=np.uint32)
@@ -265,21 +265,22 @@ def test_gpu_cube_equals_per_pixel_evaluation_on_every_colour(ctx, space, monkey
     for red in (0, 2):
         out = {}
         for cube in ("1", "0"):
-            monkeypatch.setenv("GS360_COLOR_CUBE", cube)
-            stage = color.ColorStage(color.CubeLUT(table.shape[0], table, dmin, dmax), space)
-            out[cube] = stage.apply(ctx, image, red_index=red)
-            stage.close()
+            with ctx.options(color_cube=int(cube)):
+                stage = color.ColorStage(color.CubeLUT(table.shape[0], table, dmin, dmax), space)
+                out[cube] = stage.apply(ctx, image, red_index=red)
+                stage.close()
         assert np.array_equal(out["1"], out["0"]), (space, red)
         want = color_np.color_pipeline(image[rows], table, dmin, dmax, space, red_index=red)
         assert np.array_equal(out["1"][rows], want), (space, red)
     # 4 channels (alpha passes through) and the byte path (odd width) read the same cube
-    monkeypatch.setenv("GS360_COLOR_CUBE", "1")
+    ctx.set_option("color_cube", 1)
     stage = color.ColorStage(color.CubeLUT(table.shape[0], table, dmin, dmax), space)
     rgba = np.concatenate([image[:64, :1021], rng.integers(0, 256, (64, 1021, 1), dtype=np.uint8)], -1)
     got = stage.apply(ctx, rgba, red_index=2)
     assert np.array_equal(got[..., 3], rgba[..., 3])
     assert np.array_equal(got[..., :3], color_np.color_pipeline(np.ascontiguousarray(rgba[..., :3]), table, dmin, dmax, space, red_index=2))
     stage.close()
+    ctx.set_option("color_cube", -1)
 
 
 @pytest.mark.gpu

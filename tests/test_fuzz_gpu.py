@@ -9,21 +9,27 @@ from conftest import ROOT
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanemap,ring", [("", ""), ("rows", ""), ("blocked", ""), ("", "1"), ("blocked", "3"), ("staged", ""), ("staged", "2")])
+@pytest.mark.parametrize("lanemap,ring", [("", ""), ("rows", ""), ("blocked", ""), ("", "1"), ("blocked", "3"), ("staged", ""), ("staged", "2"),
+                                          ("srcmajor", ""), ("srcmajor-only", "")])
 def test_fuzz_parity_short(lanemap, ring):
-    """lanemap forces one lane map of the equirect kernel, ring caps the members of a yaw ring (1 = no coordinate sharing)"""
-    import os
-    env = dict(os.environ)
-    env.pop("GS360_LANEMAP", None)
-    env.pop("GS360_RING", None)
-    env.pop("GS360_STAGE", None)
+    """lanemap forces one lane map of the equirect kernel, ring caps the members of a yaw ring (1 = no coordinate sharing); "srcmajor" forces
+    the source-major kernel onto every call whose geometry fits it, "srcmajor-only" spends the whole run on such rings (context options:
+    include/gs360.h, gs360_ctx_set_option -- the library reads no environment variable after context creation)"""
+    opts, extra = [], []
     if lanemap == "staged":                            # the LDS-staged kernel forced on every call that can take it (auto: only calls dominated by pitched, >= 1.75-texel-step views)
-        env["GS360_LANEMAP"], env["GS360_STAGE"] = "rows", "1"
+        opts += ["lanemap=0", "stage=1"]
+    elif lanemap == "srcmajor":
+        opts += ["srcmajor=1"]
+    elif lanemap == "srcmajor-only":
+        opts += ["srcmajor=1"]
+        extra = ["--only", "srcmajor"]
     elif lanemap:
-        env["GS360_LANEMAP"] = lanemap
+        opts += [f"lanemap={1 if lanemap == 'blocked' else 0}"]
     if ring:
-        env["GS360_RING"] = ring
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "fuzz_parity.py"), "--seconds", "8", "--seed", "77"],
-                       capture_output=True, text=True, timeout=300, env=env)
+        opts += [f"ring={ring}"]
+    cmd = [sys.executable, str(ROOT / "tests" / "tools" / "fuzz_parity.py"), "--seconds", "8", "--seed", "77"] + extra
+    for o in opts:
+        cmd += ["--option", o]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "failures=0" in r.stdout

@@ -4,7 +4,7 @@ cfg1  5760x2880 -> `default` preset 8 x 1600^2                                  
 cfg4  2 x 4000^2 (synthetic) and 2 x 3840^2 (template sensor) -> all 10 SFM10 views in ONE gs360_remap_tables_u8
       launch, linear and cubic                                                 (DF:2001-2014, DF:229-234)
 cfg5  8K -> `fisheyelike` 10 x 2048^2 through gs360_equirect_views_masked_u8 with a seeded disk mask
-The oracle runs on all host threads; every byte of the listed views is compared, the rest by checksums.
+The oracle runs on all host threads; EVERY byte of EVERY view is compared (round-4 VERDICT item 4: no checksum-only view).
 """
 import numpy as np
 import pytest
@@ -13,10 +13,6 @@ import gs360
 from util import HFOV_12MM, HFOV_14MM, HFOV_17MM, PRESET_FISHEYELIKE, TEMPLATE_CALIB, rand_image, ring_views
 
 pytestmark = pytest.mark.gpu
-
-
-def _sums(imgs):
-    return [int(np.asarray(a, np.uint64).sum()) for a in imgs]
 
 
 def _diff(got, want, what):
@@ -31,9 +27,8 @@ def test_cfg1_full_size_default_preset_8x1600(ctx, orc):
     specs = ring_views(8, 1600, HFOV_12MM)
     got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs])
     want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], threads=0)
-    for k in (0, 3, 4):                       # yaw 0, 135, 180 (the seam view): every byte
+    for k in range(len(specs)):               # every byte of all eight views
         _diff(got[k], want[k], f"cfg1 view {k}")
-    assert _sums(got) == _sums(want)
 
 
 def _disk_mask(H, W, seed, n=40):
@@ -48,13 +43,17 @@ def _disk_mask(H, W, seed, n=40):
 
 
 @pytest.mark.parametrize("interp", [1, 2, "staged"])
-def test_cfg5_full_size_fisheyelike_masked_10x2048(ctx, orc, interp, monkeypatch):
+def test_cfg5_full_size_fisheyelike_masked_10x2048(ctx, orc, interp):
     """BASELINE configs[4] as specified: 8K -> fisheyelike 10 x 2048^2 with the keep-mask multiply fused in the launch.
-    "staged" = bilinear forced through the LDS-staged kernel (GS360_STAGE=1; by itself the engine stages only calls dominated by pitched views that step >= 1.75 texels)."""
-    monkeypatch.delenv("GS360_STAGE", raising=False)
-    if interp == "staged":
-        monkeypatch.setenv("GS360_STAGE", "1")
+    "staged" = bilinear forced through the LDS-staged kernel (option "stage" = 1; by itself the engine stages only calls dominated by pitched views that step >= 1.75 texels)."""
+    staged = interp == "staged"
+    if staged:
         interp = 1
+    with ctx.options(stage=1 if staged else -1):
+        _cfg5_masked(ctx, orc, interp)
+
+
+def _cfg5_masked(ctx, orc, interp):
     H, W = 3840, 7680
     src = rand_image(H, W, seed=102)
     mask = _disk_mask(H, W, 103)
@@ -66,9 +65,8 @@ def test_cfg5_full_size_fisheyelike_masked_10x2048(ctx, orc, interp, monkeypatch
     ctx.sync(0)
     got = [ctx.download(d, (2048, 2048, 3)) for d in dsts]
     want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], threads=0, interp=interp, mask=mask)
-    for k in (0, 1, 7):                       # level, +30 pitch, the yaw-180 -30 pitch view: every byte
+    for k in range(len(specs)):               # every byte of all ten views
         _diff(got[k], want[k], f"cfg5 masked view {k} interp={interp}")
-    assert _sums(got) == _sums(want)
     assert all(0.02 < (g == 0).all(axis=2).mean() < 0.9 for g in got)      # the mask removed pixels in every view
     for b in [d_src, d_mask] + dsts:
         ctx.free(b)

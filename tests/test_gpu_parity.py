@@ -27,20 +27,17 @@ def _assert_same(got, want, what):
 
 
 # ---- equirect ---------------------------------------------------------------------------------
-@pytest.fixture(params=["rows", "blocked", "auto", "staged"])
-def lanemap(request, monkeypatch):
-    """the equirect kernel has two lane maps (64-pixel rows / 4x16 patches) chosen per view on the host by the
-    minification; GS360_LANEMAP forces one so that every shape below is checked under both.  "staged" = the LDS-staged
-    kernel forced on (GS360_STAGE=1; 16 x 16 wavefront tiles, boxes copied into LDS, gather form where a box does not qualify)"""
-    monkeypatch.delenv("GS360_STAGE", raising=False)
-    if request.param == "staged":
-        monkeypatch.setenv("GS360_LANEMAP", "rows")
-        monkeypatch.setenv("GS360_STAGE", "1")
-    elif request.param == "auto":
-        monkeypatch.delenv("GS360_LANEMAP", raising=False)
-    else:
-        monkeypatch.setenv("GS360_LANEMAP", request.param)
-    return request.param
+@pytest.fixture(params=["rows", "blocked", "auto", "staged", "srcmajor"])
+def lanemap(request, ctx):
+    """the equirect kernel has two lane maps (64-pixel rows / 4x16 patches) chosen per view on the host by the minification; the context
+    option "lanemap" forces one so that every shape below is checked under both.  "staged" = the LDS-staged kernel forced on (option
+    "stage" = 1; 16 x 16 wavefront tiles, boxes copied into LDS, gather form where a box does not qualify); "srcmajor" = the source-major
+    kernel forced onto every call whose geometry fits it (level yaw rings that fill their circle), everything else as in "auto"."""
+    want = {"rows": dict(lanemap=0), "blocked": dict(lanemap=1), "auto": {}, "staged": dict(lanemap=0, stage=1), "srcmajor": dict(srcmajor=1)}[request.param]
+    base = dict(lanemap=-1, stage=-1, srcmajor=-1)
+    base.update(want)
+    with ctx.options(**base):
+        yield request.param
 
 
 def test_equirect_cfg2_ring_small_source(ctx, orc, lanemap):
@@ -218,10 +215,14 @@ def test_equirect_cubic(ctx, orc, channels, lanemap):
     _assert_same(got, want, f"equirect cubic C={channels}")
 
 
-def test_equirect_cubic_persistent_walk_probe(ctx, orc, monkeypatch):
-    """GS360_EQ_PERSIST (a probe: the C ABI ships the cubic equirect kernels with one tile per workgroup): a capped
+def test_equirect_cubic_persistent_walk_probe(ctx, orc):
+    """option "eq_persist" (a probe: the C ABI ships the cubic equirect kernels with one tile per workgroup): a capped
     grid whose workgroups walk the tile order must render the same bytes, 8- and 16-bit."""
-    monkeypatch.setenv("GS360_EQ_PERSIST", "8")
+    with ctx.options(eq_persist=8):
+        _cubic_persistent_walk(ctx, orc)
+
+
+def _cubic_persistent_walk(ctx, orc):
     src = rand_image(193, 386, c=3, seed=72)
     specs = [(0, 0, 110, 110, 330, 170), (90, 0, 110, 110, 330, 170), (-75.5, 33, 90, 120, 167, 229), (10, -89, 60, 60, 133, 131)]
     got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], interp=gs360.INTERP_CUBIC)
@@ -319,10 +320,14 @@ def test_table_remap_map_plans(ctx, orc, channels, interp, dtype):
 
 
 @pytest.mark.parametrize("persist", ["0", "8", "24"])
-def test_bicubic_persistent_workgroups_walk_every_tile(ctx, orc, persist, monkeypatch):
+def test_bicubic_persistent_workgroups_walk_every_tile(ctx, orc, persist):
     """The bicubic RGB kernels (table + fused fisheye) cap their grid and let each workgroup walk tiles b, b + gridDim.x, ...;
-    GS360_TABLE_PERSIST forces the cap (0 = one tile per workgroup, 8 / 24 = 13-40 tiles per workgroup here)."""
-    monkeypatch.setenv("GS360_TABLE_PERSIST", persist)
+    the option "table_persist" forces the cap (0 = one tile per workgroup, 8 / 24 = 13-40 tiles per workgroup here)."""
+    with ctx.options(table_persist=int(persist)):
+        _bicubic_persistent(ctx, orc)
+
+
+def _bicubic_persistent(ctx, orc):
     H, W, h, w = 211, 300, 150, 333                      # 6 x 10 tiles per job
     src = rand_image(H, W, c=3, seed=71)
     d_src = ctx.to_device(src)
@@ -413,10 +418,10 @@ def test_table_remap_identity_and_shifts(ctx):
 
 
 @pytest.mark.parametrize("interp", [2, 4])
-def test_table_remap_every_phase_and_integer_grid(ctx, orc, interp, monkeypatch):
+def test_table_remap_every_phase_and_integer_grid(ctx, orc, interp):
     """bicubic / Lanczos-4 RGB on windows inside the image: every one of the 32 x 32 sub-pixel phases (the Lanczos kernel rebuilds
     its 2-D weights per pixel from the 1-D table; phase 0 and the patched block of each phase are its special cases), the integer
-    grid (phase 0 everywhere: identity), and the same through the table-reading path (GS360_LANCZOS_TABLE)."""
+    grid (phase 0 everywhere: identity), and the same through the table-reading path (option "lanczos_table")."""
     H, W = 96, 131
     src = rand_image(H, W, c=3, seed=91)
     fy, fx = np.meshgrid(np.arange(32, dtype=np.float32), np.arange(32, dtype=np.float32), indexing="ij")
@@ -430,12 +435,11 @@ def test_table_remap_every_phase_and_integer_grid(ctx, orc, interp, monkeypatch)
     ident = orc.remap_u8(src, xx, yy, interp=interp, border_value=(3, 0, 0, 0))
     inner = (slice(4, H - 5), slice(4, W - 7))
     assert np.array_equal(ident[inner], src[inner])       # OpenCV's table keeps integer positions exact
-    for table_path in ("", "1"):
-        if table_path:
-            monkeypatch.setenv("GS360_LANCZOS_TABLE", table_path)
-        got = ctx.remap(src, mx, my, interpolation=interp, border_value=(3, 0, 0, 0))
-        _assert_same([got], [want], f"all phases interp={interp} table_path={table_path!r}")
-        assert np.array_equal(ctx.remap(src, xx, yy, interpolation=interp, border_value=(3, 0, 0, 0)), ident)
+    for table_path in (0, 1):
+        with ctx.options(lanczos_table=table_path):
+            got = ctx.remap(src, mx, my, interpolation=interp, border_value=(3, 0, 0, 0))
+            _assert_same([got], [want], f"all phases interp={interp} table_path={table_path!r}")
+            assert np.array_equal(ctx.remap(src, xx, yy, interpolation=interp, border_value=(3, 0, 0, 0)), ident)
 
 
 def test_table_remap_fisheye_maps_from_oracle(ctx, orc):
@@ -504,16 +508,12 @@ def test_frame_pipeline_pinned_streams(ctx, orc):
 
 # ---- full BASELINE sizes: bit-exact where the oracle is fast enough, size-independent properties otherwise -------
 def test_full_size_cfg3_full360coverage_checks(ctx, orc):
-    """BASELINE cfg3 frame: 7680x3840 -> 12 x 1600^2 (full360coverage).  Every byte of 3 views (level, +30, -30
-    pitch) against the oracle, plus a checksum over all 12."""
+    """BASELINE cfg3 frame: 7680x3840 -> 12 x 1600^2 (full360coverage).  Every byte of all 12 views against the oracle."""
     src = rand_image(3840, 7680, seed=33)
     specs = [(y, p, HFOV_14MM, HFOV_14MM, 1600, 1600) for y, p in PRESET_FULL360]
     got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs])
-    pick = [0, 1, 8]
-    want = orc.equirect_views_u8(src, [orc.make_view(*specs[k]) for k in pick], threads=0)
-    _assert_same([got[k] for k in pick], want, "cfg3 full size")
-    all_want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], threads=0)
-    assert [int(g.astype(np.uint64).sum()) for g in got] == [int(w.astype(np.uint64).sum()) for w in all_want]
+    want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], threads=0)
+    _assert_same(got, want, "cfg3 full size")
 
 
 def test_full_size_properties_roll_constant_symmetry(ctx):

@@ -106,6 +106,49 @@ def fuzz_equirect(ctx, rng, case):
     return ok
 
 
+def fuzz_srcmajor(ctx, rng, case):
+    """Level yaw rings that fill their circle -- the shape the source-major kernel takes (count | W, (3 W / count) % 16 == 0, view width
+    % 4 == 0): random counts, panorama sizes, fields of view (strong and weak minification), view sizes incl. odd heights, yaw offsets
+    that are NOT whole texels, view orders, several frames, padded destination rows.  The option "srcmajor" decides whether the kernel
+    is actually taken (1: whenever the geometry fits); the result must be the oracle's either way."""
+    count = int(rng.choice([2, 3, 4, 5, 6, 8, 12, 16]))
+    unit = 16 * count // int(np.gcd(16 * count, 3 * 1)) if False else 16 * count        # W multiple of 16 * count keeps both divisibility rules
+    W = unit * int(rng.integers(1, max(2, 2200 // unit)))
+    H = int(rng.choice([W // 2, int(rng.integers(max(2, W // 4), W))]))
+    w = 4 * int(rng.integers(2, 60))
+    h = int(rng.integers(2, 200))
+    hf = float(rng.uniform(20, 170)); vf = float(rng.choice([hf, float(rng.uniform(20, 170))]))
+    off = float(rng.choice([0.0, 0.0, 360.0 / W * int(rng.integers(0, W)), float(rng.uniform(-180, 180))]))
+    order = rng.permutation(count)
+    specs = [(off + int(q) * 360.0 / count, 0.0, hf, vf, w, h) for q in order]
+    nf = int(rng.choice([1, 1, 2, 3]))
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(nf)]
+    d_src = [ctx.to_device(f) for f in frames]
+    views = [gs360.View.make(*s) for s in specs]
+    dpad = int(rng.choice([0, 0, 4, 8, 3]))
+    dstride = w * 3 + dpad if dpad else 0
+    d_out = [ctx.alloc((dstride or w * 3) * h + 64) for _ in range(nf * count)]
+    for b in d_out:
+        ctx.memset(b, 0xAB)
+    ctx.equirect_views_dev(d_src, W, H, 3, views, d_out, dst_stride=dstride)
+    ok = True
+    for f in range(nf):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        for k, s in enumerate(specs):
+            raw = ctx.download(d_out[f * count + k], (h, dstride or w * 3))
+            got = raw[:, :w * 3].reshape(h, w, 3)
+            if not np.array_equal(got, want[k]):
+                ok = False
+                bad = np.argwhere(got != want[k])
+                print(f"[srcmajor] case {case}: frame {f} view {k} {s} src {W}x{H} count={count} dpad={dpad}: {len(bad)} bytes differ, first at {bad[0].tolist()}")
+            if dstride and not np.all(raw[:, w * 3:] == 0xAB):
+                ok = False
+                print(f"[srcmajor] case {case}: view {k} wrote into the row padding")
+    for b in d_out + d_src:
+        ctx.free(b)
+    return ok
+
+
 def fuzz_table(ctx, rng, case):
     c = int(rng.choice([1, 3, 3, 4]))
     W = int(rng.integers(1, 300))
@@ -329,14 +372,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
+                    help="context option (include/gs360.h: gs360_ctx_set_option), e.g. lanemap=1, stage=1, ring=3, srcmajor=1")
+    ap.add_argument("--only", default="", help="comma list of case families (equirect,table,fisheye,color,u16,srcmajor)")
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=2)
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     t0 = time.time()
-    counts = {"equirect": 0, "table": 0, "fisheye": 0, "color": 0, "u16": 0}
-    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye, "color": fuzz_color, "u16": fuzz_u16}
+    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye, "color": fuzz_color, "u16": fuzz_u16, "srcmajor": fuzz_srcmajor}
+    names = tuple(n for n in fns if not args.only or n in args.only.split(","))
+    counts = {n: 0 for n in names}
     case, failures = 0, 0
     while time.time() - t0 < args.seconds and failures < 5:
-        name = ("equirect", "table", "fisheye", "color", "u16")[case % 5]
+        name = names[case % len(names)]
         rng = np.random.default_rng([args.seed, case])
         if not fns[name](ctx, rng, f"{args.seed}:{case}"):
             failures += 1
