@@ -87,6 +87,7 @@ struct gs360_ctx {
     // Options (gs360_ctx_set_option; seeded ONCE from the environment by gs360_ctx_create for the documented user switches).  The hot
     // path reads these atomics, never the environment: getenv racing a host thread's putenv is undefined behaviour.
     std::atomic<int> opt[kOptCount];
+    std::atomic<int> last_eq_kernel{-1};      // read-only option "last_eq_kernel": 0 gather, 1 LDS-staged, 2 source-major (which kernel the last equirect call launched)
     // source-major plans of this context (gs360_srcmajor.hip), most recent calls' geometries
     std::mutex sm_mutex;
     std::vector<gs360::SmPlan*> sm_plans;
@@ -438,12 +439,22 @@ int gs360_ctx_set_option(gs360_ctx* c, const char* key, int value) {
 
 int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
     if (!c || !key || !value) return fail(GS360_ERR_ARG, "NULL argument");
+    if (!std::strcmp(key, "last_eq_kernel")) {
+        *value = c->last_eq_kernel.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
     for (int k = 0; k < kOptCount; ++k)
         if (!std::strcmp(key, kOpts[k].key)) {
             *value = c->opt[k].load(std::memory_order_relaxed);
             return GS360_OK;
         }
     return fail(GS360_ERR_ARG, "unknown option '%s'", key);
+}
+
+int gs360_device_pci_bus_id(gs360_ctx* c, char* buf, size_t n) {
+    if (!c || !buf || n < 16) return fail(GS360_ERR_ARG, "NULL argument or buffer shorter than 16 bytes");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)n, c->device));
+    return GS360_OK;
 }
 
 int gs360_device_info(gs360_ctx* c, char* name, size_t n, int32_t* cu_count, uint64_t* hbm_bytes) {
@@ -619,6 +630,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         if (mask_stride == 0) mask_stride = (size_t)W;
         if (mask_stride < (size_t)W) return fail(GS360_ERR_ARG, "mask_stride smaller than a row");
         if ((uint64_t)mask_stride * (uint64_t)H >= ((uint64_t)1 << 32)) return fail(GS360_ERR_UNSUPPORTED, "mask too large");
+        if (H + 1 > 65535) return fail(GS360_ERR_UNSUPPORTED, "masked equirect calls take H < 65535 (the mask pack pass launches one grid row per mask row)");
         for (int f = 0; f < n_frames; ++f)
             if (!mask_frames[f]) return fail(GS360_ERR_ARG, "mask_frames[%d] is NULL", f);
     }
@@ -707,13 +719,16 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             {
                 std::lock_guard<std::mutex> lock(c->sm_mutex);
                 rc = sm_launch(Ls[i], c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
-                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), kSmLdsPerGroup, c->stream[slot], &he);
+                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he);
             }
             if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));
             if (rc == 1 && i == 0) ring = false;         // the geometry does not fit the plan format (decided by the first chunk: nothing launched yet)
             else if (rc == 1) return fail(GS360_ERR_HIP, "source-major plan vanished between frame chunks");
         }
-        if (ring) return GS360_OK;
+        if (ring) {
+            c->last_eq_kernel.store(2, std::memory_order_relaxed);
+            return GS360_OK;
+        }
     }
     // LDS-staged kernel (eq_staged_kernel, north_star's "LDS-staged source texels"): bilinear RGB u8 views whose row stride keeps dword
     // alignment from row to row; its wavefront tiles are 16 x 16 pixels of the general (non-level) tiling.  When it is taken
@@ -726,7 +741,8 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // GS360_STAGE=0: never; GS360_STAGE=1: every call that can (tests, probes).
     {
         const int mode = opt_stage;                       // -1 auto
-        bool can = mode != 0 && C == 3 && esize == 1 && interp == GS360_INTERP_LINEAR && (src_stride & 3) == 0;
+        // (the staged kernel forms destination row offsets in 32 bits with a 24-bit multiply: padded strides beyond that take the gather kernels)
+        bool can = mode != 0 && C == 3 && esize == 1 && interp == GS360_INTERP_LINEAR && (src_stride & 3) == 0 && dst_stride < ((size_t)1 << 24);
         double px_all = 0.0, px_win = 0.0;
         for (int k = 0; k < n_views && can; ++k) {
             can = ev[k].blocked == 0;
@@ -736,6 +752,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             px_all += px;
             // (views whose rows are not whole dwords: the staged kernel would write them byte by byte, the gather kernels have a dword path)
             const size_t row_bytes = dst_stride ? dst_stride : (size_t)views[k].width * 3;
+            if ((uint64_t)views[k].height * (uint64_t)row_bytes >= ((uint64_t)1 << 32)) can = false;
             if (!ev[k].level && !ev[k].fish && step >= 1.75 && (row_bytes & 3) == 0 && (views[k].width & 3) == 0) px_win += px;
         }
         if (can && (mode == 1 || 2.0 * px_win > px_all))
@@ -867,6 +884,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             } else {
                 HIP_TRY(launch_equirect(L, C, c->stream[slot]));
             }
+            c->last_eq_kernel.store(staged ? 1 : 0, std::memory_order_relaxed);
         }
         r0 = r1;
     }

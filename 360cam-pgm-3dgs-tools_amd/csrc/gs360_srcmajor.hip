@@ -338,8 +338,7 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked) {
 
 // Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
 // Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, hipStream_t s, hipError_t* herr) {
-    static uint64_t clock = 0;
+int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr) {
     const EqView& V = L.view[0];
     const int N = L.n_views;
     *herr = hipSuccess;
@@ -361,15 +360,20 @@ int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx
         }
         cache.push_back(plan);
     }
-    plan->stamp = ++clock;
+    uint64_t newest = 0;
+    for (SmPlan* p : cache) newest = std::max(newest, p->stamp);
+    plan->stamp = newest + 1;      // (the caller holds the context's plan lock)
     SmArgs P;
     std::memset(&P, 0, sizeof(P));
     for (int f = 0; f < L.n_frames; ++f) P.src[f] = L.src[f];
     for (int i = 0; i < L.n_frames * N; ++i) P.dst[i] = L.dst[i];
     P.tiles = plan->d_tiles; P.entries = plan->d_entries;
     P.W = L.W; P.H = L.H; P.N = N; P.w = V.out_w; P.h = V.out_h; P.PB = plan->PB;
+    // images per workgroup: as many as divide 2 N (the plan entries are copied once per workgroup and the copy of image g + 1 hides behind
+    // image g), but a small job -- the product path renders one frame per call -- keeps at least four workgroups per CU's worth of them
     int G = 1;
-    for (int g = 1; g <= kSmMaxImages; ++g) if ((2 * N) % g == 0) G = g;
+    for (int g = 1; g <= kSmMaxImages; ++g)
+        if ((2 * N) % g == 0 && (g == 1 || (long long)plan->n_tiles * (2 * N / g) * L.n_frames >= 4ll * n_cu)) G = g;
     P.G = G; P.groups_per_tile = 2 * N / G; P.groups_per_frame = plan->n_tiles * P.groups_per_tile;
     P.total_groups = P.groups_per_frame * L.n_frames; P.gchunk = (P.total_groups + 7) / 8;
     P.buf_bytes = plan->buf_bytes; P.ent_bytes = plan->ent_bytes;
@@ -382,12 +386,8 @@ int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx
     P.src_stride = L.src_stride;
     P.dst_stride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
     const size_t lds = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes;
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        *herr = hipFuncSetAttribute((const void*)eq_srcmajor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);
-        if (*herr != hipSuccess) return -1;
-        lds_attr = lds_limit;
-    }
+    *herr = hipFuncSetAttribute((const void*)eq_srcmajor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
+    if (*herr != hipSuccess) return -1;
     hipLaunchKernelGGL(eq_srcmajor_kernel, dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
     *herr = hipGetLastError();
     return *herr == hipSuccess ? 0 : -1;

@@ -23,7 +23,7 @@ MAX_FRAMES = 16
 
 EXPORTS = (
     "gs360_abi_version", "gs360_device_count", "gs360_last_error", "gs360_ctx_create", "gs360_ctx_destroy",
-    "gs360_device_info", "gs360_ctx_set_option", "gs360_ctx_get_option", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
+    "gs360_device_info", "gs360_device_pci_bus_id", "gs360_ctx_set_option", "gs360_ctx_get_option", "gs360_dev_alloc", "gs360_dev_free", "gs360_host_alloc", "gs360_host_free",
     "gs360_upload", "gs360_download", "gs360_dev_memset", "gs360_dev_bswap16", "gs360_sync", "gs360_event_record",
     "gs360_event_elapsed_ms", "gs360_equirect_views_u8", "gs360_equirect_views_masked_u8", "gs360_remap_table_u8",
     "gs360_fisheye_views_u8", "gs360_remap_tables_u8", "gs360_map_plan_create", "gs360_map_plan_destroy", "gs360_remap_plans_u8", "gs360_remap_plans_u16",
@@ -92,6 +92,7 @@ def load_library(path=None):
         L.gs360_ctx_create.argtypes = [i, i, pvp]
         L.gs360_ctx_destroy.argtypes = [vp]
         L.gs360_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.gs360_device_pci_bus_id.argtypes = [vp, C.c_char_p, sz]
         L.gs360_ctx_set_option.argtypes = [vp, C.c_char_p, i]
         L.gs360_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.gs360_dev_alloc.argtypes = [vp, sz, pvp]
@@ -276,6 +277,12 @@ class Context:
 
     def sync(self, slot=-1):
         _check(self.L.gs360_sync(self.handle, slot), self.L)
+
+    def pci_bus_id(self):
+        """'domain:bus:device.function' of this context's GPU"""
+        buf = C.create_string_buffer(64)
+        _check(self.L.gs360_device_pci_bus_id(self.handle, buf, 64), self.L)
+        return buf.value.decode()
 
     def set_option(self, key, value):
         """kernel-selection switch of this context (include/gs360.h: gs360_ctx_set_option); results never depend on it"""

@@ -29,6 +29,7 @@ _SLOTS_PER_DEVICE = 4
 _LINGER_S = float(os.environ.get("GS360_BATCH_LINGER_MS", "3")) * 1e-3
 _PREFETCH_FRAMES = int(os.environ.get("GS360_PREFETCH_FRAMES", "8"))      # still images decoded ahead of their view jobs (0 = off)
 _PREFETCH_THREADS = int(os.environ.get("GS360_PREFETCH_THREADS", "4"))    # decoder threads of the read-ahead
+_STALE_RUN_S = float(os.environ.get("GS360_STALE_RUN_S", "30"))            # an earlier run's untouched sources are dropped by the next announce() after this long
 _RECENT_SOURCES = 512                   # sources whose device is remembered after their record is gone (bounded)
 
 
@@ -47,7 +48,7 @@ class _Batch:
 
 class _Source:
     """What the engine remembers about one source while it is in flight."""
-    __slots__ = ("dev", "expected", "remaining", "active", "touched", "ahead")
+    __slots__ = ("dev", "expected", "remaining", "active", "touched", "ahead", "run", "stamp")
 
     def __init__(self, dev):
         self.dev = dev                  # index into Engine.states: all views of a source share a device
@@ -56,6 +57,8 @@ class _Source:
         self.active = 0                 # view jobs inside run_job right now
         self.touched = False            # a view job has asked for the frame (the read-ahead leaves it alone from then on)
         self.ahead = False              # decoded ahead and still holding a read-ahead permit
+        self.run = 0                    # the announce() that listed it last (0 = never announced)
+        self.stamp = time.monotonic()   # last time a job list or a job touched it
 
 
 class _DeviceState:
@@ -125,7 +128,8 @@ class Engine:
         self._inflight = [0] * len(self.states)   # sources currently held per device (device_for balances on THIS, not on history)
         self._recent = collections.OrderedDict()  # source -> device of its last record, the newest _RECENT_SOURCES of them
         self._last_dev = len(self.states) - 1     # round-robin tie-break starts at device 0
-        self._prefetch_queue = collections.deque()   # announced still-image sources not yet decoded ahead
+        self._prefetch_queue = collections.deque()   # (run, source): announced still-image sources not yet decoded ahead
+        self._run_id = 0                          # announce() counter
         self._prefetch_threads = []
         self._prefetch_permits = threading.Semaphore(_PREFETCH_FRAMES)
         self._prefetch_stop = threading.Event()
@@ -187,14 +191,27 @@ class Engine:
         with self._announce_lock:
             return self._source(str(src_path)).dev
 
-    def retire(self):
-        """End of a run (the drop-in CLI's main() calls it; announce() does the same for what an earlier run left behind): forget
-        every source no job is working on -- a cancelled or failed run leaves announced jobs that never arrive -- and empty the
-        read-ahead queue.  Permits of frames decoded ahead and never used go back."""
+    def retire(self, run=None):
+        """End of a run (the drop-in CLI's main() calls it): forget every source no job is working on -- a cancelled or failed run leaves
+        announced jobs that never arrive -- and empty the read-ahead queue; permits of frames decoded ahead and never used go back.
+        With `run` (the value announce() returned) only THAT run's sources and queue entries go: a long-lived host with overlapping
+        exports (the GUI) ends one run without touching the other's queued sources."""
         with self._announce_lock:
-            self._prefetch_queue.clear()
-            for key in [k for k, r in self._sources.items() if r.active == 0]:
+            if run is None:
+                self._prefetch_queue.clear()
+            else:
+                self._prefetch_queue = collections.deque(e for e in self._prefetch_queue if e[0] != run)
+            for key in [k for k, r in self._sources.items() if r.active == 0 and (run is None or r.run == run)]:
                 self._drop(key)
+
+    def _retire_stale(self, current_run):
+        """(announce lock held) what an earlier run left behind and nobody came back for: records of OTHER runs with no job inside and no
+        activity for _STALE_RUN_S seconds.  A run that is still working keeps its queued sources, their `expected` counts and their
+        read-ahead (round-4 ADVICE: a second announce() used to discard them)."""
+        now = time.monotonic()
+        for key in [k for k, r in self._sources.items() if r.active == 0 and r.run != current_run and now - r.stamp > _STALE_RUN_S]:
+            self._drop(key)
+        self._prefetch_queue = collections.deque(e for e in self._prefetch_queue if e[1] in self._sources)
 
     def bookkeeping(self):
         """sizes of the per-source tables (tests: a long-lived engine must come back to empty)"""
@@ -374,17 +391,21 @@ class Engine:
         """Optional hint from a caller that knows its whole job list (the drop-in CLI's main()): how many view jobs each
         source has, and how many of them can be in flight at once.  Lets a batch leader stop lingering as soon as every
         view that can arrive has arrived.  Without it every batch simply lingers for the full window."""
-        self.retire()                             # leftovers of an earlier (cancelled) run
         counts = collections.Counter(str(j.src) for j in jobs)
         with self._announce_lock:
+            self._run_id += 1
+            run = self._run_id
+            self._retire_stale(run)               # leftovers of earlier runs that were cancelled (nothing has touched them for a while)
             for k, n in counts.items():           # deal the sources to the devices in job-list order (Counter keeps it)
                 rec = self._source(k)
                 rec.expected = min(n, workers) if workers else n
                 rec.remaining = (rec.remaining or 0) + n
-        self._start_prefetch([j.src for j in jobs if j.is_still_image])
+                rec.run, rec.stamp = run, time.monotonic()
+        self._start_prefetch([j.src for j in jobs if j.is_still_image], run)
+        return run
 
     # -- decode-ahead -----------------------------------------------------------------------------
-    def _start_prefetch(self, sources):
+    def _start_prefetch(self, sources, run=0):
         """With the whole job list known, decode + upload the next still images in the background while the view jobs of the
         current ones render and encode.  Without it a frame's decode (70 ms for a 5.7K PNG) sits on the critical path of its 8
         view jobs: the first job decodes, the others wait, and with `-j 16` only two frames are ever in flight.  At most
@@ -397,7 +418,7 @@ class Engine:
         if len(order) < 2 or _PREFETCH_FRAMES <= 0:
             return
         with self._announce_lock:
-            self._prefetch_queue.extend(order)
+            self._prefetch_queue.extend((run, k) for k in order)
             need = min(_PREFETCH_THREADS, len(order)) - len(self._prefetch_threads)
             for _ in range(max(0, need)):
                 t = threading.Thread(target=self._prefetch_loop, name="gs360-decode-ahead", daemon=True)
@@ -414,17 +435,18 @@ class Engine:
             src = None
             with self._announce_lock:
                 while self._prefetch_queue:
-                    cand = self._prefetch_queue.popleft()
+                    _run, cand = self._prefetch_queue.popleft()
                     rec = self._sources.get(cand)
                     if rec is not None and not rec.touched:   # else its view jobs are already running (they decode it themselves)
                         src = cand
                         rec.ahead = True
+                        dev = rec.dev                         # resolved HERE: a record dropped after the lock is released must not be re-created by a lookup
                         break
             if src is None:
                 self._prefetch_permits.release()
                 break
             try:
-                st = self.states[self.device_for(src)]
+                st = self.states[dev]
                 self.release_frame(st, self.resident_frame(st, src))
             except Exception:  # noqa: BLE001  (the view job reports the real error when it gets there)
                 self._job_touches(src, entering=False)
@@ -436,6 +458,7 @@ class Engine:
         with self._announce_lock:
             rec = self._source(str(src))
             rec.touched = True
+            rec.stamp = time.monotonic()
             if entering:
                 rec.active += 1
             if rec.ahead:

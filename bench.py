@@ -61,8 +61,12 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB
 # line its taps touch at least once -- 718,080 lines per frame summed over the six views (119,680 each; counted from the
 # oracle's map, tests/test_oracle_equirect.py) -- plus the stores, at the 6.29 TB/s the HBM sustains for streaming copies.
 LINE_BYTES_PER_FRAME = 718_080 * 128 + 11_520_000
+# ... and the bound of the source-major kernel (round 5), which pulls each distinct line ONCE for all six views: the union of the views'
+# line sets is 413,172 lines per frame (tests/test_oracle_equirect.py), + the stores
+UNION_LINE_BYTES_PER_FRAME = 413_172 * 128 + 11_520_000
 HBM_STREAM_GBS = 6290.0
-MULTI_RANK_LAUNCHES_PER_STEP = 16  # N > 1: launches of `--frames` frames per step (N = 1: one) -- see the job comment in main()
+LAUNCHES_PER_STEP = 16             # a step = 16 launches of `--frames` frames at EVERY N (round-4 verdict: same step semantics at N = 1 and N > 1)
+EQ_KERNEL_NAMES = {0: "eq_views_kernel<3>", 1: "eq_staged_kernel", 2: "eq_srcmajor_kernel"}
 
 
 def norm_yaw(a):
@@ -218,6 +222,7 @@ def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
                                    f"full360coverage 12x{size}x{size}, pinned host -> H2D -> one 12-view launch -> D2H per frame "
                                    "(BASELINE.json configs[2]; PC:1049-1078)",
                        "frames_total": args.stream_frames, "frames_rank0": len(mine), "views": len(views), "device": info["name"],
+                       "rank_devices": info["rank_devices"], "world_seen": info["world_seen"],
                        "parallelism": f"frames sharded x{world}, no collective", "parity_vs_oracle": parity,
                        "frames_per_s": round(args.stream_frames / elapsed, 1), "rank0_seconds": round(local, 4),
                        "pcie_bytes_per_frame": {"h2d": in_b, "d2h": out_b},
@@ -298,6 +303,7 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
                                    f"{world} rank(s) -> full360coverage 12x{size}x{size}, {batch} frames per launch, kernel-only "
                                    "(BASELINE.json configs[2])",
                        "frames_total": args.job_frames, "frames_rank0": len(mine), "views": len(views), "device": info["name"],
+                       "rank_devices": info["rank_devices"], "world_seen": info["world_seen"],
                        "resident_GB_rank0": round(len(mine) * W * H * C / 1e9, 1), "upload_s_rank0": round(t_up, 1),
                        "parallelism": f"frames sharded x{world}, no collective", "parity_vs_oracle": parity,
                        "frames_per_s": round(args.job_frames / elapsed, 1), "per_rank_seconds": per_rank,
@@ -394,6 +400,21 @@ def main():
 
     ctx = gs360.Context(device=local_rank if use_dist else 0, n_slots=3 if args.mode == "stream" else 2)
     info = ctx.info()
+    # which GPU each rank really sits on: every rank's PCI bus id is gathered into config.rank_devices (+ the world size the process
+    # group reports), and a job whose RCCL ranks share a device is refused (exit 3) -- N ranks over RCCL must mean N distinct GPUs.
+    # (gloo ranks may share devices: the control-flow tests on a 1-GPU box; the duplicates are reported, not refused)
+    info["rank_devices"] = [ctx.pci_bus_id()]
+    info["world_seen"] = 1
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, info["rank_devices"][0])
+        info["rank_devices"] = [str(g) for g in gathered]
+        info["world_seen"] = int(dist.get_world_size())
+        if args.backend == "nccl" and len(set(info["rank_devices"])) != world:
+            if rank == 0:
+                print(f"bench.py: {world} RCCL ranks on {len(set(info['rank_devices']))} distinct device(s) {info['rank_devices']}: "
+                      "one rank per GPU is the contract", file=sys.stderr)
+            sys.exit(3)
 
     def barrier():
         ctx.sync(-1)
@@ -430,11 +451,10 @@ def main():
         d_frames = [ctx.to_device(f) for f in frames_host]
     d_out = [ctx.alloc(SIZE * SIZE * C) for _ in range(nf * N_VIEWS)]
     step = ctx.make_equirect_call(d_frames, W, H, C, views, d_out, slot=0, src_stride=stride if args.stride_pad else 0)
-    # the fixed job: `--steps` steps of LAUNCHES_PER_STEP launches of nf frames, the launches dealt round-robin to the ranks.  One
-    # rank: a step is one launch (the headline run, unchanged).  N > 1 ranks: a step is MULTI_RANK_LAUNCHES_PER_STEP launches, so
-    # that at the driver's --steps 20 a rank still has >= 12 ms of timed work at N = 8 (one launch is 0.3 ms: with one launch per
-    # step a rank's share was 2.5 launches = 0.8 ms and launch jitter decided the curve); `value` is a rate, comparable across N
-    launches_per_step = 1 if world == 1 else MULTI_RANK_LAUNCHES_PER_STEP
+    # the fixed job: `--steps` steps of LAUNCHES_PER_STEP launches of nf frames, the launches dealt round-robin to the ranks -- the same
+    # step at every N (one launch is 0.25 ms: at the driver's --steps 20 the timed region is 78 ms on one rank, 10 ms per rank at
+    # N = 8); `value` is a rate, comparable across N
+    launches_per_step = LAUNCHES_PER_STEP
     n_launches = len(frames_for_rank(args.steps * launches_per_step, world, rank))
     n_mine = n_launches * nf
     # settle: the same launches, untimed, until the device has been busy for --settle-ms (clocks ramp over the first ~100 ms of
@@ -458,6 +478,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms_total = ctx.event_elapsed_ms(0, 0, 1)                  # HIP events on the launch stream
+    eq_kernel = ctx.get_option("last_eq_kernel")                     # which equirect kernel the timed launches ran (0 gather, 1 LDS-staged, 2 source-major)
     kernel_ms = kernel_ms_total * nf / max(1, n_mine)                # per full launch of nf frames
     per_rank = [round(local, 6)]
     elapsed, with_barrier = job_seconds(local, elapsed, args, dist if use_dist else None, torch)
@@ -510,12 +531,13 @@ def main():
         baseline_shape = (W == 7680 and args.stride_pad == 0)   # ALGO_BYTES_PER_FRAME was counted for the 7680-wide source only
         algo_bytes = ALGO_BYTES_PER_FRAME * nf
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line_bytes = UNION_LINE_BYTES_PER_FRAME if eq_kernel == 2 else LINE_BYTES_PER_FRAME
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"        # written from rocprofv3 --pmc passes (see profiles/README.md)
         if tf.exists() and baseline_shape:
             try:
                 rec = json.loads(tf.read_text())
-                if rec.get("frames_per_launch") == nf:
+                if rec.get("frames_per_launch") == nf and rec.get("kernel", "").startswith(EQ_KERNEL_NAMES.get(eq_kernel, "?").split("<")[0]):
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -528,7 +550,8 @@ def main():
                                    "7680x3840x3 u8 equirect -> --preset default --count 6 --size 800 (6x800x800), "
                                    "bilinear 1/32-px fixed point (BASELINE.json configs[1])",
                        "frames_per_step": nf, "views": N_VIEWS, "out_px_per_step": px_per_step,
-                       "device": info["name"], "parallelism": f"frames sharded x{world}, no collective",
+                       "device": info["name"], "rank_devices": info["rank_devices"], "world_seen": info["world_seen"],
+                       "parallelism": f"frames sharded x{world}, no collective",
                        "launches_per_step": launches_per_step,
                        "job": f"{args.steps} steps x {launches_per_step} launch(es) x {nf} frames = {args.steps * launches_per_step * nf} frame renders, "
                               f"launches dealt round-robin to {world} rank(s)",
@@ -539,13 +562,14 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          # same launch time against the bytes the PMC counters saw move (whole 128-B lines), for context
                          "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
-                         "kernel": "eq_views_kernel<3>", "kernel_ms": round(kernel_ms, 5),
+                         "kernel": EQ_KERNEL_NAMES.get(eq_kernel, str(eq_kernel)), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          # the reachable bound next to the algorithmic one: distinct 128-B lines per view + stores at the
                          # measured streaming rate; frac = launch time at that bound / measured launch time
-                         "line_bound": {"bytes_per_launch": LINE_BYTES_PER_FRAME * nf, "peak": HBM_STREAM_GBS, "unit": "GB/s",
-                                        "achieved": round(LINE_BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9, 1),
-                                        "frac": round(LINE_BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9 / HBM_STREAM_GBS, 4)}},
+                         "line_bound": {"bytes_per_launch": line_bytes * nf, "peak": HBM_STREAM_GBS, "unit": "GB/s",
+                                        "what": ("union of the six views' lines, each once" if eq_kernel == 2 else "distinct lines per view, summed") + " + stores",
+                                        "achieved": round(line_bytes * nf / (kernel_ms * 1e-3) / 1e9, 1),
+                                        "frac": round(line_bytes * nf / (kernel_ms * 1e-3) / 1e9 / HBM_STREAM_GBS, 4)}},
             "cpu_baseline": cpu,
         }
         if secondary is not None:

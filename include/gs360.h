@@ -88,6 +88,9 @@ int gs360_last_error(char *buf, size_t buf_len);
 int gs360_ctx_create(int device, int n_slots, gs360_ctx **out);
 int gs360_ctx_destroy(gs360_ctx *ctx);
 int gs360_device_info(gs360_ctx *ctx, char *name, size_t name_len, int32_t *cu_count, uint64_t *hbm_bytes);
+/* "domain:bus:device.function" of the context's GPU (>= 16 bytes): lets a multi-process job prove that its ranks sit on DISTINCT
+ * devices (bench.py gathers it from every rank; the reference fans jobs out over one machine's workers, PC:830-836) */
+int gs360_device_pci_bus_id(gs360_ctx *ctx, char *buf, size_t buf_len);
 /* Context options: kernel-selection switches for tests, probes and A/B runs (the defaults are the measured optima; results never depend
  * on them).  The reference has no counterpart (it shells out to ffmpeg / calls cv2.remap: PC:310-314, DF:2001); a binding needs them
  * only to pin a kernel variant.  gs360_ctx_create seeds the documented user switches ONCE from the environment (GS360_STAGE,
@@ -101,6 +104,7 @@ int gs360_device_info(gs360_ctx *ctx, char *name, size_t name_len, int32_t *cu_c
  *   "eq_persist", "table_persist"                       grid caps of the persistent kernels (table_persist: -1 auto)
  *   "lanczos_table", "table_rows"                       0 | 1: A/B references of the Lanczos-4 weight rebuild and the flat spans
  *   "color_cube"     -1 / 1 tabulate | 0 per pixel      8-bit colour stage (read by gs360_color_plan_create)
+ * Read-only (get): "last_eq_kernel" -- which kernel the last equirect call launched: 0 gather, 1 LDS-staged, 2 source-major, -1 none yet.
  * Unknown keys and out-of-range values are GS360_ERR_ARG.  Thread-safe; a change applies to calls that start after it. */
 int gs360_ctx_set_option(gs360_ctx *ctx, const char *key, int value);
 int gs360_ctx_get_option(gs360_ctx *ctx, const char *key, int *value);

@@ -33,13 +33,20 @@ def test_bench_self_launch_two_ranks_share_device0():
     assert d["cpu_baseline"] is None                   # the timed CPU sample is an N=1 item
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel_ms"] > 0
     assert 0 < d["roofline"]["line_bound"]["frac"] < 1.5
+    # the line proves which devices took part: one PCI bus id per rank (gloo ranks share device 0 here: duplicates reported, not refused)
+    assert d["config"]["world_seen"] == 2 and len(d["config"]["rank_devices"]) == 2
+    assert d["config"]["rank_devices"][0] == d["config"]["rank_devices"][1] and ":" in d["config"]["rank_devices"][0]
 
 
 def test_bench_single_rank_line_matches_the_contract():
     d = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["frames_per_step"] == 16 and d["config"]["frames_rank0"] == 48
+    # a step is 16 launches of 16 frames at every N (round-4 verdict): 3 steps = 48 launches = 768 frame renders
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["frames_per_step"] == 16 and d["config"]["frames_rank0"] == 768
+    assert d["config"]["launches_per_step"] == 16 and d["config"]["world_seen"] == 1 and len(d["config"]["rank_devices"]) == 1
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 16 * 54495972
-    assert d["roofline"]["line_bound"]["bytes_per_launch"] == 16 * (718080 * 128 + 11520000)
+    # the headline shape takes the source-major kernel: its line bound is the UNION of the six views' lines, each once
+    assert d["roofline"]["kernel"] == "eq_srcmajor_kernel"
+    assert d["roofline"]["line_bound"]["bytes_per_launch"] == 16 * (413172 * 128 + 11520000)
 
 
 def test_bench_rccl_world_of_one_prints_exactly_one_json_line():
@@ -55,7 +62,7 @@ def test_bench_rccl_world_of_one_prints_exactly_one_json_line():
     assert len(out_lines) == 1, p.stdout[-2000:]
     d = json.loads(out_lines[0])
     assert set(d) == set(plain) and set(d["config"]) == set(plain["config"]) and set(d["roofline"]) == set(plain["roofline"])
-    assert d["n_gpus"] == 1 and d["config"]["frames_rank0"] == 48 and d["config"]["launches_per_step"] == 1
+    assert d["n_gpus"] == 1 and d["config"]["frames_rank0"] == 768 and d["config"]["launches_per_step"] == 16
     assert len(d["config"]["per_rank_seconds"]) == 1 and d["value"] > 0
 
 

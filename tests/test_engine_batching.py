@@ -220,8 +220,7 @@ def test_decode_ahead_runs_at_most_its_permits_ahead_and_hands_them_back(monkeyp
 
 
 def test_a_cancelled_run_hands_its_read_ahead_permits_back(monkeypatch):
-    """frames decoded ahead whose view jobs never arrive (cancel, an earlier failure): retire() -- the CLI's main() calls it, and so does
-    the next announce() -- returns their permits and empties the tables (round-3 ADVICE, engine.py:349)"""
+    """frames decoded ahead whose view jobs never arrive (cancel, an earlier failure): retire() -- the CLI's main() calls it -- returns their permits and empties the tables (round-3 ADVICE, engine.py:349)"""
     eng = bare_engine(2)
     monkeypatch.setattr(engine, "_PREFETCH_FRAMES", 2)
     monkeypatch.setattr(engine, "_PREFETCH_THREADS", 2)
@@ -237,6 +236,33 @@ def test_a_cancelled_run_hands_its_read_ahead_permits_back(monkeypatch):
     wait_until(lambda: not eng._prefetch_threads)             # the read-ahead threads see the empty queue and leave
     assert eng.bookkeeping() == {"sources": 0, "inflight": [0, 0], "queue": 0}
     assert permits.acquire(timeout=1) and permits.acquire(timeout=1)      # both permits are back
+
+
+def test_overlapping_runs_keep_each_others_queued_sources(monkeypatch):
+    """round-4 ADVICE (engine.py:377): a second announce() while the first run is still working must not discard the first run's queued
+    sources (their `expected` / `remaining` counts, their place in the read-ahead queue); retire(run) ends ONE run; what a cancelled run
+    left behind goes at the next announce() once it has been idle for _STALE_RUN_S."""
+    eng = bare_engine(2)
+    monkeypatch.setattr(engine, "_PREFETCH_FRAMES", 0)        # (no read-ahead threads: this test is about the bookkeeping)
+    mk = lambda paths: [type("J", (), {"src": s, "is_still_image": True})() for s in paths for _v in range(3)]   # noqa: E731
+    a = [f"/a/{k}.png" for k in range(4)]
+    b = [f"/b/{k}.png" for k in range(3)]
+    run_a = eng.announce(mk(a), workers=2)
+    run_b = eng.announce(mk(b), workers=2)                    # overlapping export
+    assert run_b == run_a + 1
+    with eng._announce_lock:
+        assert all(eng._sources[s].remaining == 3 and eng._sources[s].expected == 2 and eng._sources[s].run == run_a for s in a)
+        assert all(eng._sources[s].run == run_b for s in b)
+    eng.retire(run_b)                                         # the second export ends (or is cancelled): the first keeps everything
+    assert eng.bookkeeping()["sources"] == 4
+    with eng._announce_lock:
+        assert sorted(eng._sources) == a
+    monkeypatch.setattr(engine, "_STALE_RUN_S", 0.0)          # ... and a run nobody came back for goes at the next announce
+    run_c = eng.announce(mk(["/c/0.png"]), workers=1)
+    with eng._announce_lock:
+        assert sorted(eng._sources) == ["/c/0.png"] and eng._sources["/c/0.png"].run == run_c
+    eng.retire()
+    assert eng.bookkeeping() == {"sources": 0, "inflight": [0, 0], "queue": 0}
 
 
 def test_three_runs_leave_the_engine_empty_and_level(monkeypatch, tmp_path):

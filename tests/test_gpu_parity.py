@@ -33,8 +33,9 @@ def lanemap(request, ctx):
     option "lanemap" forces one so that every shape below is checked under both.  "staged" = the LDS-staged kernel forced on (option
     "stage" = 1; 16 x 16 wavefront tiles, boxes copied into LDS, gather form where a box does not qualify); "srcmajor" = the source-major
     kernel forced onto every call whose geometry fits it (level yaw rings that fill their circle), everything else as in "auto"."""
-    want = {"rows": dict(lanemap=0), "blocked": dict(lanemap=1), "auto": {}, "staged": dict(lanemap=0, stage=1), "srcmajor": dict(srcmajor=1)}[request.param]
-    base = dict(lanemap=-1, stage=-1, srcmajor=-1)
+    want = {"rows": dict(lanemap=0), "blocked": dict(lanemap=1), "auto": dict(srcmajor=-1), "staged": dict(lanemap=0, stage=1),
+            "srcmajor": dict(srcmajor=1)}[request.param]
+    base = dict(lanemap=-1, stage=-1, srcmajor=0)      # the named gather / staged variants are not pre-empted by the source-major kernel
     base.update(want)
     with ctx.options(**base):
         yield request.param
@@ -44,6 +45,8 @@ def test_equirect_cfg2_ring_small_source(ctx, orc, lanemap):
     src = rand_image(480, 960)
     got, want = _eq_both(ctx, orc, src, ring_views(6, 200, HFOV_12MM))
     _assert_same(got, want, "cfg2-shaped ring on 960x480")
+    # which kernel ran: the source-major one when forced (left to itself the library takes it from 3 texels per pixel; here 2.3)
+    assert ctx.get_option("last_eq_kernel") == {"srcmajor": 2, "staged": 1}.get(lanemap, 0)
 
 
 @pytest.mark.parametrize("name,layout,hfov", [("full360coverage", PRESET_FULL360, HFOV_14MM),
@@ -324,10 +327,10 @@ def test_bicubic_persistent_workgroups_walk_every_tile(ctx, orc, persist):
     """The bicubic RGB kernels (table + fused fisheye) cap their grid and let each workgroup walk tiles b, b + gridDim.x, ...;
     the option "table_persist" forces the cap (0 = one tile per workgroup, 8 / 24 = 13-40 tiles per workgroup here)."""
     with ctx.options(table_persist=int(persist)):
-        _bicubic_persistent(ctx, orc)
+        _bicubic_persistent(ctx, orc, persist)
 
 
-def _bicubic_persistent(ctx, orc):
+def _bicubic_persistent(ctx, orc, persist):
     H, W, h, w = 211, 300, 150, 333                      # 6 x 10 tiles per job
     src = rand_image(H, W, c=3, seed=71)
     d_src = ctx.to_device(src)

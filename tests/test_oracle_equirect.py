@@ -157,7 +157,7 @@ def test_line_bound_constant_of_bench(orc):
     128-B aligned, tight rows), summed over the six views, x 128 B + the stores."""
     import bench
     W, H = 7680, 3840
-    per_view = []
+    per_view, every = [], []
     for spec in ring_views(6, 800, HFOV_12MM):
         sx, sy = orc.equirect_map(orc.make_view(*spec), W, H)
         ix, iy = (sx >> 5).astype(np.int64), (sy >> 5).astype(np.int64)
@@ -168,8 +168,13 @@ def test_line_bound_constant_of_bench(orc):
                 first = (yy * W + xx) * 3
                 lines += [(first >> 7).ravel(), ((first + 2) >> 7).ravel()]
         per_view.append(int(np.unique(np.concatenate(lines)).size))
+        every.append(np.unique(np.concatenate(lines)))
+    union = int(np.unique(np.concatenate(every)).size)
+    assert union == 413_172
     assert per_view == [119_680] * 6
     assert bench.LINE_BYTES_PER_FRAME == sum(per_view) * 128 + 6 * 800 * 800 * 3 == 103_434_240
+    # the source-major kernel's bound: every distinct line ONCE for all six views
+    assert bench.UNION_LINE_BYTES_PER_FRAME == union * 128 + 6 * 800 * 800 * 3 == 64_406_016
 
 
 # ---- equidistant-fisheye OUTPUT (the fisheyeXY preset's v360 output=fisheye jobs, PC:351-414) ---------------------

@@ -1,0 +1,129 @@
+"""-m gpu: the source-major equirect kernel (gs360_srcmajor.hip) through the C ABI against the CPU oracle, every byte.
+
+It takes calls that are ONE level yaw ring filling its circle (`--count N`, gs360_360PerspCut.py:794; one ffmpeg v360 process per
+(frame, view) in the reference, PC:310-314).  Forced on with the context option "srcmajor" = 1 so that weakly minified rings run through
+it too; `last_eq_kernel` proves which kernel a call launched."""
+import numpy as np
+import pytest
+
+import gs360
+from util import HFOV_12MM, rand_image, ring_views
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, orc, src, specs, what, expect_kernel=2, **kw):
+    got = ctx.equirect_views(src, [gs360.View.make(*s) for s in specs], **kw)
+    assert ctx.get_option("last_eq_kernel") == expect_kernel, f"{what}: kernel {ctx.get_option('last_eq_kernel')}"
+    want = orc.equirect_views_u8(src, [orc.make_view(*s) for s in specs], threads=0)
+    for k, (g, w) in enumerate(zip(got, want)):
+        if not np.array_equal(g, w):
+            bad = np.argwhere(g != w)
+            raise AssertionError(f"{what}: view {k}: {len(bad)} mismatching bytes of {g.size}, first at {bad[0].tolist()}")
+
+
+@pytest.fixture
+def forced(ctx):
+    with ctx.options(srcmajor=1, srcmajor_bx=768, srcmajor_rows=32):
+        yield ctx
+
+
+@pytest.mark.parametrize("count", [2, 3, 4, 5, 6, 8, 12, 16])
+def test_ring_counts(forced, orc, count):
+    W = 240 * 16                      # divisible by every count above, 3 W / count a multiple of 16
+    src = rand_image(W // 2, W, seed=200 + count)
+    _check(forced, orc, src, ring_views(count, 120, 100.0), f"ring of {count}")
+
+
+@pytest.mark.parametrize("w,h", [(8, 2), (12, 7), (200, 201), (64, 333), (400, 96)])
+def test_view_sizes_incl_odd_heights(forced, orc, w, h):
+    src = rand_image(480, 960, seed=210)
+    _check(forced, orc, src, [(i * 60.0, 0.0, 95.0, 70.0, w, h) for i in range(6)], f"{w}x{h} views")
+
+
+@pytest.mark.parametrize("off", [0.0, 7.3, -123.456, 360.0 / 960 * 17, 179.99])
+def test_yaw_offsets_and_seam(forced, orc, off):
+    """rings rotated by arbitrary (sub-texel) angles: boxes that run across the 360-degree seam, quads that straddle period borders"""
+    src = rand_image(480, 960, seed=211)
+    _check(forced, orc, src, [(off + i * 90.0, 0.0, 112.0, 112.0, 160, 120) for i in range(4)], f"offset {off}")
+
+
+def test_shuffled_view_order_and_frames(forced, orc):
+    rng = np.random.default_rng(5)
+    W, H, N = 1920, 960, 6
+    specs = [ring_views(N, 200, HFOV_12MM)[k] for k in rng.permutation(N)]
+    frames = [rand_image(H, W, seed=220 + f) for f in range(3)]
+    d_src = [forced.to_device(f) for f in frames]
+    dstride = 200 * 3 + 8
+    d_out = [forced.alloc(dstride * 200 + 64) for _ in range(3 * N)]
+    for b in d_out:
+        forced.memset(b, 0xCD)
+    forced.equirect_views_dev(d_src, W, H, 3, [gs360.View.make(*s) for s in specs], d_out, dst_stride=dstride)
+    forced.sync(0)
+    assert forced.get_option("last_eq_kernel") == 2
+    for f in range(3):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        for k in range(N):
+            raw = forced.download(d_out[f * N + k], (200, dstride))
+            assert np.array_equal(raw[:, :600].reshape(200, 200, 3), want[k]), (f, k)
+            assert np.all(raw[:, 600:] == 0xCD), "row padding written"
+    for b in d_src + d_out:
+        forced.free(b)
+
+
+@pytest.mark.parametrize("bx,rows", [(256, 8), (512, 16), (768, 48), (1024, 24), (2048, 8)])
+def test_tile_shapes(ctx, orc, bx, rows):
+    src = rand_image(960, 1920, seed=230)
+    with ctx.options(srcmajor=1, srcmajor_bx=bx, srcmajor_rows=rows):
+        _check(ctx, orc, src, ring_views(6, 240, HFOV_12MM), f"tile {bx} x {rows}")
+
+
+def test_plan_cache_eviction_and_reuse(forced, orc):
+    """more geometries than the context keeps plans for, then the first ones again"""
+    src = rand_image(480, 960, seed=240)
+    geoms = [[(i * 60.0 + o, 0.0, 100.0 + o, 100.0, 96 + 4 * o, 64) for i in range(6)] for o in range(6)]
+    for rnd in range(2):
+        for g in geoms:
+            _check(forced, orc, src, g, f"geometry round {rnd}")
+
+
+def test_shapes_it_must_leave_to_the_gather_kernels(forced, orc):
+    src = rand_image(480, 960, seed=250)
+    # width not a multiple of four; a pitched ring; a ring that does not fill its circle; one ring + a stray view
+    _check(forced, orc, src, [(i * 60.0, 0.0, 100.0, 100.0, 98, 64) for i in range(6)], "width 98", expect_kernel=0)
+    _check(forced, orc, src, [(i * 60.0, 30.0, 100.0, 100.0, 96, 64) for i in range(6)], "pitched ring", expect_kernel=0)
+    _check(forced, orc, src, [(i * 60.0, 0.0, 100.0, 100.0, 96, 64) for i in range(5)], "5 of 6", expect_kernel=0)
+    _check(forced, orc, src, [(i * 60.0, 0.0, 100.0, 100.0, 96, 64) for i in range(6)] + [(10.0, 0.0, 100.0, 100.0, 96, 64)], "ring + stray",
+           expect_kernel=0)
+    # 7 does not divide 960
+    _check(forced, orc, src, [(i * 360.0 / 7, 0.0, 100.0, 100.0, 96, 64) for i in range(7)], "count 7", expect_kernel=0)
+
+
+def test_auto_selection(ctx, orc):
+    """left to itself the library takes it for strongly minified rings only (>= 3 source texels per output pixel)"""
+    src = rand_image(960, 1920, seed=260)
+    with ctx.options(srcmajor=-1):
+        _check(ctx, orc, src, ring_views(6, 200, HFOV_12MM), "step 4.6: source-major", expect_kernel=2)
+        _check(ctx, orc, src, ring_views(6, 400, HFOV_12MM), "step 2.3: gather", expect_kernel=0)
+    with ctx.options(srcmajor=0):
+        _check(ctx, orc, src, ring_views(6, 200, HFOV_12MM), "switched off", expect_kernel=0)
+
+
+def test_cfg2_full_size_sixteen_frames_every_byte(ctx, orc):
+    """BASELINE configs[1] as bench.py launches it: 16 distinct 8K frames x 6 x 800^2 in one call, every byte of all 96 views"""
+    W, H, N = 7680, 3840, 6
+    specs = ring_views(N, 800, HFOV_12MM)
+    frames = [rand_image(H, W, seed=300 + f) for f in range(16)]
+    d_src = [ctx.to_device(f) for f in frames]
+    d_out = [ctx.alloc(800 * 800 * 3) for _ in range(16 * N)]
+    with ctx.options(srcmajor=-1):
+        ctx.equirect_views_dev(d_src, W, H, 3, [gs360.View.make(*s) for s in specs], d_out)
+        ctx.sync(0)
+        assert ctx.get_option("last_eq_kernel") == 2
+    for f in range(16):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        for k in range(N):
+            got = ctx.download(d_out[f * N + k], (800, 800, 3))
+            assert np.array_equal(got, want[k]), f"frame {f} view {k}"
+    for b in d_src + d_out:
+        ctx.free(b)

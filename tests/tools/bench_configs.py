@@ -148,10 +148,14 @@ def fisheye_cfg(ctx, steps):
     want = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=1, threads=0), t["valid"], 0)
     uv = sum(orc.table_distinct_texels(tables[s["view_id"]]["map_x"], tables[s["view_id"]]["map_y"], 4000, 4000) for s in specs)
     px = 6 * 1750 * 1750
-    algo_table = px * (3 + 8 + 1) + uv * 3
-    res.append({"config": "cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, TABLE mode (reference-identical maps)", "ms_per_pair": round(ms, 4),
-                "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_table / 1e6, 1),
-                "achieved_GB_per_s": round(algo_table / ms / 1e6, 0), "frac_of_8TBps": round(algo_table / ms / 1e6 / 8000, 3),
+    # algorithmic = stores + distinct source texels; the maps (8 B per pixel + 1 B valid; 4 + 1 through a plan) are OVERHEAD
+    algo_px = px * 3 + uv * 3
+    algo_table = algo_px + px * (8 + 1)
+    res.append({"config": "cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, TABLE mode (reference-identical maps), same pair every step (Infinity-Cache-warm)",
+                "ms_per_pair": round(ms, 4),
+                "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_px / 1e6, 1), "overhead_MB_per_pair": round(px * 9 / 1e6, 1),
+                "achieved_GB_per_s": round(algo_px / ms / 1e6, 0), "frac_of_8TBps": round(algo_px / ms / 1e6 / 8000, 3),
+                "frac_incl_map_bytes": round(algo_table / ms / 1e6 / 8000, 3),
                 "parity_vs_oracle": bool(np.array_equal(got, want))})
     # the same launch through MAP PLANS: the float tables packed once (5 bytes per pixel instead of 9), as the drop-in CLI runs 8-bit pairs
     plans = {s["view_id"]: {nearest: None for nearest in (False, True)} for s in specs}
@@ -167,11 +171,12 @@ def fisheye_cfg(ctx, steps):
         ms = time_steps(ctx, plan_call, steps)
         got = ctx.download(d_out[v0], (1750, 1750, 3))
         want_i = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=interp, threads=0), t["valid"], 0)
-        algo_plan = px * (3 + 4 + 1) + uv * 3
-        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, TABLE mode through map plans, {label}", "ms_per_pair": round(ms, 4),
-                    "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_plan / 1e6, 1),
-                    "achieved_GB_per_s": round(algo_plan / ms / 1e6, 0), "frac_of_8TBps": round(algo_plan / ms / 1e6 / 8000, 3),
-                    "frac_on_float_map_bytes": round(algo_table / ms / 1e6 / 8000, 3),
+        algo_plan = algo_px + px * (4 + 1)
+        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, TABLE mode through map plans, {label}, same pair every step (Infinity-Cache-warm)",
+                    "ms_per_pair": round(ms, 4),
+                    "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_px / 1e6, 1), "overhead_MB_per_pair": round(px * 5 / 1e6, 1),
+                    "achieved_GB_per_s": round(algo_px / ms / 1e6, 0), "frac_of_8TBps": round(algo_px / ms / 1e6 / 8000, 3),
+                    "frac_incl_map_bytes": round(algo_plan / ms / 1e6 / 8000, 3),
                     "parity_vs_oracle": bool(np.array_equal(got, want_i))})
     # ... and with FOUR lens pairs taken in turn (384 MB of sources: each pair's images come from HBM, as in a run over many pairs;
     # the rows above render the same pair every step, Infinity-Cache-warm)
@@ -190,8 +195,10 @@ def fisheye_cfg(ctx, steps):
     got = ctx.download(d_out[v0], (1750, 1750, 3))
     want_r = orc.valid_fill(orc.remap_u8(np.ascontiguousarray(src_last), t["map_x"], t["map_y"], interp=1, threads=0), t["valid"], 0)
     res.append({"config": "cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, TABLE mode through map plans, linear, four pairs in turn (sources from HBM)",
-                "ms_per_pair": round(ms, 4), "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_plan / 1e6, 1),
-                "achieved_GB_per_s": round(algo_plan / ms / 1e6, 0), "frac_of_8TBps": round(algo_plan / ms / 1e6 / 8000, 3),
+                "ms_per_pair": round(ms, 4), "MPix_per_s": round(px / ms / 1e3, 0), "algorithmic_MB_per_pair": round(algo_px / 1e6, 1),
+                "overhead_MB_per_pair": round(px * 5 / 1e6, 1),
+                "achieved_GB_per_s": round(algo_px / ms / 1e6, 0), "frac_of_8TBps": round(algo_px / ms / 1e6 / 8000, 3),
+                "frac_incl_map_bytes": round(algo_plan / ms / 1e6 / 8000, 3),
                 "parity_vs_oracle": bool(np.array_equal(got, want_r))})
     for pd in more:
         for b in pd.values():
@@ -220,10 +227,11 @@ def fisheye_cfg(ctx, steps):
     for interp, label, ms16, map_bytes, got16 in timed16:
         t_last = tables[specs[-1]["view_id"]]
         want16 = orc.valid_fill(orc.remap_u16(imgs16[t_last["lens_key"]], t_last["map_x"], t_last["map_y"], interp=interp, threads=0), t_last["valid"], 0)
-        algo16 = px * (6 + map_bytes + 1) + uv * 6
-        res.append({"config": f"cfg4 shape on 16-bit lens images, TABLE mode, CV_16U {label}, one batched launch", "ms_per_pair": round(ms16, 4),
-                    "MPix_per_s": round(px / ms16 / 1e3, 0), "algorithmic_MB_per_pair": round(algo16 / 1e6, 1),
+        algo16 = px * 6 + uv * 6
+        res.append({"config": f"cfg4 shape on 16-bit lens images, TABLE mode, CV_16U {label}, one batched launch (Infinity-Cache-warm)", "ms_per_pair": round(ms16, 4),
+                    "MPix_per_s": round(px / ms16 / 1e3, 0), "algorithmic_MB_per_pair": round(algo16 / 1e6, 1), "overhead_MB_per_pair": round(px * (map_bytes + 1) / 1e6, 1),
                     "achieved_GB_per_s": round(algo16 / ms16 / 1e6, 0), "frac_of_8TBps": round(algo16 / ms16 / 1e6 / 8000, 3),
+                    "frac_incl_map_bytes": round((algo16 + px * (map_bytes + 1)) / ms16 / 1e6 / 8000, 3),
                     "parity_vs_oracle": bool(np.array_equal(got16, want16))})
     calib = gs360.Calib.make(c.width, c.height, c.f, c.cx, c.cy, c.k1, c.k2, c.k3)
     views = [gs360.View.make(tables[s["view_id"]]["yaw_rel_deg"], s["pitch_deg"], s["hfov_deg"], s["vfov_deg"], 1750, 1750) for s in specs]
@@ -305,43 +313,61 @@ def color_cfg(ctx, steps):
     return res
 
 
-def cfg4_rows(ctx, steps, interps=((1, "linear"), (2, "cubic"))):
-    """cfg4 (2 x 4000^2 fisheye -> 6 x 1750^2, table mode, one batched launch per pair) for the given cv2 interpolations."""
+def cfg4_rows(ctx, steps, interps=((1, "linear"), (2, "cubic")), rotate=4):
+    """cfg4 (2 x 4000^2 fisheye -> 6 x 1750^2, table mode, one batched launch per pair) for the given cv2 interpolations, HBM-COLD: `rotate`
+    distinct lens pairs, each with its own copy of the tables / map plans, are rendered in turn (4 x 96 MB of images + 4 x 165 MB of float
+    tables = 1 GB against the 256 MiB Infinity Cache), as the headline rotates 16 frames.  Bytes per SURVEY section 8(d): ALGORITHMIC =
+    stores + distinct source texels; the maps' own traffic (8 B per pixel as float tables, 4 B through a plan, + 1 B valid) is reported
+    beside it as OVERHEAD ("table mode's 8 B/px map reads are overhead, not algorithmic"); `frac` is on the algorithmic bytes."""
     cal_kw = dict(TEMPLATE_CALIB, width=4000, height=4000)
     c = fe.SensorCalibration("0", "equisolid_fisheye", 4000, 4000, cal_kw["f"], cal_kw["cx"], cal_kw["cy"], cal_kw["k1"], cal_kw["k2"], cal_kw["k3"])
     specs = fe.sfm10_specs(1750, 14.0, "36 36", 40.0, 40.0)[:6]
     tables = fe.choose_lens_tables({"0": c}, "0", "0", specs, 0.0, 180.0, 190.0)
     imgs = {"X": synth(4000, 4000, 1), "Y": synth(4000, 4000, 2)}
-    dev = {k: ctx.to_device(v) for k, v in imgs.items()}
-    d_tab = {v: (ctx.to_device(t["map_x"]), ctx.to_device(t["map_y"]), ctx.to_device(np.ascontiguousarray(t["valid"], np.uint8)))
-             for v, t in tables.items()}
+    pairs_host = [imgs] + [{k: np.ascontiguousarray(np.roll(v, 211 * r, axis=1)) for k, v in imgs.items()} for r in range(1, rotate)]
+    devs = [{k: ctx.to_device(v) for k, v in ph.items()} for ph in pairs_host]
+    d_tabs = [{v: (ctx.to_device(t["map_x"]), ctx.to_device(t["map_y"]), ctx.to_device(np.ascontiguousarray(t["valid"], np.uint8)))
+               for v, t in tables.items()} for _ in range(rotate)]
     d_out = {v: ctx.alloc(1750 * 1750 * 3) for v in tables}
-    jobs = [(dev[tables[s["view_id"]]["lens_key"]], 4000, 4000) + tuple(d_tab[s["view_id"]]) + (1750, 1750, 0, d_out[s["view_id"]])
-            for s in specs]
     uv = sum(orc.table_distinct_texels(tables[s["view_id"]]["map_x"], tables[s["view_id"]]["map_y"], 4000, 4000) for s in specs)
     px = 6 * 1750 * 1750
-    algo = px * (3 + 8 + 1) + uv * 3
+    algo = px * 3 + uv * 3                                    # SURVEY 8(d): stores + distinct texels
+    over_float, over_plan = px * (8 + 1), px * (4 + 1)        # the maps (+ valid): overhead of table mode
     v0 = specs[1]["view_id"]
     t = tables[v0]
-    # the tables as map plans (packed once, 5 bytes per pixel instead of 9: how the drop-in CLI applies them to every pair of a run)
-    plans = {s["view_id"]: ctx.map_plan(*d_tab[s["view_id"]], 1750, 1750, nearest=False) for s in specs}
-    pjobs = [(dev[tables[s["view_id"]]["lens_key"]], 4000, 4000, plans[s["view_id"]], True, 1750, 1750, 0, d_out[s["view_id"]]) for s in specs]
-    algo_plan = px * (3 + 4 + 1) + uv * 3
+    plans = [{s["view_id"]: ctx.map_plan(*d_tabs[r][s["view_id"]], 1750, 1750, nearest=False) for s in specs} for r in range(rotate)]
+    jobs = [[(devs[r][tables[s["view_id"]]["lens_key"]], 4000, 4000) + tuple(d_tabs[r][s["view_id"]]) + (1750, 1750, 0, d_out[s["view_id"]])
+             for s in specs] for r in range(rotate)]
+    pjobs = [[(devs[r][tables[s["view_id"]]["lens_key"]], 4000, 4000, plans[r][s["view_id"]], True, 1750, 1750, 0, d_out[s["view_id"]])
+              for s in specs] for r in range(rotate)]
     timed = []
     for interp, label in interps:           # time everything first: the oracle's OpenMP team spins on the host afterwards
-        ms = time_steps(ctx, lambda: ctx.remap_tables_dev(jobs, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0), steps)
-        timed.append((interp, label, ms, algo, ctx.download(d_out[v0], (1750, 1750, 3))))
-        ms = time_steps(ctx, lambda: ctx.remap_plans_dev(pjobs, 3, interp=interp, border_value=(0, 0, 0, 0), slot=0), steps)
-        timed.append((interp, label + ", map plans", ms, algo_plan, ctx.download(d_out[v0], (1750, 1750, 3))))
+        for planned in (False, True):
+            turn = [0]
+
+            def call():
+                r = turn[0] % rotate
+                turn[0] += 1
+                if planned:
+                    ctx.remap_plans_dev(pjobs[r], 3, interp=interp, border_value=(0, 0, 0, 0), slot=0)
+                else:
+                    ctx.remap_tables_dev(jobs[r], 3, interp=interp, border_value=(0, 0, 0, 0), slot=0)
+            ms = time_steps(ctx, call, steps)
+            last = (turn[0] - 1) % rotate
+            timed.append((interp, label + (", map plans" if planned else ""), ms, over_plan if planned else over_float, last,
+                          ctx.download(d_out[v0], (1750, 1750, 3))))
     res = []
-    for interp, label, ms, ab, got in timed:
-        want = orc.valid_fill(orc.remap_u8(imgs[t["lens_key"]], t["map_x"], t["map_y"], interp=interp, threads=0), t["valid"], 0)
-        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, table mode, {label}", "key": label.replace(", map plans", "-plans"),
-                    "ms_per_pair": round(ms, 4), "algorithmic_MB_per_pair": round(ab / 1e6, 1), "frac_of_8TBps": round(ab / ms / 1e6 / 8000, 3),
+    for interp, label, ms, over, last, got in timed:
+        want = orc.valid_fill(orc.remap_u8(pairs_host[last][t["lens_key"]], t["map_x"], t["map_y"], interp=interp, threads=0), t["valid"], 0)
+        res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, table mode, {label}, {rotate} pairs in turn (HBM-cold)",
+                    "key": label.replace(", map plans", "-plans"),
+                    "ms_per_pair": round(ms, 4), "algorithmic_MB_per_pair": round(algo / 1e6, 1), "overhead_MB_per_pair": round(over / 1e6, 1),
+                    "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3), "frac_incl_map_bytes": round((algo + over) / ms / 1e6 / 8000, 3),
                     "parity_vs_oracle": bool(np.array_equal(got, want))})
-    for pl in plans.values():
-        ctx.map_plan_free(pl)
-    for b in list(dev.values()) + [x for tup in d_tab.values() for x in tup] + list(d_out.values()):
+    for pr in plans:
+        for pl in pr.values():
+            ctx.map_plan_free(pl)
+    for b in [x for d in devs for x in d.values()] + [x for dt in d_tabs for tup in dt.values() for x in tup] + list(d_out.values()):
         ctx.free(b)
     return res
 
@@ -366,10 +392,20 @@ def secondary_rows(ctx, steps=20):
         r = equirect_cfg(ctx, name, w, h, specs, 8 if key in ("cfg1", "cfg1-cubic", "cfg2-cubic") else 4, steps, interp=interp, with_mask=with_mask)
         out.append({"config": key, "workload": name, "unit": "frame", "us_per_unit": r["us_per_frame"], "frac": r["frac_of_8TBps"],
                     "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "parity_vs_oracle": r["parity_vs_oracle"]})
+    for key, name, interp in (("cfg2-u16", "8K rgb48 (uint16) -> 6x800^2, linear", gs360.INTERP_LINEAR),
+                              ("cfg2-u16-cubic", "8K rgb48 (uint16) -> 6x800^2, cubic", gs360.INTERP_CUBIC)):
+        r = equirect_u16_cfg(ctx, name, 7680, 3840, ring_views(6, 800, HFOV_12MM), 4, steps, interp)
+        out.append({"config": key, "workload": name, "unit": "frame", "us_per_unit": r["us_per_frame"], "frac": r["frac_of_8TBps"],
+                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "parity_vs_oracle": r["parity_vs_oracle"]})
     for r in cfg4_rows(ctx, steps):
         out.append({"config": "cfg4-" + r["key"], "workload": r["config"], "unit": "lens pair",
                     "us_per_unit": round(r["ms_per_pair"] * 1e3, 1), "frac": r["frac_of_8TBps"],
-                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_pair"], "parity_vs_oracle": r["parity_vs_oracle"]})
+                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_pair"], "overhead_MB_per_unit": r["overhead_MB_per_pair"],
+                    "frac_incl_overhead": r["frac_incl_map_bytes"], "parity_vs_oracle": r["parity_vs_oracle"]})
+    for r in color_cfg(ctx, steps):
+        kind = "color-u16" if "uint16" in r["config"] else ("color-noise" if "noise" in r["config"] else "color-smooth")
+        out.append({"config": kind, "workload": r["config"], "unit": "4000^2 image", "us_per_unit": round(r["ms_per_image"] * 1e3, 1),
+                    "frac": r["frac_of_8TBps"], "algorithmic_MB_per_unit": r["algorithmic_MB_per_image"], "parity_vs_oracle": r["parity_vs_oracle"]})
     return out
 
 
