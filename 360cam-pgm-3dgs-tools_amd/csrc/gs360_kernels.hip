@@ -85,20 +85,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_EQ_WAVES
 #define GS360_EQ_WAVES 5     // wavefronts per SIMD of the bilinear equirect kernel (measured optimum, see the kernel comment)
 #endif
-#ifndef GS360_LEAN_PAIRED
-#define GS360_LEAN_PAIRED 0  // lean member loop: row-paired gathers (v_permlane32_swap) or one gather per tap row
-#endif
-#ifndef GS360_ALIGNBYTE_RAW
-#define GS360_ALIGNBYTE_RAW 1
-#endif
-#if GS360_ALIGNBYTE_RAW      // v_alignbyte_b32 shifts by S2[1:0] bytes: a byte offset's upper bits need not be masked off
-#define GS360_AB(o) (o)
-#else
-#define GS360_AB(o) ((o) & 3u)
-#endif
-#ifndef GS360_PROBE
-#define GS360_PROBE 0        // measurement probes (never shipped): 1 = tap reads folded into 256 bytes, 2 = dword row stores dropped
-#endif
+#define GS360_AB(o) (o)   // v_alignbyte_b32 shifts by S2[1:0] bytes: a byte offset's upper bits need not be masked off
 #ifndef GS360_EQ_ROWS_KERNEL
 #define GS360_EQ_ROWS_KERNEL 1
 #endif
@@ -119,9 +106,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef GS360_RING_PARK_CUBIC
 #define GS360_RING_PARK_CUBIC 1
-#endif
-#ifndef GS360_PAIRED_FETCH
-#define GS360_PAIRED_FETCH 1
 #endif
 #ifndef GS360_SHIFTED_STORE
 #define GS360_SHIFTED_STORE 1   // dword stores for row segments that start off a dword boundary (0: byte stores, A/B reference)
@@ -148,21 +132,15 @@ struct RowsRaw { uint32_t a0, a1, a2, b0, b1, b2, sh; };   // sh = (o0 & 3) | (o
 __device__ __forceinline__ RowsRaw ld_rows_rgb_issue(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1) {
     RowsRaw r;
     r.sh = (o0 & 3u) | ((o1 & 3u) << 2);
-#if GS360_PAIRED_FETCH
     const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0 & ~3u, o1 & ~3u, false, false);
     const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
     const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
-#else
-    const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o0 & ~3u), 4));
-    const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o1 & ~3u), 4));
-#endif
     r.a0 = qa[0]; r.a1 = qa[1]; r.a2 = qa[2];
     r.b0 = qb[0]; r.b1 = qb[1]; r.b2 = qb[2];
     return r;
 }
 __device__ __forceinline__ void ld_rows_rgb_finish(const RowsRaw& r, uint2& t0, uint2& t1) {
     const uint32_t s0 = r.sh & 3u, s1 = r.sh >> 2;
-#if GS360_PAIRED_FETCH
     const u32x2 d0 = __builtin_amdgcn_permlane32_swap(r.a0, r.b0, false, false);   // .x = row y0, .y = row y1, own pixel
     const u32x2 d1 = __builtin_amdgcn_permlane32_swap(r.a1, r.b1, false, false);
     const u32x2 d2 = __builtin_amdgcn_permlane32_swap(r.a2, r.b2, false, false);
@@ -170,12 +148,6 @@ __device__ __forceinline__ void ld_rows_rgb_finish(const RowsRaw& r, uint2& t0, 
     t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, s0);
     t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, s1);
     t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, s1);
-#else
-    t0.x = __builtin_amdgcn_alignbyte(r.a1, r.a0, s0);
-    t0.y = __builtin_amdgcn_alignbyte(r.a2, r.a1, s0);
-    t1.x = __builtin_amdgcn_alignbyte(r.b1, r.b0, s1);
-    t1.y = __builtin_amdgcn_alignbyte(r.b2, r.b1, s1);
-#endif
 }
 __device__ __forceinline__ void ld_rows_rgb(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1, uint2& t0, uint2& t1) {
     ld_rows_rgb_finish(ld_rows_rgb_issue(src, o0, o1), t0, t1);
@@ -207,7 +179,7 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
             const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)packed);
             const uint32_t dw = __builtin_amdgcn_perm(pb, pa, rp.sel);   // = (pa >> sh) | (pb << (24 - sh)) on 24-bit pixels, one instruction
             int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
-            if (lane < full && !((GS360_PROBE & 2) && dw != 0x12345678u)) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
+            if (lane < full) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
             if (lane == full && rem)
                 for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
             return;
@@ -331,13 +303,8 @@ __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, i
     // one full-rate v_mad_u32_u24 per row instead of 64-bit multiply/add chains, and the load can use the
     // SGPR-base + VGPR-offset addressing form.
     const uint32_t col = (uint32_t)ixl * C;
-#if GS360_PROBE & 1      // probe builds only: every tap read lands in the first 256 bytes of the frame (no misses)
-    const uint32_t o0 = (__umul24((uint32_t)y0, (uint32_t)stride) + col) & 0xffu;
-    const uint32_t o1 = (__umul24((uint32_t)y1, (uint32_t)stride) + col) & 0xffu;
-#else
     const uint32_t o0 = __umul24((uint32_t)y0, (uint32_t)stride) + col;
     const uint32_t o1 = __umul24((uint32_t)y1, (uint32_t)stride) + col;
-#endif
     const uint8_t* r0 = src + o0;
     const uint8_t* r1 = src + o1;
     EqTaps<C> t;
@@ -1262,28 +1229,10 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                 const uint32_t col = (uint32_t)min(cx[s] >> 5, S.W - 5) * 3u;
                 o0[s] = (uint32_t)r0[s] + col;
                 o1[s] = (uint32_t)r1[s] + col;
-#if GS360_PROBE & 1
-                o0[s] &= 0xffu; o1[s] &= 0xffu;
-#endif
-#if GS360_LEAN_PAIRED
-                const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0[s] & ~3u, o1[s] & ~3u, false, false);
-                const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
-                const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
-#else
                 const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o0[s] & ~3u), 4));
                 const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (o1[s] & ~3u), 4));
-#endif
-#if GS360_PROBE & 4      // probe: no tap reads at all
-                ra[s][0] = o0[s]; ra[s][1] = o1[s]; ra[s][2] = (uint32_t)cx[s]; rb[s][0] = o1[s]; rb[s][1] = o0[s]; rb[s][2] = (uint32_t)cx[s] + 1u;
-                (void)qa; (void)qb;
-#else
                 ra[s][0] = qa[0]; ra[s][1] = qa[1]; ra[s][2] = qa[2];
-#if GS360_PROBE & 16     // probe: one gather per pixel (the second tap row reuses the first one's data)
-                rb[s][0] = ra[s][1]; rb[s][1] = ra[s][2]; rb[s][2] = ra[s][0]; (void)qb;
-#else
                 rb[s][0] = qb[0]; rb[s][1] = qb[1]; rb[s][2] = qb[2];
-#endif
-#endif
             }
         };
         auto resolve = [&](uint32_t (&pk)[kRowsPerWave], const bool flip, const int4 fyq) {
@@ -1293,20 +1242,10 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s) {
                 EqTaps<3> t;
-#if GS360_LEAN_PAIRED
-                const u32x2 d0 = __builtin_amdgcn_permlane32_swap(ra[s][0], rb[s][0], false, false);
-                const u32x2 d1 = __builtin_amdgcn_permlane32_swap(ra[s][1], rb[s][1], false, false);
-                const u32x2 d2 = __builtin_amdgcn_permlane32_swap(ra[s][2], rb[s][2], false, false);
-                t.t0.x = __builtin_amdgcn_alignbyte(d1.x, d0.x, GS360_AB(o0[s]));
-                t.t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, GS360_AB(o0[s]));
-                t.t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, GS360_AB(o1[s]));
-                t.t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, GS360_AB(o1[s]));
-#else
                 t.t0.x = __builtin_amdgcn_alignbyte(ra[s][1], ra[s][0], GS360_AB(o0[s]));
                 t.t0.y = __builtin_amdgcn_alignbyte(ra[s][2], ra[s][1], GS360_AB(o0[s]));
                 t.t1.x = __builtin_amdgcn_alignbyte(rb[s][1], rb[s][0], GS360_AB(o1[s]));
                 t.t1.y = __builtin_amdgcn_alignbyte(rb[s][2], rb[s][1], GS360_AB(o1[s]));
-#endif
                 eq_blend_f<3>(t, cx[s] & 31, fys[s], px[s]);
                 any_fix |= cx[s] >= fix_from;
             }
@@ -1339,20 +1278,16 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                 uint32_t dw[kRowsPerWave];
 #pragma unroll
                 for (int s = 0; s < kRowsPerWave; ++s) {
-#if GS360_PROBE & 8      // probe: no cross-lane repack
-                    dw[s] = pk[s] + (uint32_t)(la4 + lb4);
-#else
                     const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(la4 & 252, (int)pk[s]);
                     const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)pk[s]);
                     dw[s] = __builtin_amdgcn_perm(pb, pa, rp.sel);
-#endif
                 }
                 const uint32_t off = (uint32_t)lane << 2;
 #pragma unroll
                 for (int s = 0; s < kRowsPerWave; ++s) {
                     if (!row_ok[s]) continue;
                     uint8_t* const row = d0 + (int64_t)(flip ? out_h - 1 - ys[s] : ys[s]) * dstride;
-                    if (lane < full && !((GS360_PROBE & 2) && dw[s] != 0x12345678u)) __builtin_nontemporal_store(dw[s], reinterpret_cast<uint32_t*>(row + (size_t)off));
+                    if (lane < full) __builtin_nontemporal_store(dw[s], reinterpret_cast<uint32_t*>(row + (size_t)off));
                     if (rem && lane == full)
                         for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw[s] >> (8 * k));
                 }
@@ -1833,7 +1768,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
 #pragma unroll
             for (int s = 0; s < kRowsPerWave; ++s) {
                 const int y = flip ? out_h - 1 - ys[s] : ys[s];
-                if (cc < full && ys[s] < out_h && !((GS360_PROBE & 2) && dw[s] != 0x12345678u))
+                if (cc < full && ys[s] < out_h)
                     *reinterpret_cast<uint32_t*>(d + (size_t)(__umul24((uint32_t)y, dstride) + (uint32_t)(c0 * 3 + 4 * cc))) = dw[s];
             }
             return;

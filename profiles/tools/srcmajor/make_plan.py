@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, '/root/repo')
 
 
-def build(sx, sy, W, H, N, Bx, R, w, h, quad=True, pad=64, split=False, soa=False, ragged=False, ldsent=False):
+def build(sx, sy, W, H, N, Bx, R, w, h, quad=True, pad=64, split=False, soa=False, ragged=False, ldsent=False, rq=1):
     """sx, sy: int32 (h, w) EQ-SPEC coordinates of member 0.  Returns (header dict, tiles (T,8) int32, entries (E,2) uint32)."""
     assert W % N == 0 and (3 * W) % 16 == 0
     PB = 3 * (W // N)
@@ -36,7 +36,7 @@ def build(sx, sy, W, H, N, Bx, R, w, h, quad=True, pad=64, split=False, soa=Fals
     order = np.lexsort((ii.ravel(), jj.ravel(), vrel.ravel(), tid))
     tid_s = tid[order]; v_s = vrel.ravel()[order]; j_s = jj.ravel()[order]; i_s = ii.ravel()[order]
     xr_s = xr.ravel()[order]; iy_s = iy.ravel()[order]; fx_s = fx.ravel()[order]; fy_s = fy.ravel()[order]; nf_s = noflip.ravel()[order]
-    tiles = []; ent = []; rowtab = []; row_off = []; rt_pos = 0; ragged_bytes = [0]
+    tiles = []; ent = []; rowtab = []; row_off = []; rt_pos = 0; ragged_bytes = [0]; cls_total = [0]
     bounds = np.flatnonzero(np.diff(tid_s)) + 1
     starts = np.concatenate(([0], bounds)); ends = np.concatenate((bounds, [len(tid_s)]))
     ebeg = 0
@@ -47,7 +47,7 @@ def build(sx, sy, W, H, N, Bx, R, w, h, quad=True, pad=64, split=False, soa=Fals
         y0 = int(iy_t.min()); nrows = int(iy_t.max()) - y0 + 2
         pitch = wch * 16
         lds = (iy_t - y0) * pitch + (xr_t - x0)
-        if ragged:      # per row of the box: chunks [c_lo, c_hi) that some tap touches (tap rows r and r + 1, bytes [x, x + 6))
+        if ragged and not ldsent:      # per row of the box: chunks [c_lo, c_hi) that some tap touches (tap rows r and r + 1, bytes [x, x + 6))
             rr = np.concatenate([iy_t - y0, iy_t - y0 + 1]); xx = np.concatenate([xr_t - x0, xr_t - x0])
             lo = np.full(nrows, 1 << 30); hi = np.zeros(nrows, np.int64)
             np.minimum.at(lo, rr, xx // 16); np.maximum.at(hi, rr, (xx + 5) // 16 + 1)
@@ -86,13 +86,31 @@ def build(sx, sy, W, H, N, Bx, R, w, h, quad=True, pad=64, split=False, soa=Fals
             tiles.append((x0, y0, nrows, wch, ebeg, len(Q), ebeg + len(Q), len(S1)))
             ent.append(Q); ent.append(S1); ebeg += len(Q) + len(S1)
             continue
+        if ldsent and ragged:      # row table for the class-sorted ragged loader: [classes: count | rows << 16][rows: row | first chunk << 8], count descending
+            rr = np.concatenate([iy_t - y0, iy_t - y0 + 1]); xx = np.concatenate([xr_t - x0, xr_t - x0])
+            lo = np.full(nrows, 1 << 30); hi = np.zeros(nrows, np.int64)
+            np.minimum.at(lo, rr, xx // 16); np.maximum.at(hi, rr, (xx + 5) // 16 + 1)
+            n_r = np.where(hi > 0, hi - lo, 0); lo = np.where(hi > 0, lo, 0)
+            n_q = ((n_r + rq - 1) // rq) * rq
+            n_q = np.minimum(n_q, wch - lo)                      # stay inside the box
+            order_r = np.argsort(-n_q, kind="stable")
+            order_r = order_r[n_q[order_r] > 0]
+            cls_vals, cls_counts = [], []
+            for r_ in order_r:
+                if not cls_vals or cls_vals[-1] != n_q[r_]:
+                    cls_vals.append(int(n_q[r_])); cls_counts.append(0)
+                cls_counts[-1] += 1
+            tab = [c | (k << 16) for c, k in zip(cls_vals, cls_counts)] + [int(r_) | (int(lo[r_]) << 8) for r_ in order_r]
+            rowtab.append(np.array(tab, np.int32)); row_off.append(rt_pos); rt_pos += len(tab)
+            ragged_bytes[0] += int(n_q.sum()) * 16
+            cls_total[0] += len(cls_vals)
         if ldsent:
             assert (cnt == 4).all()
             nqp = ((nq + 15) // 16) * 16
             hdrw = np.zeros(nqp, np.uint32); pw = np.zeros(4 * nqp, np.uint32)
             hdrw[:nq] = (w0[0::4] & np.uint32(0x0fffffff)); hdrw[nq:] = hdrw[nq - 1]
             pw[:4 * nq] = w1; pw[4 * nq:] = np.tile(w1[-4:], nqp - nq)
-            tiles.append((x0, y0, nrows, wch, ebeg, nqp, 0, 0))
+            tiles.append((x0, y0, nrows, wch, ebeg, nqp, row_off[-1] if ragged else 0, len(cls_vals) if ragged else 0))
             ent.append(hdrw); ent.append(pw); ebeg += 5 * nqp
             continue
         E = np.zeros((nq * 4, 2), np.uint32)
@@ -107,7 +125,14 @@ def build(sx, sy, W, H, N, Bx, R, w, h, quad=True, pad=64, split=False, soa=Fals
     tiles = np.array(tiles, np.int32); entries = np.concatenate(ent)
     if soa or ldsent:
         entries = np.concatenate([entries, np.zeros(len(entries) & 1, np.uint32)]).reshape(-1, 2)
-    if ragged:          # the row tables ride behind the entries (as uint2 words); tiles[:, 6] = their offset in int32 units from the start of that block
+    if ragged and ldsent:
+        rt = np.concatenate(rowtab)
+        rt = np.concatenate([rt, np.zeros(len(rt) & 1, np.int32)]).view(np.uint32)
+        flat = entries.reshape(-1)
+        tiles[:, 6] += len(flat)              # dword offset of the tile's row table in the pool
+        entries = np.concatenate([flat, rt]).reshape(-1, 2)
+        print("class-sorted ragged rows: load MB/frame", ragged_bytes[0] * 2 * N / 1e6, "classes per tile", cls_total[0] / len(tiles))
+    elif ragged:          # the row tables ride behind the entries (as uint2 words); tiles[:, 6] = their offset in int32 units from the start of that block
         rt = np.concatenate(rowtab)
         rt = np.concatenate([rt, np.zeros(len(rt) & 1, np.int32)]).view(np.uint32).reshape(-1, 2)
         tiles[:, 7] = len(entries)           # uint2 index where the row tables start
@@ -128,7 +153,7 @@ def main():
     quad = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     W, H, N, S, HF = 7680, 3840, 6, 800, 112.61986494804043
     sx, sy = orc.equirect_map(orc.make_view(0.0, 0.0, HF, HF, S, S), W, H)
-    hdr, tiles, entries = build(sx, sy, W, H, N, Bx, R, S, S, quad=quad in (1, 4, 5), pad=64 if quad else 1, split=quad in (2, 3), soa=quad == 3, ragged=quad == 4, ldsent=quad == 5)
+    hdr, tiles, entries = build(sx, sy, W, H, N, Bx, R, S, S, quad=quad in (1, 4, 5, 6), pad=64 if quad else 1, split=quad in (2, 3), soa=quad == 3, ragged=quad in (4, 6), ldsent=quad in (5, 6), rq=int(sys.argv[5]) if len(sys.argv) > 5 else 1)
     print(hdr, "valid", int(((entries[:, 0] >> 28) & 1).sum()), "full", int(((entries[:, 0] >> 29) & 1).sum()),
           "load MB/frame", float((tiles[:, 2] * tiles[:, 3] * 16).sum()) * 2 * N / 1e6)
     with open(out, 'wb') as f:

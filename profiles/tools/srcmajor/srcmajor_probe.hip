@@ -800,6 +800,161 @@ __global__ __launch_bounds__(64 * (NCW + 1)) void srcmajor7_kernel(const SmLaunc
     }
 }
 
+// v9 = v7 with class-sorted ragged rows: per box row only the chunks some tap touches, rows sorted by chunk count so that the exec mask
+// changes a handful of times per image instead of every row (boxes that cross the seam keep the full-row loader).
+// (v7:) quad ownership (no byte path), the tile's plan entries LDS-resident (copied once per workgroup by the loader, replayed by every
+// image of the tile: the consumers issue no memory reads at all, only their stores), constant exec mask in the loader's row loop.
+template <int MODE, int NCW>
+__global__ __launch_bounds__(64 * (NCW + 1)) void srcmajor9_kernel(const SmLaunch2 P, const int ent_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+    __shared__ uint8_t* s_dst[12 * kMaxViews];
+    const SmLaunch& L = P.L;
+    const int b = blockIdx.x;
+    const int t = (b & 7) * P.gchunk + (b >> 3);
+    if (t >= P.total_groups) return;
+    const int f = t / P.groups_per_frame;
+    const int r = t - f * P.groups_per_frame;
+    const int ti = r / P.groups_per_tile, g0 = (r - ti * P.groups_per_tile) * P.G;
+    const SmTile T = L.tiles[ti];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = P.G;
+    uint8_t* const s_ent = s_lds;                        // [hdr: nq dwords][px words: 4 nq dwords]
+    uint8_t* const s_tile = s_lds + ent_bytes;
+    if (tid < G * L.N) {
+        const int g = tid / L.N, v = tid - g * L.N;
+        int q = v + ((g0 + g) >> 1); if (q >= L.N) q -= L.N;
+        s_dst[g * kMaxViews + v] = L.dst[f * L.N + L.qmap[q]];
+    }
+    const uint8_t* __restrict__ src = L.src[f];
+    const int rowbytes = 3 * L.W;
+    const int pitch = T.wch * 16;
+    const int nq = T.ecnt;
+    const uint32_t* __restrict__ pool32 = reinterpret_cast<const uint32_t*>(L.entries);
+    const int ncls = T.pad1;
+    int cls_lane = 0, row_lane = 0, nlist = 0;
+    if (wave == 0) {
+        if (lane < ncls) cls_lane = (int)pool32[T.pad0 + lane];
+        for (int c = 0; c < ncls; ++c) nlist += __builtin_amdgcn_readlane(cls_lane, c) >> 16;
+        if (lane < nlist) row_lane = (int)pool32[T.pad0 + ncls + lane];
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    auto dma_full = [&](const int img, uint8_t* const buf) {
+        const int k = img >> 1;
+        const bool flip = img & 1;
+        const int xk = T.x0 + k * L.PB;
+        for (int cb = 0; cb < T.wch; cb += 64) {
+            int x = xk + (cb + lane) * 16;
+            if (x >= rowbytes) x -= rowbytes;
+            if (x >= rowbytes) x -= rowbytes;
+            if (cb + lane < T.wch) {
+                int y = flip ? L.H - 1 - T.y0 : T.y0;
+                const int ystep = flip ? -1 : 1;
+                for (int row = 0; row < T.nrows; ++row, y += ystep) {
+                    const int yc = min(max(y, 0), L.H - 1);
+                    const uint8_t* rowp = src + (size_t)yc * L.src_stride;
+                    __builtin_amdgcn_global_load_lds((global_void_t*)(rowp + (uint32_t)x), (lds_void_t*)(buf + row * pitch + cb * 16), 16, 0, SM_DMA_AUX);
+                }
+            }
+        }
+    };
+    auto dma = [&](const int img, uint8_t* const buf) {
+        const int k = img >> 1;
+        const bool flip = img & 1;
+        const int xk = T.x0 + k * L.PB;
+        if (xk + pitch > rowbytes || T.wch > 64) { dma_full(img, buf); return; }       // the box crosses the seam: full rows, per-lane wrap
+        // lane p = p-th row of the sorted list: its global base (flip, clamp, 64-bit multiply ONCE per image across the lanes) and LDS offset
+        const int row = row_lane & 0xff, c0 = row_lane >> 8;
+        int y = flip ? L.H - 1 - (T.y0 + row) : T.y0 + row;
+        y = min(max(y, 0), L.H - 1);
+        const uint64_t rb = (uint64_t)(uintptr_t)src + (uint64_t)(uint32_t)y * (uint64_t)L.src_stride + (uint32_t)(xk + c0 * 16);
+        const int rb_lo = (int)(uint32_t)rb, rb_hi = (int)(uint32_t)(rb >> 32);
+        const int lo_lane = row * pitch + c0 * 16;
+        const uint32_t v16 = (uint32_t)lane * 16u;
+        int p = 0;
+        for (int c = 0; c < ncls; ++c) {
+            const int cw = __builtin_amdgcn_readlane(cls_lane, c);
+            const int cnt = cw & 0xffff, kk = cw >> 16;
+            if (lane < cnt) {                                     // ONE exec change per class
+                for (int i = 0; i < kk; ++i) {
+                    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(rb_hi, p + i) << 32) | (uint32_t)__builtin_amdgcn_readlane(rb_lo, p + i);
+                    const int lo = __builtin_amdgcn_readlane(lo_lane, p + i);
+                    __builtin_amdgcn_global_load_lds((global_void_t*)(reinterpret_cast<const uint8_t*>(base) + v16), (lds_void_t*)(buf + lo), 16, 0, SM_DMA_AUX);
+                }
+            }
+            p += kk;
+        }
+    };
+    if (wave == 0) {
+        const uint8_t* ge = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(L.entries) + T.ebeg);
+        const int eb = 20 * nq;
+        for (int o = 0; o < eb; o += 1024)
+            if (o + lane * 16 < eb)
+                __builtin_amdgcn_global_load_lds((global_void_t*)(ge + o + lane * 16), (lds_void_t*)(s_ent + o), 16, 0, 0);
+        if (MODE != 3) dma(g0, s_tile);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    const int k4 = lane & 3;
+    const uint32_t sel = k4 == 0 ? 0x04020100u : (k4 == 1 ? 0x05040201u : 0x06050402u);
+    const uint32_t* const e_hdr = reinterpret_cast<const uint32_t*>(s_ent);
+    const uint32_t* const e_px = e_hdr + nq;
+    const int npx = 4 * nq;
+    const bool dbg_on = P.dbg && (b % 61) == 0 && b / 61 < 256;
+    unsigned long long* const dbg = P.dbg + (size_t)(b / 61) * 64;
+    for (int g = 0; g < G; ++g) {
+        uint8_t* const cur_buf = s_tile + (g & 1) * P.buf_bytes;
+        if (dbg_on && lane == 0 && wave < 2 && g < 6) dbg[wave * 24 + g * 4 + 0] = __builtin_readcyclecounter();
+        if (wave == 0) {
+            if (g + 1 < G && MODE != 3) dma(g0 + g + 1, s_tile + ((g + 1) & 1) * P.buf_bytes);
+            if (dbg_on && lane == 0 && g < 6) dbg[g * 4 + 1] = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (dbg_on && lane == 0 && g < 6) dbg[g * 4 + 2] = __builtin_readcyclecounter();
+        } else if (MODE != 2) {
+            const bool flip = (g0 + g) & 1;
+            const int jbase = flip ? L.h - 1 : 0, jsgn = flip ? -1 : 1;
+            for (int i0 = (wave - 1) * 64; i0 < npx; i0 += 64 * NCW) {
+                const uint32_t pw = e_px[i0 + lane];
+                const uint32_t hd = e_hdr[(i0 + lane) >> 2];
+                const uint32_t o0 = pw & 0x1ffffu, o1 = o0 + (uint32_t)pitch;
+                const int fx = (pw >> 17) & 31, fy = (pw >> 22) & 31;
+                const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (o0 & ~3u));
+                const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (o1 & ~3u));
+                uint32_t a0, a1, a2, b0, b1, b2;
+                if (MODE == 5) { a0 = pw * 3u; a1 = pw * 5u; a2 = pw * 7u; b0 = hd * 3u; b1 = hd * 5u; b2 = hd * 7u; }      // probe: no tap reads from LDS
+                else { a0 = qa[0]; a1 = qa[1]; a2 = qa[2]; b0 = qb[0]; b1 = qb[1]; b2 = qb[2]; }
+                const uint32_t t0x = __builtin_amdgcn_alignbyte(a1, a0, o0), t0y = __builtin_amdgcn_alignbyte(a2, a1, o0);
+                const uint32_t t1x = __builtin_amdgcn_alignbyte(b1, b0, o1), t1y = __builtin_amdgcn_alignbyte(b2, b1, o1);
+                uint32_t pk;
+                if (MODE == 1) {
+                    pk = (t0x ^ t0y ^ t1x ^ t1y) & 0xffffffu;
+                } else {
+                    const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);
+                    const uint32_t wr0 = __umul24(ah, (uint32_t)(32 - fy)), wr1 = __umul24(ah, (uint32_t)fy);
+                    const uint32_t c0 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1x, t1x, PAIR(0, 3)), wr1, dot2_i16(__builtin_amdgcn_perm(t0x, t0x, PAIR(0, 3)), wr0, 512)) >> 10;
+                    const uint32_t c1 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(1, 4)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(1, 4)), wr0, 512)) >> 10;
+                    const uint32_t c2 = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t1y, t1x, PAIR(2, 5)), wr1, dot2_i16(__builtin_amdgcn_perm(t0y, t0x, PAIR(2, 5)), wr0, 512)) >> 10;
+                    pk = c0 | (c1 << 8) | (c2 << 16);
+                }
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+                const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
+                const int i = hd & 0xfff, j = (hd >> 12) & 0xfff, vrel = (hd >> 24) & 15;    // the quad's first column
+                const int jj = jbase + jsgn * j;
+                uint8_t* const d = s_dst[g * kMaxViews + vrel];
+                // lane k of a quad writes dword k of its 12 bytes; lane 3 repeats lane 2's store (same value, same address)
+                const uint32_t off = (uint32_t)(jj * L.w + i) * 3u + 4u * (uint32_t)min(k4, 2);
+                const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw, 0xA4, 0xf, 0xf, false);    // quad_perm [0,1,2,2]
+                if (MODE == 4) { if (dwq == 0x12345678u && fx == 77) *(__attribute__((address_space(1))) uint32_t*)((uintptr_t)d + off) = dwq; }   // probe: no stores
+                else if (SM_NT_STORE) __builtin_nontemporal_store(dwq, (__attribute__((address_space(1))) uint32_t*)((uintptr_t)d + off));
+                else *(__attribute__((address_space(1))) uint32_t*)((uintptr_t)d + off) = dwq;
+            }
+        }
+        if (dbg_on && lane == 0 && wave == 1 && g < 6) dbg[24 + g * 4 + 1] = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        if (dbg_on && lane == 0 && wave < 2 && g < 6) dbg[wave * 24 + g * 4 + 3] = __builtin_readcyclecounter();
+    }
+}
+
+
 // v8 = v7 with TWO loader wavefronts (even / odd images): a tile image is requested two turns ahead, so both LDS buffers are landing
 // zones except while one is being rendered (twice the bytes in flight per CU).
 // (v7:) quad ownership (no byte path), the tile's plan entries LDS-resident (copied once per workgroup by the loader, replayed by every
@@ -983,6 +1138,8 @@ int main(int argc, char** argv) {
         if (ncw == 74) { if (mode == 0) L7(0, 4) if (mode == 1) L7(1, 4) if (mode == 2) L7(2, 4) if (mode == 3) L7(3, 4) return; }
         if (ncw == 78) { if (mode == 0) L7(0, 8) if (mode == 1) L7(1, 8) if (mode == 2) L7(2, 8) if (mode == 3) L7(3, 8) if (mode == 4) L7(4, 8) if (mode == 5) L7(5, 8) return; }
 #define L8(M, C) { const size_t l7 = lds2 + ent_bytes; CK(hipFuncSetAttribute((const void*)srcmajor8_kernel<M, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l7)); hipLaunchKernelGGL((srcmajor8_kernel<M, C>), dim3(grid2), dim3(64 * (C + 2)), l7, 0, P, ent_bytes); }
+#define L9(M, C) { const size_t l7 = lds2 + ent_bytes; CK(hipFuncSetAttribute((const void*)srcmajor9_kernel<M, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l7)); hipLaunchKernelGGL((srcmajor9_kernel<M, C>), dim3(grid2), dim3(64 * (C + 1)), l7, 0, P, ent_bytes); }
+        if (ncw == 98) { if (mode == 0) L9(0, 8) if (mode == 1) L9(1, 8) if (mode == 2) L9(2, 8) if (mode == 3) L9(3, 8) if (mode == 4) L9(4, 8) if (mode == 5) L9(5, 8) return; }
         if (ncw == 84) { if (mode == 0) L8(0, 4) if (mode == 1) L8(1, 4) if (mode == 2) L8(2, 4) if (mode == 3) L8(3, 4) return; }
         if (ncw == 86) { if (mode == 0) L8(0, 6) if (mode == 1) L8(1, 6) if (mode == 2) L8(2, 6) if (mode == 3) L8(3, 6) return; }
         if (ncw == 88) { if (mode == 0) L8(0, 8) if (mode == 1) L8(1, 8) if (mode == 2) L8(2, 8) if (mode == 3) L8(3, 8) if (mode == 4) L8(4, 8) if (mode == 5) L8(5, 8) return; }
@@ -1002,7 +1159,7 @@ int main(int argc, char** argv) {
       printf("occupancy API: %d workgroups per CU (dynamic LDS %zu)\n", nb, lds2); }
     for (int mode = 0; mode < 6; ++mode) {
         if (mode_only >= 0 && mode != mode_only) continue;
-        if (mode >= 4 && ncw != 78 && ncw != 88) continue;
+        if (mode >= 4 && ncw != 78 && ncw != 88 && ncw != 98) continue;
         const int NSET = getenv("SM_QUICK") ? 3 : 400, NIT = getenv("SM_QUICK") ? 5 : 100;
         for (int i = 0; i < NSET; ++i) launch2(mode);
         CK(hipDeviceSynchronize());
