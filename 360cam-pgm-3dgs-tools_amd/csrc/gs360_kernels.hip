@@ -25,67 +25,13 @@
 // CPU oracle bit for bit; only explicit __builtin_fmaf may fuse.
 #include <type_traits>
 
-#include "gs360_kernels.h"
-#include "gs360_eqspec.h"
-#include "gs360_blend.h"
-#include "gs360_rowstore.h"
+#include "gs360_sampler.h"
 
 namespace gs360 {
 
-// ------------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint2 ld_u64(const uint8_t* p) {
-    uint2 v;
-    __builtin_memcpy(&v, p, 8);  // unaligned 8-byte load (gfx950 runs in unaligned access mode)
-    return v;
-}
-__device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }
-
-// Lane index / uniform value behind an optimisation barrier.  The store helpers derive a dozen per-lane constants from the
-// lane index (dword slicing of 3-byte pixels); inside the ring-member loop of eq_views_kernel the compiler would hoist all
-// of them -- for every store variant -- out of the loop and spill (measured: 120 VGPRs spilled at a 96-register budget).
-// A value that comes out of a volatile asm cannot be hoisted or merged, so each store recomputes its few constants in place.
-__device__ __forceinline__ int lane_here() {
-    int l = threadIdx.x & 63;
-    asm volatile("" : "+v"(l));
-    return l;
-}
-__device__ __forceinline__ int uniform_here(int v) {
-    v = __builtin_amdgcn_readfirstlane(v);     // wave-uniform by construction; a no-op when the value already sits in an SGPR
-    asm volatile("" : "+s"(v));
-    return v;
-}
-
-// "some lane": the comparison's lane mask tested directly.  (__any() goes through an int -- v_cndmask 0/1 + v_cmp_ne per call --
-// and these tests sit in the arithmetic-bound inner loops.)
-__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-// min(max(x, 0), hi) for a wave-uniform hi >= 0 as ONE v_med3_i32 (the compiler only fuses the pair when both bounds are constants)
-__device__ __forceinline__ int clamp0_uniform(int x, int hi) {
-    int r;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
-    return r;
-}
-
-// 8 bytes starting at the (unaligned) address p, fetched as ONE dword-aligned 12-byte access and shifted into
-// place with v_alignbyte.  The texture-address path merges dword-aligned lane accesses of a quad into cache-line
-// requests; byte-misaligned ones are looked up lane by lane (measured: 96 tag lookups per 64-lane instruction).
-// Reads bytes [p & ~3, (p & ~3) + 12).
-__device__ __forceinline__ uint2 ld_u64_via_aligned96(const uint8_t* p) {
-    uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));  // stays a global pointer
-    uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-    uint2 v;
-    v.x = __builtin_amdgcn_alignbyte(d1, d0, o);
-    v.y = __builtin_amdgcn_alignbyte(d2, d1, o);
-    return v;
-}
-
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_EQ_WAVES
 #define GS360_EQ_WAVES 5     // wavefronts per SIMD of the bilinear equirect kernel (measured optimum, see the kernel comment)
 #endif
-#define GS360_AB(o) (o)   // v_alignbyte_b32 shifts by S2[1:0] bytes: a byte offset's upper bits need not be masked off
 #ifndef GS360_EQ_ROWS_KERNEL
 #define GS360_EQ_ROWS_KERNEL 1
 #endif
@@ -107,112 +53,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef GS360_RING_PARK_CUBIC
 #define GS360_RING_PARK_CUBIC 1
 #endif
-#ifndef GS360_SHIFTED_STORE
-#define GS360_SHIFTED_STORE 1   // dword stores for row segments that start off a dword boundary (0: byte stores, A/B reference)
-#endif
 #ifndef GS360_EQ_LEAN
 #define GS360_EQ_LEAN 1      // bilinear RGB row-per-slot views: the lean, software-pipelined member loop (0: the round-3 loop, A/B reference)
 #endif
 
-
-// The 8 tap bytes (two RGB pixels + 2) of rows y0 and y1 of one pixel, at byte offsets o0 / o1 from `src`.
-// Row-paired gathers: issued naively, one instruction reads row y0 of all 64 pixels and the next one row y1; where the
-// view bends across source rows, row Y is "y0" for one run of lanes and "y1" for the neighbouring run, so the second
-// instruction asks for lines the first one has just missed on and the L1 stalls on the pending fill.  Here lanes 0-31
-// of the first instruction read row y0 and lanes 32-63 row y1 of the SAME 32 pixels (second instruction: the other 32
-// pixels), so both uses of a line meet in one instruction and are merged by the address coalescer.
-// v_permlane32_swap (gfx950) builds the two address vectors from (o0, o1) in one operation and puts the returned
-// dwords back in pixel order.  Each read is a dword-aligned 12-byte access shifted into place with v_alignbyte.
-// Two steps so that a wavefront can put ALL its gathers in flight before the first result is touched (the caller separates
-// the steps with a scheduling barrier: left to itself the scheduler interleaves load pairs with their consumers as soon as
-// the surrounding code tightens the register budget, which serialises the misses -- measured 20.7 -> 30.1 us per cfg2 frame):
-//   ld_rows_rgb_issue   address swap + the two 12-byte loads (raw dwords, still in fetch order)
-//   ld_rows_rgb_finish  swap the returned dwords back into pixel order and shift them into place
-struct RowsRaw { uint32_t a0, a1, a2, b0, b1, b2, sh; };   // sh = (o0 & 3) | (o1 & 3) << 2
-__device__ __forceinline__ RowsRaw ld_rows_rgb_issue(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1) {
-    RowsRaw r;
-    r.sh = (o0 & 3u) | ((o1 & 3u) << 2);
-    const u32x2 adr = __builtin_amdgcn_permlane32_swap(o0 & ~3u, o1 & ~3u, false, false);
-    const uint32_t* qa = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.x, 4));
-    const uint32_t* qb = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + adr.y, 4));
-    r.a0 = qa[0]; r.a1 = qa[1]; r.a2 = qa[2];
-    r.b0 = qb[0]; r.b1 = qb[1]; r.b2 = qb[2];
-    return r;
-}
-__device__ __forceinline__ void ld_rows_rgb_finish(const RowsRaw& r, uint2& t0, uint2& t1) {
-    const uint32_t s0 = r.sh & 3u, s1 = r.sh >> 2;
-    const u32x2 d0 = __builtin_amdgcn_permlane32_swap(r.a0, r.b0, false, false);   // .x = row y0, .y = row y1, own pixel
-    const u32x2 d1 = __builtin_amdgcn_permlane32_swap(r.a1, r.b1, false, false);
-    const u32x2 d2 = __builtin_amdgcn_permlane32_swap(r.a2, r.b2, false, false);
-    t0.x = __builtin_amdgcn_alignbyte(d1.x, d0.x, s0);
-    t0.y = __builtin_amdgcn_alignbyte(d2.x, d1.x, s0);
-    t1.x = __builtin_amdgcn_alignbyte(d1.y, d0.y, s1);
-    t1.y = __builtin_amdgcn_alignbyte(d2.y, d1.y, s1);
-}
-__device__ __forceinline__ void ld_rows_rgb(const uint8_t* __restrict__ src, uint32_t o0, uint32_t o1, uint2& t0, uint2& t1) {
-    ld_rows_rgb_finish(ld_rows_rgb_issue(src, o0, o1), t0, t1);
-}
-
-// bilinear blend of one channel, weights a0+a1 = 32, b0+b1 = 32  ->  (sum + 512) >> 10
-__device__ __forceinline__ uint32_t blend(uint32_t s00, uint32_t s01, uint32_t s10, uint32_t s11,
-                                          uint32_t w00, uint32_t w01, uint32_t w10, uint32_t w11) {
-    return (s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + 512u) >> 10;
-}
-
-// Store one wavefront row segment of n_px pixels.  Lane l holds the pixel at position l of the segment
-// (reversed = false) or at position n_px-1-l (reversed = true, the mirrored half of a view); channels in px[0..C-1].
-// C == 3: pixels are packed to 24 bits and re-sliced into dwords with two cross-lane shuffles so that the
-// row leaves as 4-byte stores (lane j writes bytes 4j..4j+3 = tail of pixel 4j/3 + head of the next one).
-// skip_first drops position 0 (the centre column of an odd-width view, which is its own mirror); the caller then
-// passes aligned4 = false and the per-lane byte path below handles it.
-// SHIFTED = false leaves the off-boundary dword path out (the bicubic equirect kernels sit at their register limit).
-template <int C, bool SHIFTED = true>
-__device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4], int n_px, bool aligned4, const RowPack& rp,
-                                          bool reversed = false, bool skip_first = false) {
-    const int lane = rp.lane;
-    if constexpr (C == 3) {
-        if (aligned4) {
-            uint32_t packed = px[0] | (px[1] << 8) | (px[2] << 16);
-            // source lanes (as byte addresses, wrapped to the wavefront): pixel a and a + 1, or their mirror images
-            const int la4 = reversed ? 4 * (n_px - 1) - rp.a4 : rp.a4, lb4 = reversed ? la4 - 4 : la4 + 4;
-            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(la4 & 252, (int)packed);
-            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb4 & 252, (int)packed);
-            const uint32_t dw = __builtin_amdgcn_perm(pb, pa, rp.sel);   // = (pa >> sh) | (pb << (24 - sh)) on 24-bit pixels, one instruction
-            int n_bytes = 3 * n_px, full = n_bytes >> 2, rem = n_bytes & 3;
-            if (lane < full) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(row) + lane);   // written once, never re-read
-            if (lane == full && rem)
-                for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
-            return;
-        }
-        if (SHIFTED && GS360_SHIFTED_STORE && !skip_first) {
-            // a segment that starts off a dword boundary (widths that are not multiples of four): the same two shuffles, the segment's
-            // byte stream re-sliced at its own misalignment -- lanes 0..47 write the aligned dwords inside it, lanes 48..50 its 0-3 head
-            // bytes, lanes 52..54 its 0-3 tail bytes (one dword store + one byte store instead of three byte stores per pixel)
-            const uint32_t packed = px[0] | (px[1] << 8) | (px[2] << 16);
-            const int n_bytes = 3 * n_px;
-            const int dh = (int)((0u - (uint32_t)reinterpret_cast<uintptr_t>(row)) & 3u);      // head bytes
-            const int nf = (n_bytes - dh) >> 2, tl = (n_bytes - dh) & 3, k = lane & 3;
-            const int sj = lane < 48 ? 4 * lane + dh : (lane < 52 ? k : dh + 4 * nf + k);     // first stream byte of this lane's piece
-            const int a = (sj * 21846) >> 16, b = sj - 3 * a;                                 // pixel, byte in it
-            const int qa = min(a, n_px - 1), qb = min(a + 1, n_px - 1);
-            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (reversed ? n_px - 1 - qa : qa), (int)packed);
-            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (reversed ? n_px - 1 - qb : qb), (int)packed);
-            const uint32_t dw = __builtin_amdgcn_perm(pb, pa, b == 0 ? 0x04020100u : (b == 1 ? 0x05040201u : 0x06050402u));
-            if (lane < nf) __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(__builtin_assume_aligned(row + sj, 4)));
-            else if ((lane >= 48 && lane < 52 && k < dh) || (lane >= 52 && lane < 56 && k < tl)) row[sj] = (uint8_t)dw;
-            return;
-        }
-    }
-    const int pos = reversed ? n_px - 1 - lane : lane;
-    if constexpr (C == 4) {
-        if (aligned4) {
-            if (lane < n_px) reinterpret_cast<uint32_t*>(row)[pos] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-            return;
-        }
-    }
-    if (lane < n_px && !(skip_first && pos == 0))
-        for (int c = 0; c < C; ++c) row[pos * C + c] = (uint8_t)px[c];
-}
 
 // Store for the blocked lane map (RGB).  A wavefront holds a patch of 4 rows x (16 NS) columns in NS slots -- lane l of
 // slot s0+s is pixel (row l>>4, column 16 s + (l&15)).  Pixels are written as packed dwords into the wavefront's LDS
@@ -286,13 +130,6 @@ struct BlkStore {
 //              sits in the last columns, are flagged and repaired later by eq_sample_slow.
 //   eq_blend   unpacks the taps and applies the 1/32-px fixed-point bilinear weights.
 template <int C>
-struct EqTaps {
-    uint2 t0, t1;   // raw bytes of rows y0 / y1 starting at column ix
-    RowsRaw raw;    // C == 3: the loads in flight (eq_taps_finish turns them into t0 / t1)
-    bool fix;       // needs the slow (wrapping) path
-};
-
-template <int C>
 __device__ __forceinline__ EqTaps<C> eq_fetch(const uint8_t* __restrict__ src, int64_t stride, int W, int H, int sx, int sy) {
     const int ix = sx >> 5, iy = sy >> 5;
     // |lat| <= pi/2 by construction of eq_atan2_red, so sy lies in [-16, 32 H - 16] and iy in [-1, H - 1]: one clamp per row
@@ -330,33 +167,6 @@ __device__ __forceinline__ void eq_taps_finish(EqTaps<C>& t) {
 
 // (dot2_i16, dot2_i16_from, GS360_PAIR and the RGB row blend: gs360_blend.h, shared with gs360_srcmajor.hip)
 
-template <int C>
-__device__ __forceinline__ void eq_blend_f(const EqTaps<C>& t, const int fx, const int fy, uint32_t (&out)[4]);
-template <int C>
-__device__ __forceinline__ void eq_blend(const EqTaps<C>& t, int sx, int sy, uint32_t (&out)[4]) {
-    eq_blend_f<C>(t, sx & 31, sy & 31, out);
-}
-template <int C>
-__device__ __forceinline__ void eq_blend_f(const EqTaps<C>& t, const int fx, const int fy, uint32_t (&out)[4]) {   // fx, fy in [0, 31]
-    // (sum S a b + 512) >> 10 with a in {32-fx, fx}, b in {32-fy, fy}: the weights of one row, a0 b | (a1 b) << 16, are
-    // one multiply of the packed horizontal pair (a1 b <= 1024 cannot carry into the upper half)
-    const uint32_t ah = (uint32_t)(32 - fx) | ((uint32_t)fx << 16);             // < 2^22
-    const uint32_t wr0 = __umul24(ah, (uint32_t)(32 - fy)), wr1 = __umul24(ah, (uint32_t)fy);
-    if constexpr (C == 3) {          // row bytes: r0 g0 b0 r1 | g1 b1 . .
-        uint32_t px[3];
-        blend_rgb_rows(t.t0, t.t1, fx, fy, px);
-        out[0] = px[0]; out[1] = px[1]; out[2] = px[2];
-    } else if constexpr (C == 4) {   // row bytes: r0 g0 b0 a0 | r1 g1 b1 a1
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            out[c] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.y, t.t1.x, GS360_PAIR(c, 4 + c)), wr1,
-                                        dot2_i16_from(__builtin_amdgcn_perm(t.t0.y, t.t0.x, GS360_PAIR(c, 4 + c)), wr0, 512)) >> 10;
-    } else {                         // row bytes: v0 v1
-        out[0] = (uint32_t)dot2_i16(__builtin_amdgcn_perm(t.t1.x, t.t1.x, GS360_PAIR(0, 1)), wr1,
-                                    dot2_i16_from(__builtin_amdgcn_perm(t.t0.x, t.t0.x, GS360_PAIR(0, 1)), wr0, 512)) >> 10;
-    }
-}
-
 // byte-wise path with the horizontal wrap (ix + 1 == W -> column 0); used only for flagged lanes
 template <int C>
 __device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
@@ -373,145 +183,6 @@ __device__ __forceinline__ void eq_sample_slow(const uint8_t* __restrict__ src, 
         out[c] = blend(r0[ix * C + c], r0[ix1 * C + c], r1[ix * C + c], r1[ix1 * C + c], w00, w01, w10, w11);
 }
 
-// ---- cubic variant of the equirect sampler (4x4 Keys taps, OpenCV fixed-point table) -------------------------------
-// Two steps, like the bilinear fetch: cubic_issue_rgb puts the 4 row reads of one RGB pixel in flight (12 contiguous bytes
-// each, fetched as a dword-aligned 16-byte read) without control flow and without touching a result; eq_cubic_blend shifts
-// the rows into place, reads the 32-byte weight entry (LDS: short latency, so it need not occupy 8 registers while the
-// gathers fly) and blends.  Lanes whose window touches the seam or the last columns are flagged and redone by eq_cubic_slow.
-struct EqCubicTaps {
-    uint32_t raw[4][4];   // the four aligned dwords of each window row, as loaded
-    uint32_t sh;          // byte offset of the window inside the aligned read (the same for all four rows)
-    int phase;            // fy * 32 + fx
-    bool fix;
-};
-
-// window anchored at texel (ix, iy) with phase (fx, fy); `fix` = the window's columns could not be read in place.
-// `stride4` (wave-uniform): the row stride is a multiple of 4, so all four rows start at the same misalignment (`sh` = that one
-// value; otherwise four 2-bit fields).  Every read is src + a 32-bit lane offset: scalar base + vector offset addressing, no
-// 64-bit vector adds.
-__device__ __forceinline__ EqCubicTaps cubic_issue_rgb(const uint8_t* __restrict__ src, uint32_t stride, bool stride4, int W, int H,
-                                                       int ix, int iy, int fx, int fy) {
-    EqCubicTaps t;
-    const int x0 = clamp0_uniform(ix - 1, W - 6);           // 16-byte aligned read of 12 tap bytes stays in-row
-    t.fix = (x0 != ix - 1);
-    t.phase = fy * 32 + fx;
-    const uint32_t col = (uint32_t)x0 * 3u;
-    uint32_t offs[4];                                       // the branches meet on 32-bit offsets, not on pointers
-    if (stride4) {
-        const uint32_t o = ((uint32_t)reinterpret_cast<uintptr_t>(src) + col) & 3u;
-        t.sh = o;
-        const uint32_t cb = col - o;
-        // Common case (wave-uniform test): no window of the wavefront touches the first or the last image row -- the four rows
-        // are off0 + k * stride (the kernel is arithmetic-bound).
-        if (!any_lane(iy < 1 || iy > H - 3)) {
-            offs[0] = __umul24((uint32_t)(iy - 1), stride) + cb;
-#pragma unroll
-            for (int ky = 1; ky < 4; ++ky) offs[ky] = offs[ky - 1] + stride;
-        } else {
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky) offs[ky] = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + cb;
-        }
-    } else {
-        t.sh = 0;
-#pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            const uint32_t off = __umul24((uint32_t)min(max(iy - 1 + ky, 0), H - 1), stride) + col;
-            const uint32_t o = ((uint32_t)reinterpret_cast<uintptr_t>(src) + off) & 3u;
-            offs[ky] = off - o;
-            t.sh |= o << (2 * ky);
-        }
-    }
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(src + (size_t)offs[ky], 4));
-        t.raw[ky][0] = q[0]; t.raw[ky][1] = q[1]; t.raw[ky][2] = q[2]; t.raw[ky][3] = q[3];
-    }
-    return t;
-}
-
-// The launch constants the samplers need, as plain values (see the ring-member loop of eq_views_kernel: they are handed over
-// behind an optimisation barrier so that they stay in registers instead of being re-read from the kernel argument).
-struct EqSrc {
-    int W, H;
-    int64_t src_stride, mask_stride;
-    bool stride4;        // src_stride % 4 == 0
-};
-
-__device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqSrc& L, const uint8_t* __restrict__ src, int sx, int sy) {
-    return cubic_issue_rgb(src, (uint32_t)L.src_stride, L.stride4, L.W, L.H, sx >> 5, sy >> 5, sx & 31, sy & 31);
-}
-
-// 48 multiply-adds per pixel as 24 v_dot2_i32_i16 (see eq_blend): constant selectors -- the 12 tap bytes of a row are
-// b0..b11, channel c owns b[c], b[3+c], b[6+c], b[9+c] -- and the table already stores the weights as int16 pairs.
-// `wtab` is the workgroup's LDS copy of the table (cubic_lds_fill / cubic_lds_weights).
-
-// The LDS copy of the 32 x 32-phase weight table is kept as TWO half tables -- window rows 0-1 of every phase (16 bytes each), then
-// rows 2-3 -- instead of 1024 entries of 32 bytes: a lane's two 16-byte reads then collide with another lane's only when their
-// phases differ by a multiple of 16 instead of 8 (round 3: 59 % of the cubic kernels' LDS-active cycles were bank conflicts).
-#ifndef GS360_CUBIC_SPLIT
-#define GS360_CUBIC_SPLIT 1
-#endif
-__device__ __forceinline__ void cubic_lds_weights(const int16_t* wtab, int phase, uint32_t (&wpk)[8]) {
-    const uint4* wq = reinterpret_cast<const uint4*>(wtab);
-#if GS360_CUBIC_SPLIT
-    const uint4 wa = wq[phase], wb = wq[1024 + phase];
-#else
-    const uint4 wa = wq[2 * phase], wb = wq[2 * phase + 1];
-#endif
-    wpk[0] = wa.x; wpk[1] = wa.y; wpk[2] = wa.z; wpk[3] = wa.w; wpk[4] = wb.x; wpk[5] = wb.y; wpk[6] = wb.z; wpk[7] = wb.w;
-}
-// fill: thread t copies 16-byte piece i of the global table ([phase][2] pieces) to its place in the LDS layout
-__device__ __forceinline__ void cubic_lds_fill(int16_t* s_wtab, const int16_t* g_tab, int n_threads) {
-    const uint4* g = reinterpret_cast<const uint4*>(g_tab);
-    uint4* l = reinterpret_cast<uint4*>(s_wtab);
-    for (int i = threadIdx.x; i < 2048; i += n_threads) {
-#if GS360_CUBIC_SPLIT
-        l[(i & 1) * 1024 + (i >> 1)] = g[i];
-#else
-        l[i] = g[i];
-#endif
-    }
-}
-
-template <bool ONE_SHIFT>
-__device__ __forceinline__ void eq_cubic_rows(const EqCubicTaps& t, const uint32_t (&wpk)[8], int (&acc)[3]) {
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky) {
-        const uint32_t o = ONE_SHIFT ? t.sh : ((t.sh >> (2 * ky)) & 3u);
-        const uint32_t d0 = __builtin_amdgcn_alignbyte(t.raw[ky][1], t.raw[ky][0], o);
-        const uint32_t d1 = __builtin_amdgcn_alignbyte(t.raw[ky][2], t.raw[ky][1], o);
-        const uint32_t d2 = __builtin_amdgcn_alignbyte(t.raw[ky][3], t.raw[ky][2], o);
-        const uint32_t w01 = wpk[2 * ky], w23 = wpk[2 * ky + 1];
-        // perm(a, b, sel): bytes 0..3 come from b, 4..7 from a.  Row 0 starts the three chains from the rounding constant.
-        const uint32_t p0 = __builtin_amdgcn_perm(d0, d0, GS360_PAIR(0, 3));             // b0, b3
-        const uint32_t p1 = __builtin_amdgcn_perm(d1, d0, GS360_PAIR(1, 4));             // b1 = d0.1, b4 = d1.0
-        const uint32_t p2 = __builtin_amdgcn_perm(d1, d0, GS360_PAIR(2, 5));             // b2 = d0.2, b5 = d1.1
-        if (ky == 0) {
-            acc[0] = dot2_i16_from(p0, w01, 1 << 14);
-            acc[1] = dot2_i16_from(p1, w01, 1 << 14);
-            acc[2] = dot2_i16_from(p2, w01, 1 << 14);
-        } else {
-            acc[0] = dot2_i16(p0, w01, acc[0]);
-            acc[1] = dot2_i16(p1, w01, acc[1]);
-            acc[2] = dot2_i16(p2, w01, acc[2]);
-        }
-        acc[0] = dot2_i16(__builtin_amdgcn_perm(d2, d1, GS360_PAIR(2, 5)), w23, acc[0]);            // b6 = d1.2, b9 = d2.1
-        acc[1] = dot2_i16(__builtin_amdgcn_perm(d2, d1, GS360_PAIR(3, 6)), w23, acc[1]);            // b7 = d1.3, b10 = d2.2
-        acc[2] = dot2_i16(__builtin_amdgcn_perm(d2, d2, GS360_PAIR(0, 3)), w23, acc[2]);            // b8 = d2.0, b11 = d2.3
-    }
-}
-
-__device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, const int16_t* wtab, bool stride4, uint32_t (&out)[4]) {
-    uint32_t wpk[8];
-    cubic_lds_weights(wtab, t.phase, wpk);
-    int acc[3];                                           // (sum + 2^14) >> 15: the chains start at 2^14
-    if (stride4) eq_cubic_rows<true>(t, wpk, acc);        // wave-uniform
-    else eq_cubic_rows<false>(t, wpk, acc);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max(acc[c] >> 15, 0), 255);
-}
-
-// generic cubic sample: columns wrap, rows clamp (any channel count; also the repair path of the RGB fast path)
 template <int C>
 __device__ __forceinline__ void eq_cubic_slow(const EqSrc& L, const int16_t* wtab, const uint8_t* __restrict__ src, int sx, int sy, uint32_t (&out)[4]) {
     const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
@@ -1868,740 +1539,6 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
 
 
 // ------------------------------------------------------------------------------------------------
-// cv2.remap semantics (shared by the table kernel and the fused fisheye kernel)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int cv_round(float v) {  // SSE cvtss2si: half-to-even, indefinite -> INT_MIN
-    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (int)0x80000000;
-    return (int)__builtin_rintf(v);
-}
-__device__ __forceinline__ int sat_s16(int v) { return min(max(v, -32768), 32767); }
-
-// ---- map plans -------------------------------------------------------------------------------------------------------------------
-// cv2.remap turns its float maps into 1/32-pixel fixed point on every call (cvRound(map * 32), integer part saturated to int16) before
-// any sampling; a plan does that once and keeps the result in 5 bytes per pixel instead of the 9 of two floats and a valid byte.  The
-// integer part is clamped to [-8, 4087]: every position whose widest window (Lanczos-4: x - 3 .. x + 4) still touches a source of up
-// to 4079 x 4079 pixels is kept as it is, and one that is moved had no tap inside the image before and has none after -- the border
-// constant either way.  The samplers take the position back as floats k / 32, exact, whose cvRound(. * 32) is k again.
-__global__ __launch_bounds__(256) void map_pack_kernel(const float* __restrict__ map_x, const float* __restrict__ map_y,
-                                                       const uint8_t* __restrict__ valid, int64_t n, int nearest,
-                                                       uint32_t* __restrict__ packed, uint8_t* __restrict__ packed_hi) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float mx = map_x[i], my = map_y[i];
-    int ix, iy, fx = 0, fy = 0;
-    if (nearest) {
-        ix = sat_s16(cv_round(mx));
-        iy = sat_s16(cv_round(my));
-    } else {
-        const int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
-        fx = sx & 31; fy = sy & 31;
-        ix = sat_s16(sx >> 5);
-        iy = sat_s16(sy >> 5);
-    }
-    ix = min(max(ix, -8), kMapPlanMaxDim + 8) + 8;
-    iy = min(max(iy, -8), kMapPlanMaxDim + 8) + 8;
-    packed[i] = (uint32_t)ix | ((uint32_t)iy << 12) | ((uint32_t)fx << 24) | ((uint32_t)(fy & 7) << 29);
-    packed_hi[i] = (uint8_t)((fy >> 3) | ((!valid || valid[i]) ? 4 : 0));
-}
-
-template <int C>
-__device__ __forceinline__ void cv_sample_linear(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                                 float mx, float my, const uint8_t (&cval)[4], uint32_t (&out)[4]) {
-    // Straight-line formulation (single exit): taps are fetched from clamped, always-valid addresses and
-    // replaced by the border constant afterwards, exactly reproducing remapBilinear's BORDER_CONSTANT rule.
-    int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
-    int fx = sx & 31, fy = sy & 31;
-    int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
-    bool outside = ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0;
-    uint32_t a0 = 32 - fx, a1 = fx, b0 = 32 - fy, b1 = fy;
-    uint32_t w00 = a0 * b0, w01 = a1 * b0, w10 = a0 * b1, w11 = a1 * b1;
-    bool x0in = (unsigned)ix < (unsigned)W, x1in = (unsigned)(ix + 1) < (unsigned)W;
-    bool y0in = (unsigned)iy < (unsigned)H, y1in = (unsigned)(iy + 1) < (unsigned)H;
-    int xa = min(max(ix, 0), W - 1), xb = min(max(ix + 1, 0), W - 1);
-    int ya = min(max(iy, 0), H - 1), yb = min(max(iy + 1, 0), H - 1);
-    const uint8_t* ra = src + (int64_t)ya * stride;
-    const uint8_t* rb = src + (int64_t)yb * stride;
-    uint32_t s00[4], s01[4], s10[4], s11[4];
-    bool wide = false;
-    if constexpr (C == 3) wide = x0in && y0in && ix < W - 2 && y1in;  // 8-byte reads stay inside the buffer
-    if (wide) {
-        uint2 t0 = ld_u64(ra + 3 * xa), t1 = ld_u64(rb + 3 * xa);
-        s00[0] = byte_of(t0.x, 0); s00[1] = byte_of(t0.x, 1); s00[2] = byte_of(t0.x, 2);
-        s01[0] = byte_of(t0.x, 3); s01[1] = byte_of(t0.y, 0); s01[2] = byte_of(t0.y, 1);
-        s10[0] = byte_of(t1.x, 0); s10[1] = byte_of(t1.x, 1); s10[2] = byte_of(t1.x, 2);
-        s11[0] = byte_of(t1.x, 3); s11[1] = byte_of(t1.y, 0); s11[2] = byte_of(t1.y, 1);
-    } else {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            s00[c] = ra[xa * C + c]; s01[c] = ra[xb * C + c];
-            s10[c] = rb[xa * C + c]; s11[c] = rb[xb * C + c];
-        }
-    }
-    bool in00 = x0in && y0in, in01 = x1in && y0in, in10 = x0in && y1in, in11 = x1in && y1in;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        uint32_t cv = cval[c];
-        uint32_t v = blend(in00 ? s00[c] : cv, in01 ? s01[c] : cv, in10 ? s10[c] : cv, in11 ? s11[c] : cv,
-                           w00, w01, w10, w11);
-        out[c] = outside ? cv : v;
-    }
-}
-
-template <int C>
-__device__ __forceinline__ void cv_sample_nearest(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                                  float mx, float my, const uint8_t (&cval)[4], uint32_t (&out)[4]) {
-    int ix = sat_s16(cv_round(mx)), iy = sat_s16(cv_round(my));
-    bool inside = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
-    int xa = min(max(ix, 0), W - 1), ya = min(max(iy, 0), H - 1);
-    const uint8_t* s = src + (int64_t)ya * stride + (int64_t)xa * C;
-    if constexpr (C == 3) {
-        // one gather instead of three: the pixel's 3 bytes lie in the 8 bytes that start at its dword -- inside the row for every
-        // column but the last two, which keep the byte reads.  (Single exit: an early return here put the callers' pixel arrays
-        // into scratch memory, 81 us -> 2 ms per cfg4 pair; tests/test_capi_load.py now watches the compiler's report.)
-        uint32_t v;
-        if (xa <= W - 3) {
-            const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(s) & 3u;
-            const uint2 q = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(s - o, 4));
-            v = __builtin_amdgcn_alignbyte(q.y, q.x, o);
-        } else {
-            v = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
-        }
-        out[0] = inside ? (v & 0xffu) : (uint32_t)cval[0];
-        out[1] = inside ? ((v >> 8) & 0xffu) : (uint32_t)cval[1];
-        out[2] = inside ? ((v >> 16) & 0xffu) : (uint32_t)cval[2];
-    } else {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            uint32_t v = s[c];
-            out[c] = inside ? v : (uint32_t)cval[c];
-        }
-    }
-}
-
-// remapBicubic, BORDER_CONSTANT: 4x4 window at (ix-1, iy-1); int16 weights (sum 32768) from the 32x32-phase table;
-// taps outside the image are the border constant; (sum + 2^14) >> 15 saturated to u8.
-template <int C>
-__device__ __forceinline__ void cv_sample_cubic(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                                float mx, float my, const uint8_t (&cval)[4],
-                                                const int16_t* __restrict__ tab, uint32_t (&out)[4]) {
-    int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
-    int fx = sx & 31, fy = sy & 31;
-    int x0 = sat_s16(sx >> 5) - 1, y0 = sat_s16(sy >> 5) - 1;
-    bool outside = x0 >= W || x0 + 4 <= 0 || y0 >= H || y0 + 4 <= 0;
-    const uint4* wq = reinterpret_cast<const uint4*>(tab + (fy * 32 + fx) * 16);   // 32 B = two 16-B reads
-    uint4 wa = wq[0], wb = wq[1];
-    const uint32_t wpk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-    int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky) {
-        int yy = y0 + ky;
-        bool yin = (unsigned)yy < (unsigned)H;
-        const uint8_t* row = src + (int64_t)min(max(yy, 0), H - 1) * stride;
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            int xx = x0 + kx;
-            bool in = yin && ((unsigned)xx < (unsigned)W);
-            const uint8_t* px = row + (int64_t)min(max(xx, 0), W - 1) * C;
-            uint32_t pk = wpk[(ky * 4 + kx) >> 1];
-            int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] += (int)(in ? (uint32_t)px[c] : (uint32_t)cval[c]) * w;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int r = (acc[c] + (1 << 14)) >> 15;
-        out[c] = outside ? (uint32_t)cval[c] : (uint32_t)min(max(r, 0), 255);
-    }
-}
-
-// remapLanczos4, BORDER_CONSTANT: 8x8 window at (ix-3, iy-3), same fixed-point scheme as the bicubic sampler with the
-// 32x32-phase x 64-entry int16 table (128 B per phase, one 16-byte read per window row).  Rarely selected
-// (`--interpolation lanczos4`, DF:229-234), so it is the straight-line form only.
-template <int C>
-__device__ __forceinline__ void cv_sample_lanczos4(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                                   float mx, float my, const uint8_t (&cval)[4],
-                                                   const int16_t* __restrict__ tab, uint32_t (&out)[4]) {
-    int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
-    int fx = sx & 31, fy = sy & 31;
-    int x0 = sat_s16(sx >> 5) - 3, y0 = sat_s16(sy >> 5) - 3;
-    bool outside = x0 >= W || x0 + 8 <= 0 || y0 >= H || y0 + 8 <= 0;
-    const uint4* wq = reinterpret_cast<const uint4*>(tab + (fy * 32 + fx) * 64);
-    if constexpr (C == 3) {
-        // window inside the image (and its aligned 28-byte row reads inside the row): the 8 RGB taps of a window row are 24
-        // contiguous bytes -> seven dwords from the dword boundary below them, shifted into place; two taps x two packed
-        // int16 weights per v_dot2 (12 per row) instead of 24 byte loads and 24 multiply-adds per row.  Exact integers.
-        if (x0 >= 0 && y0 >= 0 && x0 + 10 <= W && y0 + 8 <= H && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0) {
-            int a3[3] = {0, 0, 0};
-#pragma unroll
-            for (int ky = 0; ky < 8; ++ky) {
-                const uint4 wr = wq[ky];
-                const uint32_t wpk[4] = {wr.x, wr.y, wr.z, wr.w};
-                const uint8_t* p = src + (int64_t)(y0 + ky) * stride + (int64_t)x0 * 3;
-                const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
-                uint32_t r[7], d[6];
-#pragma unroll
-                for (int t = 0; t < 7; ++t) r[t] = q[t];
-#pragma unroll
-                for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(r[t + 1], r[t], o);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int p0 = 6 * m + c, p1 = p0 + 3;            // bytes of taps 2m and 2m+1, channel c
-                        a3[c] = dot2_i16(__builtin_amdgcn_perm(d[p1 >> 2], d[p0 >> 2], GS360_PAIR(p0 & 3, 4 + (p1 & 3))), wpk[m], a3[c]);
-                    }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((a3[c] + (1 << 14)) >> 15, 0), 255);
-            return;
-        }
-    }
-    if (outside) {                                        // the whole window outside the image: the border value, no taps
-#pragma unroll
-        for (int c = 0; c < C; ++c) out[c] = (uint32_t)cval[c];
-        return;
-    }
-    int acc[4] = {0, 0, 0, 0};
-#pragma unroll 2
-    for (int ky = 0; ky < 8; ++ky) {
-        const uint4 wr = wq[ky];
-        const uint32_t wpk[4] = {wr.x, wr.y, wr.z, wr.w};
-        int yy = y0 + ky;
-        bool yin = (unsigned)yy < (unsigned)H;
-        const uint8_t* row = src + (int64_t)min(max(yy, 0), H - 1) * stride;
-#pragma unroll
-        for (int kx = 0; kx < 8; ++kx) {
-            int xx = x0 + kx;
-            bool in = yin && ((unsigned)xx < (unsigned)W);
-            const uint8_t* px = row + (int64_t)min(max(xx, 0), W - 1) * C;
-            uint32_t pk = wpk[kx >> 1];
-            int w = (int)(int16_t)((kx & 1) ? (pk >> 16) : (pk & 0xffffu));
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] += (int)(in ? (uint32_t)px[c] : (uint32_t)cval[c]) * w;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int r = (acc[c] + (1 << 14)) >> 15;
-        out[c] = outside ? (uint32_t)cval[c] : (uint32_t)min(max(r, 0), 255);
-    }
-}
-
-// cv2 Lanczos-4 for an RGB window inside the image with the 2-D weights REBUILT per pixel (TableLaunch::lz_c1 / lz_cen; `lds` = the
-// workgroup's copy: 256 floats of 1-D coefficients, then 2048 dwords of patched pairs).  OpenCV's table entry is
-// saturate_cast<short>(cvRound((cy * cx) * 2^15)): the float32 product cy * (cx * 2^15) is the same float (a power of two scales
-// exactly), and adding 1.5 * 2^23 rounds it to nearest-even into the low mantissa bits, whose low 16 are the int16 weight.  Only
-// the block the table's sum fix-up patches (rows 4-5, taps 4-5: shipped per phase) and phase 0's one saturated entry differ.
-// 128 B of a 128 KiB table per pixel through a 32 KiB L1 was what bounded this sampler, not its 64 taps.
-// Returns false (nothing written) when the window is not inside: the caller falls back to cv_sample_lanczos4.
-__device__ __forceinline__ bool cv_lanczos4_rgb_rebuilt(const uint8_t* __restrict__ src, int64_t stride, int W, int H, float mx, float my,
-                                                        const float* lds, uint32_t (&out)[4]) {
-    const int sx = cv_round(mx * 32.0f), sy = cv_round(my * 32.0f);
-    const int fx = sx & 31, fy = sy & 31;
-    const int x0 = sat_s16(sx >> 5) - 3, y0 = sat_s16(sy >> 5) - 3;
-    if (!(x0 >= 0 && y0 >= 0 && x0 + 10 <= W && y0 + 8 <= H && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0)) return false;
-    const float4* cyq = reinterpret_cast<const float4*>(lds + fy * 8);
-    const float4* cxq = reinterpret_cast<const float4*>(lds + fx * 8);
-    const float4 cya = cyq[0], cyb = cyq[1], cxa = cxq[0], cxb = cxq[1];
-    const float cy[8] = {cya.x, cya.y, cya.z, cya.w, cyb.x, cyb.y, cyb.z, cyb.w};
-    const float cx32[8] = {cxa.x * 32768.0f, cxa.y * 32768.0f, cxa.z * 32768.0f, cxa.w * 32768.0f,
-                           cxb.x * 32768.0f, cxb.y * 32768.0f, cxb.z * 32768.0f, cxb.w * 32768.0f};
-    const int phase = fy * 32 + fx;
-    const uint2 cen = reinterpret_cast<const uint2*>(lds + 256)[phase];
-    int a3[3] = {0, 0, 0};
-#pragma unroll 2
-    for (int ky = 0; ky < 8; ++ky) {
-        uint32_t wpk[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float t0 = cy[ky] * cx32[2 * m] + 12582912.0f;          // (contraction is off: product and sum round separately)
-            const float t1 = cy[ky] * cx32[2 * m + 1] + 12582912.0f;
-            wpk[m] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, t1), __builtin_bit_cast(uint32_t, t0), 0x05040100u);
-        }
-        if (ky == 3) wpk[1] = phase == 0 ? 0x7fff0000u : wpk[1];          // cy = cx = 1: 2^15 saturates to 32767 in the table
-        if (ky == 4) wpk[2] = cen.x;
-        if (ky == 5) wpk[2] = cen.y;
-        const uint8_t* p = src + (int64_t)(y0 + ky) * stride + (int64_t)x0 * 3;
-        const uint32_t o = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(p - o, 4));
-        uint32_t r[7], d[6];
-#pragma unroll
-        for (int t = 0; t < 7; ++t) r[t] = q[t];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) d[t] = __builtin_amdgcn_alignbyte(r[t + 1], r[t], o);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int p0 = 6 * m + c, p1 = p0 + 3;                    // bytes of taps 2m and 2m+1, channel c
-                a3[c] = dot2_i16(__builtin_amdgcn_perm(d[p1 >> 2], d[p0 >> 2], GS360_PAIR(p0 & 3, 4 + (p1 & 3))), wpk[m], a3[c]);
-            }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max((a3[c] + (1 << 14)) >> 15, 0), 255);
-    return true;
-}
-
-// Split bilinear fetch for cv2 semantics (same idea as eq_fetch): the two row reads are issued unconditionally from
-// a clamped, always-valid position so that a wavefront keeps all its gathers in flight; `fast` says the 2x2
-// footprint was fully inside the image and the wide read stayed in-row, otherwise the pixel is redone afterwards by
-// the straight-line border path (cv_sample_linear).  Needs W >= 8 and 32-bit tap offsets (checked on the host).
-template <int C>
-struct CvTaps {
-    uint2 t0, t1;
-    RowsRaw raw;    // C == 3: the loads in flight (cv_taps_finish)
-    int fx, fy;
-    bool fast;
-};
-
-// (sx, sy: the 1/32-pixel fixed point cv2.remap derives from the maps, cvRound(map * 32); a map plan holds them ready-made)
-template <int C>
-__device__ __forceinline__ CvTaps<C> cv_fetch_linear_fx(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                                        const int sx, const int sy) {
-    const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
-    constexpr int kBack = (C == 3) ? 5 : 2;
-    CvTaps<C> t;
-    t.fx = sx & 31;
-    t.fy = sy & 31;
-    t.fast = (uint32_t)ix <= (uint32_t)(W - kBack) && (uint32_t)iy < (uint32_t)(H - 1);       // both >= 0 and inside (W >= 8)
-    // a window that is not `fast` is redone by the border sampler: its reads only have to be readable -- the image's first bytes
-    const uint32_t o0 = t.fast ? __umul24((uint32_t)iy, (uint32_t)stride) + (uint32_t)ix * C : 0u;
-    const uint32_t o1 = o0 + (t.fast ? (uint32_t)stride : 0u);
-    const uint8_t* r0 = src + o0;
-    const uint8_t* r1 = src + o1;
-    if constexpr (C == 1) {
-        uint16_t a, b;
-        __builtin_memcpy(&a, r0, 2);
-        __builtin_memcpy(&b, r1, 2);
-        t.t0 = make_uint2(a, 0);
-        t.t1 = make_uint2(b, 0);
-    } else if constexpr (C == 3) {
-        t.raw = ld_rows_rgb_issue(src, o0, o1);
-    } else {
-        t.t0 = ld_u64(r0);
-        t.t1 = ld_u64(r1);
-    }
-    return t;
-}
-template <int C>
-__device__ __forceinline__ CvTaps<C> cv_fetch_linear(const uint8_t* __restrict__ src, int64_t stride, int W, int H, float mx, float my) {
-    return cv_fetch_linear_fx<C>(src, stride, W, H, cv_round(mx * 32.0f), cv_round(my * 32.0f));
-}
-
-template <int C>
-__device__ __forceinline__ void cv_blend_fast(CvTaps<C>& t, uint32_t (&out)[4]) {
-    if constexpr (C == 3) ld_rows_rgb_finish(t.raw, t.t0, t.t1);
-    EqTaps<C> e;
-    e.t0 = t.t0;
-    e.t1 = t.t1;
-    e.fix = false;
-    eq_blend<C>(e, t.fx, t.fy, out);     // same 1/32-px weights: only the fractional bits of sx, sy are used
-}
-
-// cv2 bicubic for the wavefront's four row slots of an RGB image.  Windows that lie inside the image take the
-// equirect kernel's path (four dword-aligned 16-byte row reads + the 32-byte weight entry issued together, dot-product
-// blend); the others are redone by the straight-line border sampler.  Needs W >= 8 and 32-bit tap offsets (`pipelined`).
-__device__ __forceinline__ void cv_cubic_slots_rgb(const uint8_t* __restrict__ src, int64_t stride, int W, int H,
-                                                   const float (&mxs)[kRowsPerWave], const float (&mys)[kRowsPerWave],
-                                                   const uint8_t (&cval)[4], const int16_t* __restrict__ tab,
-                                                   const int16_t* tab_lds, uint32_t (&px)[kRowsPerWave][4]) {
-    // tab_lds: the workgroup's LDS copy of the table for the fast path (every lane reads another 32-byte entry: left in global
-    // memory the 32 KiB table competes with the source lines for the 32 KiB vector L1 and costs two more gathers per pixel)
-    static_assert(kRowsPerWave == 4, "four row slots");
-    const bool stride4 = uniform_here((int)(stride & 3)) == 0;
-    bool fast[4];
-#pragma unroll
-    for (int s0 = 0; s0 < 4; s0 += 2) {                   // two slots at a time: 8 row reads in flight, 24 tap dwords live
-        EqCubicTaps t[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int sx = cv_round(mxs[s0 + u] * 32.0f), sy = cv_round(mys[s0 + u] * 32.0f);
-            const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
-            fast[s0 + u] = ix >= 1 && iy >= 1 && ix <= W - 5 && iy <= H - 3;
-            t[u] = cubic_issue_rgb(src, (uint32_t)stride, stride4, W, H, ix, iy, sx & 31, sy & 31);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        eq_cubic_blend(t[0], tab_lds, stride4, px[s0]);
-        eq_cubic_blend(t[1], tab_lds, stride4, px[s0 + 1]);
-    }
-    if (any_lane(!(fast[0] && fast[1] && fast[2] && fast[3]))) {
-        // border windows: ONE copy of the straight-line sampler in a rolled loop, so that its 48 byte loads do not set the
-        // register budget of the path above.  The loop always works on slot 0 and ROTATES the four slots after every turn (plain
-        // register moves, back in place after four turns): picking the slot with `rr == k ? a[k] : ...` made the compiler keep the
-        // coordinate arrays in scratch memory and store them there on the hot path of every tile (+4 B/px of writes, measured as
-        // WRITE_SIZE 54 -> 108 MB per cfg4 launch).
-        float x0 = mxs[0], x1 = mxs[1], x2 = mxs[2], x3 = mxs[3], y0 = mys[0], y1 = mys[1], y2 = mys[2], y3 = mys[3];
-        bool f0 = fast[0], f1 = fast[1], f2 = fast[2], f3 = fast[3];
-        uint32_t p0[3] = {px[0][0], px[0][1], px[0][2]}, p1[3] = {px[1][0], px[1][1], px[1][2]},
-                 p2[3] = {px[2][0], px[2][1], px[2][2]}, p3[3] = {px[3][0], px[3][1], px[3][2]};
-#pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-            if (!f0) {
-                uint32_t o[4];
-                cv_sample_cubic<3>(src, stride, W, H, x0, y0, cval, tab, o);
-                p0[0] = o[0]; p0[1] = o[1]; p0[2] = o[2];
-            }
-            const float tx = x0, ty = y0;
-            const bool tf = f0;
-            x0 = x1; x1 = x2; x2 = x3; x3 = tx;
-            y0 = y1; y1 = y2; y2 = y3; y3 = ty;
-            f0 = f1; f1 = f2; f2 = f3; f3 = tf;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint32_t t = p0[c];
-                p0[c] = p1[c]; p1[c] = p2[c]; p2[c] = p3[c]; p3[c] = t;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { px[0][c] = p0[c]; px[1][c] = p1[c]; px[2][c] = p2[c]; px[3][c] = p3[c]; }
-    }
-}
-
-// One instantiation per interpolation: the 8x8 Lanczos window would otherwise set the register budget (and with it the
-// occupancy) of the bilinear path.
-template <int C, int INTERP>
-__device__ __forceinline__ void table_remap_tile(const TableBatch& B, const int b, const int16_t* s_wtab) {
-    int t = (b & 7) * B.chunk + (b >> 3);
-    if (t >= B.total_tiles) return;
-    int j = 0;
-    while (j + 1 < B.n_jobs && t >= B.job[j + 1].tile_base) ++j;
-    const TableLaunch& L = B.job[j];          // wave-uniform: fields are read from the kernel argument on demand
-    t -= L.tile_base;
-    const int tiles_x = L.tiles_x;
-    int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
-    // (behind an optimisation barrier: in the persistent variant the lane-derived constants would otherwise be hoisted out of the
-    // tile loop and cost the kernel its fourth wavefront per SIMD)
-    const int lane = lane_here(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const RowPack rp = make_row_pack(lane);
-    const int x0 = tile_x * kTileW;
-    const int n_px = min(kTileW, L.w - x0);
-    const int xc = min(x0 + lane, L.w - 1);
-    // (rows off a dword boundary take the byte stores here -- store_row<C, false>: the re-sliced dword path that pays in the equirect
-    // kernels costs these kernels 12-15 %, cfg4 through plans 51 -> 59 us per pair)
-    const bool aligned4 = ((L.dst_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(L.dst) & 3) == 0);
-    // FLAT form (L.flat, set on the host for a tight, dword-aligned output whose rows are not whole dwords -- the tool's default 1750-pixel
-    // views have 5250-byte rows, and a row that starts off a dword boundary leaves as three byte stores per pixel).  The output is
-    // then addressed by the flat pixel number p = y w + x, as the maps, valid flags and plans are anyway, and "row y" becomes the span
-    // [r(y), r(y + 1)) with r(y) = y w rounded up to a multiple of four (r(h) = h w): up to three pixels at the start of a row belong
-    // to the span above.  Every span, and every 64-pixel tile cut from it, starts on a 12-byte = dword boundary of the tight output
-    // whatever the width; a span is at most w + 3 pixels long (the host adds that to the tile count).  h w < 2^30: 32-bit indices.
-    const bool flat = uniform_here(L.flat) != 0;
-    const int n_flat = uniform_here(L.h * L.w);
-    auto slot_span = [&](const int y, int& first, int& n) {           // first flat pixel of lane 0 and the pixels to store, for row slot y
-        const int yc = min(y, L.h - 1);
-        const int r0 = (yc * L.w + 3) & ~3;
-        const int r1 = yc + 1 < L.h ? ((yc + 1) * L.w + 3) & ~3 : n_flat;
-        first = r0 + x0;
-        n = y < L.h ? max(0, min(kTileW, r1 - first)) : 0;
-    };
-    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    if ((INTERP == GS360_INTERP_LINEAR || INTERP == GS360_INTERP_NEAREST || kFastCubic) && L.pipelined) {
-        // maps of the wavefront's 4 rows -> all gathers in flight -> blend -> border/valid fix-ups -> packed stores
-        const int ybase = tile_y * kTileH + wave * kRowsPerWave;
-        float mxs[kRowsPerWave], mys[kRowsPerWave];
-        bool inval[kRowsPerWave];
-        // the twelve map / valid reads of the four row slots go out together: behind a run-time `if (L.valid)` the compiler waits
-        // for each valid byte (and with it for the slot's map reads) before it issues the next slot's -- four serial round trips
-        // per tile.  Without a valid map the byte is read from the map itself (h * w readable bytes) and ignored.
-        const uint8_t* __restrict__ vptr = L.valid ? L.valid : reinterpret_cast<const uint8_t*>(L.map_x);
-        const bool has_valid = L.valid != nullptr;
-        uint8_t vbyte[kRowsPerWave];
-        int sxi[kRowsPerWave] = {0, 0, 0, 0}, syi[kRowsPerWave] = {0, 0, 0, 0};   // bilinear: the positions in 1/32-pixel fixed point
-        int first[kRowsPerWave], n_st[kRowsPerWave];      // flat form: the slot's first pixel and its pixel count (wave-uniform)
-        uint32_t idx[kRowsPerWave];                       // this lane's map entry (clamped to a readable one)
-#pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) {
-            if (flat) {
-                slot_span(ybase + rr, first[rr], n_st[rr]);
-                idx[rr] = (uint32_t)min(first[rr] + lane, n_flat - 1);
-            } else {
-                first[rr] = 0;
-                n_st[rr] = 0;
-                idx[rr] = (uint32_t)(min(ybase + rr, L.h - 1) * L.w + xc);
-            }
-        }
-        if (L.packed) {                       // a map plan (wave-uniform): one dword and one byte per pixel
-            uint32_t pw[kRowsPerWave];
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                const uint32_t o = idx[rr];
-                pw[rr] = L.packed[o];
-                vbyte[rr] = L.packed_hi[o];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                planned_coords(pw[rr], vbyte[rr], INTERP == GS360_INTERP_NEAREST, mxs[rr], mys[rr]);
-                inval[rr] = (L.use_valid != 0) & ((vbyte[rr] & 4) == 0);
-                // the bilinear fetch takes the fixed point as it is packed (the floats are for the border / bicubic paths)
-                sxi[rr] = ((int)(pw[rr] & 0xfffu) - 8) * 32 + (int)((pw[rr] >> 24) & 31u);
-                syi[rr] = ((int)((pw[rr] >> 12) & 0xfffu) - 8) * 32 + (int)((pw[rr] >> 29) | ((vbyte[rr] & 3u) << 3));
-            }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                const uint32_t o = idx[rr];
-                mxs[rr] = L.map_x[o];         // (non-temporal map loads were measured: no difference)
-                mys[rr] = L.map_y[o];
-                vbyte[rr] = vptr[o];
-            }
-            __builtin_amdgcn_sched_barrier(0);    // all twelve in flight before anything else is scheduled
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                inval[rr] = has_valid & (vbyte[rr] == 0);
-                if constexpr (INTERP == GS360_INTERP_LINEAR) {
-                    sxi[rr] = cv_round(mxs[rr] * 32.0f);
-                    syi[rr] = cv_round(mys[rr] * 32.0f);
-                }
-            }
-        }
-        uint32_t px[kRowsPerWave][4];
-        if constexpr (kFastCubic) {
-            cv_cubic_slots_rgb(L.src, L.src_stride, L.W, L.H, mxs, mys, L.cval, L.cubic_tab, s_wtab, px);
-        } else if constexpr (INTERP == GS360_INTERP_NEAREST) {   // mask cutting (DF:2031-2043): the 4 slots' reads in flight together
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
-        } else {
-            CvTaps<C> taps[kRowsPerWave];
-            bool any_slow = false;
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) {
-                taps[rr] = cv_fetch_linear_fx<C>(L.src, L.src_stride, L.W, L.H, sxi[rr], syi[rr]);
-                any_slow |= !taps[rr].fast;
-            }
-            __builtin_amdgcn_sched_barrier(0);    // every gather of the wavefront's four rows in flight before the first is consumed
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
-            if (any_lane(any_slow)) {
-#pragma unroll
-                for (int rr = 0; rr < kRowsPerWave; ++rr)
-                    if (!taps[rr].fast) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mxs[rr], mys[rr], L.cval, px[rr]);
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) {
-            if (inval[rr]) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.fill;
-            }
-            const int y = ybase + rr;
-            if (flat) {
-                if (n_st[rr] > 0) store_row<C>(L.dst + (size_t)(uint32_t)(first[rr] * C), px[rr], n_st[rr], true, rp);
-            } else if (y < L.h) {
-                store_row<C, false>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
-            }
-        }
-        return;
-    }
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = tile_y * kTileH + wave * kRowsPerWave + rr;
-        if (y >= L.h) break;
-        int first = 0, n_st = 0;
-        if (flat) {
-            slot_span(y, first, n_st);
-            if (n_st == 0) continue;
-        }
-        int64_t o = flat ? (int64_t)min(first + lane, n_flat - 1) : (int64_t)y * L.w + xc;
-        float mx, my;
-        bool inval;
-        if (L.packed) {
-            const uint32_t hb = L.packed_hi[o];
-            planned_coords(L.packed[o], hb, INTERP == GS360_INTERP_NEAREST, mx, my);
-            inval = L.use_valid && !(hb & 4);
-        } else {
-            mx = L.map_x[o]; my = L.map_y[o];        // 256 B per wavefront row, coalesced
-            inval = L.valid && !L.valid[o];
-        }
-        uint32_t px[4];
-        if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
-        else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
-        else if constexpr (INTERP == GS360_INTERP_LANCZOS4) {
-            // 64 taps: pixels the valid map rules out are not sampled at all.  (The same test in front of the cheaper samplers
-            // made the compiler index the RGBA bicubic accumulators through scratch memory.)
-            if (!inval) {
-                bool done = false;
-                if constexpr (C == 3) {
-                    if (L.lz_c1) done = cv_lanczos4_rgb_rebuilt(L.src, L.src_stride, L.W, L.H, mx, my, reinterpret_cast<const float*>(s_wtab), px);
-                }
-                if (!done) cv_sample_lanczos4<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, L.cubic_tab, px);
-            }
-        } else cv_sample_nearest<C>(L.src, L.src_stride, L.W, L.H, mx, my, L.cval, px);
-        if (inval) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) px[c] = (uint32_t)L.fill;
-        }
-        if (flat) store_row<C>(L.dst + (size_t)(uint32_t)(first * C), px, n_st, true, rp);
-        else store_row<C, false>(L.dst + (int64_t)y * L.dst_stride + (int64_t)x0 * C, px, n_px, aligned4, rp);
-    }
-}
-
-// Bicubic RGB keeps a 32 KiB LDS copy of the weight table: filled once per workgroup, so its workgroups are PERSISTENT (the
-// launcher caps the grid at a few workgroups per CU and each walks tiles b, b + gridDim.x, ... -- the stride is a multiple of 8,
-// so a workgroup stays inside its XCD's chunk of tiles).  One 64 x 16 tile per workgroup meant 32 bytes of table fill per
-// output pixel: as many bytes as the pixel's own weight entry, eight more 1 KiB loads per wavefront next to its sixteen row
-// gathers, and a load -> LDS -> barrier bubble in front of every tile.
-template <int C, int INTERP>
-__global__ __launch_bounds__(64 * kWaves) void table_remap_kernel(const TableBatch B) {
-    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    constexpr bool kLanczosRgb = (INTERP == GS360_INTERP_LANCZOS4) && (C == 3);   // 256 floats + 2048 dwords (cv_lanczos4_rgb_rebuilt)
-    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : (kLanczosRgb ? (256 + 2048) * 2 : 8)];
-    if constexpr (kFastCubic) {
-        if (B.job[0].cubic_tab) {             // (the context's table: the same pointer in every job)
-            cubic_lds_fill(s_wtab, B.job[0].cubic_tab, 64 * kWaves);
-            __syncthreads();
-        }
-#pragma unroll 1
-        for (int b = blockIdx.x; b < B.chunk * 8; b += gridDim.x) table_remap_tile<C, INTERP>(B, b, s_wtab);
-    } else if constexpr (kLanczosRgb) {
-        if (B.job[0].lz_c1) {                 // (wave-uniform; the context's tables, the same in every job)
-            uint32_t* l = reinterpret_cast<uint32_t*>(s_wtab);
-            l[threadIdx.x] = reinterpret_cast<const uint32_t*>(B.job[0].lz_c1)[threadIdx.x];
-#pragma unroll
-            for (int i = 0; i < 2048 / (64 * kWaves); ++i) l[256 + i * 64 * kWaves + threadIdx.x] = B.job[0].lz_cen[i * 64 * kWaves + threadIdx.x];
-            __syncthreads();
-        }
-#pragma unroll 1
-        for (int b = blockIdx.x; b < B.chunk * 8; b += gridDim.x) table_remap_tile<C, INTERP>(B, b, s_wtab);
-    } else {
-        table_remap_tile<C, INTERP>(B, blockIdx.x, s_wtab);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// FE-SPEC v1: fused fisheye -> perspective
-// ------------------------------------------------------------------------------------------------
-// All views of a call in one launch.  The view block is used through a REFERENCE into the by-value kernel argument
-// (scalar loads on demand): copying a dynamically indexed 148-byte block into a local made the compiler spill the whole
-// argument array to scratch (2368 B/lane, 13x slower).
-template <int C, int INTERP>
-__device__ __forceinline__ void fe_views_tile(const FeBatch& B, const int b, const int16_t* s_wtab) {
-    const FeCommon& L = B.common;
-    int t = (b & 7) * L.chunk + (b >> 3);
-    if (t >= L.total_tiles) return;
-    int j = 0;
-    while (j + 1 < L.n_views && t >= B.view[j + 1].tile_base) ++j;
-    const FeView& V = B.view[j];              // a reference: fields are fetched from the kernel argument on demand
-    t -= V.tile_base;
-    int tile_y = t / V.tiles_x, tile_x = t - tile_y * V.tiles_x;
-    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    // (persistent variant: lane-derived constants stay inside the tile, see table_remap_tile)
-    const int lane = kFastCubic ? lane_here() : (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = tile_x * kTileW;
-    const int n_px = min(kTileW, V.out_w - x0);
-    const int xc = min(x0 + lane, V.out_w - 1);
-    const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * C;
-    const bool aligned4 = ((dstride & 3) == 0) && ((reinterpret_cast<uintptr_t>(V.dst) & 3) == 0);
-    const RowPack rp = make_row_pack(lane);
-    const float x = (float)(2 * xc + 1 - V.out_w) * V.sxu;
-
-    const int ybase = tile_y * kTileH + wave * kRowsPerWave;
-    const bool pipelined = (INTERP == GS360_INTERP_LINEAR) && L.pipelined;
-    float mxs[kRowsPerWave], mys[kRowsPerWave];
-    bool oks[kRowsPerWave];
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = min(ybase + rr, V.out_h - 1);
-        float yv = (float)(2 * y + 1 - V.out_h) * V.syv;       // ray y = -yv
-        float Y = __builtin_fmaf(-V.cp, yv, V.sp);
-        float z1 = __builtin_fmaf(V.sp, yv, V.cp);
-        float X = __builtin_fmaf(V.cy, x, V.sy * z1);
-        float Z = __builtin_fmaf(-V.sy, x, V.cy * z1);
-        // N >= 1; d = N (N + Z) is 0 or >= ~1e-7 and <= ~1e7, so 2 / d and both square roots stay far from the denormal /
-        // overflow ranges in which the generic IEEE expansions differ from the reduced ones (gs360_eqspec.h)
-        float N = eq_sqrt_normal(__builtin_fmaf(x, x, __builtin_fmaf(yv, yv, 1.0f)));
-        float d = N * (N + Z);
-        float s = d > 0.0f ? eq_sqrt_normal(eq_div(2.0f, d)) : 0.0f;
-        float xn = X * s, yn = -(Y * s);
-        float r2 = __builtin_fmaf(xn, xn, yn * yn);
-        float r4 = r2 * r2;
-        float radial = __builtin_fmaf(V.k4, r4 * r4, __builtin_fmaf(V.k3, r4 * r2,
-                       __builtin_fmaf(V.k2, r4, __builtin_fmaf(V.k1, r2, 1.0f))));
-        float xd = xn * radial, yd = yn * radial;
-        if (V.tang) {
-            float xy = xn * yn;
-            xd = __builtin_fmaf(V.tp2, xy, __builtin_fmaf(V.p1, __builtin_fmaf(2.0f * xn, xn, r2), xd));
-            yd = __builtin_fmaf(V.tp1, xy, __builtin_fmaf(V.p2, __builtin_fmaf(2.0f * yn, yn, r2), yd));
-        }
-        float mx = __builtin_fmaf(yd, V.b2, __builtin_fmaf(xd, V.b1, __builtin_fmaf(xd, V.f, V.cx0)));
-        float my = __builtin_fmaf(yd, V.f, V.cy0);
-        mxs[rr] = mx;
-        mys[rr] = my;
-        // bitwise: short-circuit && turned into nested exec-mask branches with scalar loads inside each of the four slots
-        oks[rr] = (Z >= V.cos_tmax * N) & (mx >= 0.0f) & (mx <= V.wmax) & (my >= 0.0f) & (my <= V.hmax);
-    }
-    uint32_t px[kRowsPerWave][4];
-    if ((INTERP == GS360_INTERP_CUBIC) && (C == 3) && L.pipelined) {
-        if constexpr (C == 3) cv_cubic_slots_rgb(V.src, L.src_stride, V.W, V.H, mxs, mys, L.cval, L.cubic_tab, s_wtab, px);
-    } else if (pipelined) {
-        CvTaps<C> taps[kRowsPerWave];
-        bool any_slow = false;
-#pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) {
-            taps[rr] = cv_fetch_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr]);
-            any_slow |= !taps[rr].fast;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rr = 0; rr < kRowsPerWave; ++rr) cv_blend_fast<C>(taps[rr], px[rr]);
-        if (any_lane(any_slow)) {
-#pragma unroll
-            for (int rr = 0; rr < kRowsPerWave; ++rr)
-                if (!taps[rr].fast) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mxs[rr], mys[rr], L.cval, px[rr]);
-        }
-    } else {
-        // one copy of the straight-line sampler in a rolled loop; the slot is picked with wave-uniform selects so that the
-        // coordinate / pixel arrays stay in registers
-        static_assert(kRowsPerWave == 4, "four row slots");
-#pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-            const float mx = rr == 0 ? mxs[0] : rr == 1 ? mxs[1] : rr == 2 ? mxs[2] : mxs[3];
-            const float my = rr == 0 ? mys[0] : rr == 1 ? mys[1] : rr == 2 ? mys[2] : mys[3];
-            uint32_t o[4];
-            if constexpr (INTERP == GS360_INTERP_LINEAR) cv_sample_linear<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, o);
-            else if constexpr (INTERP == GS360_INTERP_CUBIC) cv_sample_cubic<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, L.cubic_tab, o);
-            else if constexpr (INTERP == GS360_INTERP_LANCZOS4) cv_sample_lanczos4<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, L.cubic_tab, o);
-            else cv_sample_nearest<C>(V.src, L.src_stride, V.W, V.H, mx, my, L.cval, o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (rr == k) px[k][c] = o[c];
-        }
-    }
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int y = ybase + rr;
-        if (y >= V.out_h) break;
-        if (!oks[rr] && L.mask_outside) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) px[rr][c] = (uint32_t)L.mask_value;
-        }
-        store_row<C, false>(V.dst + (int64_t)y * dstride + (int64_t)x0 * C, px[rr], n_px, aligned4, rp);
-        if (V.valid_out && lane < n_px) V.valid_out[(int64_t)y * V.out_w + x0 + lane] = oks[rr] ? 1 : 0;
-    }
-}
-
-// (bicubic RGB: persistent workgroups around one LDS weight-table fill, as in table_remap_kernel)
-template <int C, int INTERP>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((INTERP == GS360_INTERP_CUBIC && C == 3) ? 4 : 1, 8)))
-void fe_views_kernel(const FeBatch B) {
-    constexpr bool kFastCubic = (INTERP == GS360_INTERP_CUBIC) && (C == 3);
-    __shared__ __attribute__((aligned(16))) int16_t s_wtab[kFastCubic ? 32 * 32 * 16 : 8];
-    if constexpr (kFastCubic) {
-        if (B.common.pipelined) {
-            cubic_lds_fill(s_wtab, B.common.cubic_tab, 64 * kWaves);
-            __syncthreads();
-        }
-#pragma unroll 1
-        for (int b = blockIdx.x; b < B.common.grid_total; b += gridDim.x) fe_views_tile<C, INTERP>(B, b, s_wtab);
-    } else {
-        fe_views_tile<C, INTERP>(B, blockIdx.x, s_wtab);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 // Keep-mask threshold + pack: bit x of row y = (mask[y][x] >= 128), i.e. the byte's top bit; bit W repeats bit 0 and row H repeats
@@ -2712,101 +1649,6 @@ hipError_t launch_equirect_u16(const EqLaunch& L0, int C, bool cubic, hipStream_
             case 4: hipLaunchKernelGGL((eq_views_kernel<4, false, false, 2>), grid, block, 0, s, L); break;
             default: return hipErrorInvalidValue;
         }
-    }
-    return hipGetLastError();
-}
-
-namespace {
-
-template <int C>
-void launch_table_c(const TableBatch& B, dim3 grid, dim3 block, hipStream_t s) {
-    switch (B.job[0].interp) {
-        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, B); break;
-        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, B); break;
-        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, B); break;
-        default: hipLaunchKernelGGL((table_remap_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, B); break;
-    }
-}
-
-template <int C>
-void launch_fisheye_c(const FeBatch& B, dim3 grid, dim3 block, hipStream_t s) {
-    switch (B.common.interp) {
-        case GS360_INTERP_LINEAR: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LINEAR>), grid, block, 0, s, B); break;
-        case GS360_INTERP_CUBIC: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_CUBIC>), grid, block, 0, s, B); break;
-        case GS360_INTERP_LANCZOS4: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_LANCZOS4>), grid, block, 0, s, B); break;
-        default: hipLaunchKernelGGL((fe_views_kernel<C, GS360_INTERP_NEAREST>), grid, block, 0, s, B); break;
-    }
-}
-
-}  // namespace
-
-hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s) {
-    int base = 0;
-    for (int j = 0; j < B.n_jobs; ++j) {
-        TableLaunch& L = B.job[j];
-        L.tiles_x = (L.w + (L.flat ? 3 : 0) + kTileW - 1) / kTileW;      // (flat form: a row's span may be three pixels longer)
-        L.tile_base = base;
-        base += L.tiles_x * ((L.h + kTileH - 1) / kTileH);
-    }
-    B.total_tiles = base;
-    B.chunk = (base + 7) / 8;
-    if (base == 0) return hipSuccess;
-    dim3 grid((unsigned)(B.chunk * 8)), block(64 * kWaves);
-    // persistent workgroups for the kernel with a per-workgroup LDS table (see table_remap_kernel)
-    if (C == 3 && (B.job[0].interp == GS360_INTERP_CUBIC || B.job[0].interp == GS360_INTERP_LANCZOS4) && B.persist_blocks > 0 &&
-        (unsigned)B.persist_blocks < grid.x)
-        grid.x = (unsigned)(B.persist_blocks + 7) & ~7u;
-    switch (C) {
-        case 1: launch_table_c<1>(B, grid, block, s); break;
-        case 3: launch_table_c<3>(B, grid, block, s); break;
-        case 4: launch_table_c<4>(B, grid, block, s); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_map_pack(const float* map_x, const float* map_y, const uint8_t* valid, int64_t n, int nearest,
-                           uint32_t* packed, uint8_t* packed_hi, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(map_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, map_x, map_y, valid, n, nearest, packed, packed_hi);
-    return hipGetLastError();
-}
-
-hipError_t launch_table(const TableLaunch& L, int C, hipStream_t s) {
-    TableBatch B;
-    B.job[0] = L;
-    B.n_jobs = 1;
-    B.persist_blocks = 0;
-    return launch_table_batch(B, C, s);
-}
-
-hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s) {
-    FeBatch B;
-    int base = 0;
-    for (int k = 0; k < L.n_views; ++k) {
-        B.view[k] = L.view[k];
-        B.view[k].tile_base = base;
-        base += L.view[k].tiles_x * L.view[k].tiles_y;
-    }
-    FeCommon& K = B.common;
-    K.n_views = L.n_views;
-    K.total_tiles = base;
-    K.chunk = (base + 7) / 8;
-    K.interp = L.interp; K.mask_outside = L.mask_outside; K.mask_value = L.mask_value;
-    K.src_stride = L.src_stride; K.dst_stride = L.dst_stride;
-    for (int i = 0; i < 4; ++i) K.cval[i] = L.cval[i];
-    K.cubic_tab = L.cubic_tab;
-    K.pipelined = L.pipelined;
-    if (base == 0) return hipSuccess;
-    dim3 grid((unsigned)(K.chunk * 8)), block(64 * kWaves);
-    K.grid_total = (int32_t)grid.x;
-    if (C == 3 && L.interp == GS360_INTERP_CUBIC && L.persist_blocks > 0 && (unsigned)L.persist_blocks < grid.x)
-        grid.x = (unsigned)(L.persist_blocks + 7) & ~7u;
-    switch (C) {
-        case 1: launch_fisheye_c<1>(B, grid, block, s); break;
-        case 3: launch_fisheye_c<3>(B, grid, block, s); break;
-        case 4: launch_fisheye_c<4>(B, grid, block, s); break;
-        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
