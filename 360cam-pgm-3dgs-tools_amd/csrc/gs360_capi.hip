@@ -683,17 +683,24 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         ev[k].flip = 0;
         if (esize == 2) ev[k].blocked = 0;   // 16-bit samples: row-per-slot lane map only
     }
-    // Source-major kernel (gs360_srcmajor.hip): a call that is ONE level yaw ring filling its circle (`--count N`, PC:794) at strong
-    // minification -- the shape where neighbouring views share half their source lines -- streams every source tile once for all views
-    // instead of gathering per view (cfg2: 18.7 -> ~14.5 us per frame).  Taken when the gather kernels would use the blocked lane map
-    // (>= 3 texels per pixel); option "srcmajor": 0 never, 1 whenever the geometry fits (tests, probes).  Decided before the ring grouping
-    // below (which keeps blocked views apart); a geometry that does not fit the plan format falls through to the gather kernels.
+    // Source-major kernel (gs360_srcmajor.hip): a call that is ONE level yaw ring filling its circle (`--count N`, PC:794; the `default`
+    // preset) streams every source tile once for all views instead of gathering per view.  Where it wins (profiles/r05/srcmajor_ring_sweep.txt,
+    // 8K sources, N views, s source texels per output pixel): N >= 6 at every s measured (1.5 .. 4.6: -8 % .. -39 %; cfg2 19.3 -> 15.2 us per
+    // frame, cfg1 40.3 -> 35.9), N = 5 from s = 2.25, N = 4 never (neighbours overlap by a quarter of their field only: +14 .. +44 %), and
+    // only when the call carries at least two frames (a single frame is too few workgroups for its two-deep pipeline: +7 .. +11 %).  Option
+    // "srcmajor": 0 never, 1 whenever the geometry fits (tests, probes).  Decided before the ring grouping below (which keeps blocked views
+    // apart); a geometry that does not fit the plan format falls through to the gather kernels.
     if (opt_srcmajor != 0 && !mask_frames && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 &&
         n_views <= GS360_MAX_VIEWS) {
         bool ring = ev[0].level != 0;
+        if (ring && opt_srcmajor < 0) {
+            const double hf = clampd(views[0].hfov_deg, 1e-3, 179.9) * kPi / 180.0;
+            const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[0].width;
+            ring = n_frames >= 2 && n_views >= 5 && step >= (n_views >= 6 ? 1.5 : 2.25);
+        }
         for (int k = 0; k < n_views && ring; ++k)
             ring = ev[k].sxu == ev[0].sxu && ev[k].syv == ev[0].syv && ev[k].sp == ev[0].sp && ev[k].cp == ev[0].cp && ev[k].x0f32 == ev[0].x0f32 &&
-                   ev[k].out_w == ev[0].out_w && ev[k].out_h == ev[0].out_h && ev[k].level && (opt_srcmajor == 1 || ev[k].blocked == 1);
+                   ev[k].out_w == ev[0].out_w && ev[k].out_h == ev[0].out_h && ev[k].level;
         std::vector<EqLaunch> Ls;
         for (int f0 = 0; f0 < n_frames && ring; f0 += GS360_MAX_FRAMES) {
             const int nf = n_frames - f0 < GS360_MAX_FRAMES ? n_frames - f0 : GS360_MAX_FRAMES;

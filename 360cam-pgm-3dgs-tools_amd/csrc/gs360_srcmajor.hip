@@ -145,32 +145,46 @@ __global__ __launch_bounds__(64 * (kSmConsumers + 1)) void eq_srcmajor_kernel(co
             // Consumers: a pixel per lane (neighbouring lanes' tap windows are 14 bytes apart: a quad per lane would scatter them 55 bytes
             // apart, 4-way bank conflicts), no memory reads at all -- plan entries and taps come from LDS -- so nothing in this loop ever
             // waits for the memory queue the copies sit in; the only memory instruction is the store.
+            // The loop is vector-ALU-bound for weakly minified rings (cfg1: 20 M pixels per frame), so it does per pixel only what differs
+            // per pixel: the entry addresses are running pointers; a wavefront turn (16 quads) never mixes views (the plan pads view groups),
+            // so the destination base is one scalar pair and the store takes the SGPR-base + 32-bit-offset form; row and column offsets are
+            // two 24-bit multiply-adds with the image's flip folded into the scalars; the tap rows' LDS addresses differ by the scalar pitch
+            // and v_alignbyte reads only the low two bits of its shift operand (the plan word itself serves for both rows).
             const bool flip = (g0 + g) & 1;
-            const int jbase = flip ? P.h - 1 : 0, jsgn = flip ? -1 : 1;
-            for (int i0 = (wave - 1) * 64; i0 < npx; i0 += 64 * kSmConsumers) {
-                const uint32_t pw = e_px[i0 + lane];
-                const uint32_t hd = e_hdr[(i0 + lane) >> 2];
-                const uint32_t o0 = pw & 0x1ffffu, o1 = o0 + (uint32_t)pitch;
+            const int row_step = flip ? -dstride : dstride;                                  // |.| < 2^22 (checked by the host)
+            const int lane_off = (flip ? (P.h - 1) * dstride : 0) + 4 * min(k4, 2);           // flipped image: rows run upwards from h - 1
+            int cur_vrel = -1;
+            uint64_t dbase = 0;
+            const uint8_t* pxp = reinterpret_cast<const uint8_t*>(e_px) + ((wave - 1) * 64 + lane) * 4;
+            const uint8_t* hdp = reinterpret_cast<const uint8_t*>(e_hdr) + (((wave - 1) * 64 + lane) >> 2) * 4;
+            for (int i0 = (wave - 1) * 64; i0 < npx; i0 += 64 * kSmConsumers, pxp += 256 * kSmConsumers, hdp += 64 * kSmConsumers) {
+                const uint32_t pw = *reinterpret_cast<const uint32_t*>(pxp);
+                const uint32_t hd = *reinterpret_cast<const uint32_t*>(hdp);
                 const int fx = (pw >> 17) & 31, fy = (pw >> 22) & 31;
-                const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (o0 & ~3u));
-                const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (o1 & ~3u));
+                const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (pw & 0x1fffcu));
+                const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (pw & 0x1fffcu) + pitch);
                 const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
                 uint2 t0, t1;                            // rows iy, iy + 1: bytes r0 g0 b0 r1 | g1 b1 . .
-                t0.x = __builtin_amdgcn_alignbyte(a1, a0, o0); t0.y = __builtin_amdgcn_alignbyte(a2, a1, o0);
-                t1.x = __builtin_amdgcn_alignbyte(b1, b0, o1); t1.y = __builtin_amdgcn_alignbyte(b2, b1, o1);
+                t0.x = __builtin_amdgcn_alignbyte(a1, a0, pw); t0.y = __builtin_amdgcn_alignbyte(a2, a1, pw);
+                t1.x = __builtin_amdgcn_alignbyte(b1, b0, pw); t1.y = __builtin_amdgcn_alignbyte(b2, b1, pw);
                 uint32_t px[3];
                 blend_rgb_rows(t0, t1, fx, fy, px);
                 const uint32_t pk = px[0] | (px[1] << 8) | (px[2] << 16);
                 // lanes 4m .. 4m + 3 hold a quad: lane k cuts dword k of its 12 bytes out of pixels k and k + 1
-                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp((int)pk, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
                 const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
-                const int i = hd & 0xfff, j = (hd >> 12) & 0xfff, vrel = (hd >> 24) & 15;    // the quad's first column, its row, relative view
-                const int jj = jbase + jsgn * j;
-                uint8_t* const d = s_dst[g * GS360_MAX_VIEWS + vrel];
+                // the turn's view (wave-uniform by construction of the plan): its destination base is reloaded only when the view changes
+                const int vrel = __builtin_amdgcn_readfirstlane((int)(hd >> 24)) & 15;
+                if (vrel != cur_vrel) {                  // scalar compare + branch: a tile has two or three view groups
+                    const uint2 dq = *reinterpret_cast<const uint2*>(&s_dst[g * GS360_MAX_VIEWS + vrel]);
+                    dbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)dq.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)dq.x);
+                    cur_vrel = vrel;
+                }
+                const int roff = __mul24((int)((hd >> 12) & 0xfffu), row_step) + lane_off;          // v_mad_i32_i24
+                const uint32_t off = __umul24(hd & 0xfffu, 3u) + (uint32_t)roff;                    // v_mad_u32_u24
                 // lane 3 repeats lane 2's store (same dword, same address): an UNCONDITIONAL store keeps the loop body straight-line
-                const uint32_t off = (uint32_t)(jj * dstride + i * 3) + 4u * (uint32_t)min(k4, 2);
-                const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw, 0xA4, 0xf, 0xf, false);    // quad_perm [0,1,2,2]
-                *(__attribute__((address_space(1))) uint32_t*)((uintptr_t)d + off) = dwq;      // (a global, not a flat store: the pointer came from LDS)
+                const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp((int)dw, (int)dw, 0xA4, 0xf, 0xf, false);    // quad_perm [0,1,2,2]
+                *(__attribute__((address_space(1))) uint32_t*)(dbase + off) = dwq;             // global store, scalar base + 32-bit offset
             }
         }
         __builtin_amdgcn_s_barrier();                    // image g + 1 has landed AND every consumer is done with image g's buffer
@@ -269,7 +283,16 @@ int sm_build_plan(const EqLaunch& L0, int N, int Bx, int R, size_t lds_limit, hi
         T.wch = (xmax + 6 - T.x0 + 15) / 16;
         T.y0 = ymin;
         T.nrows = ymax - ymin + 2;
-        const int nq = (int)(b - a), nqp = (nq + 15) / 16 * 16;
+        // entries in (view, row, column) order, every VIEW GROUP padded to whole wavefront turns (16 quads = 64 pixels) with copies of its
+        // last quad -- same values to the same addresses -- so that a turn never mixes views (the consumers keep the destination base in
+        // scalar registers)
+        std::vector<const Quad*> list;
+        for (size_t q = a; q < b; ++q) {
+            list.push_back(&quads[q]);
+            if (q + 1 == b || quads[q + 1].vrel != quads[q].vrel)
+                while (list.size() % 16) list.push_back(&quads[q]);
+        }
+        const int nqp = (int)list.size();
         T.eoff = (int32_t)ent.size();
         T.nq = nqp;
         T.pad0 = T.pad1 = 0;
@@ -279,7 +302,7 @@ int sm_build_plan(const EqLaunch& L0, int N, int Bx, int R, size_t lds_limit, hi
         uint32_t* hdr = ent.data() + T.eoff;
         uint32_t* px = hdr + nqp;
         for (int q = 0; q < nqp; ++q) {
-            const Quad& Q = quads[a + std::min(q, nq - 1)];         // padding repeats the last quad: same values to the same addresses
+            const Quad& Q = *list[q];
             hdr[q] = (uint32_t)Q.i0 | ((uint32_t)Q.j << 12) | ((uint32_t)Q.vrel << 24);
             for (int k = 0; k < 4; ++k)
                 px[4 * q + k] = (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0)) | ((uint32_t)Q.ph[k] << 17);
@@ -318,7 +341,7 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked) {
     if (V.out_w % 4 || V.out_w >= 4096 || V.out_h >= 4096 || V.out_w < 8 || V.out_h < 2) return false;
     if (L.src_stride % 16) return false;
     const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
-    if (dstride % 4 || dstride * V.out_h >= ((int64_t)1 << 31)) return false;
+    if (dstride % 4 || dstride >= (1 << 22) || dstride * V.out_h >= ((int64_t)1 << 31)) return false;    // (24-bit multiply-adds form the row offsets)
     for (int f = 0; f < L.n_frames; ++f)
         if ((uintptr_t)L.src[f] & 15) return false;
     for (int i = 0; i < L.n_frames * N; ++i)

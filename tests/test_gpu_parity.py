@@ -45,7 +45,7 @@ def test_equirect_cfg2_ring_small_source(ctx, orc, lanemap):
     src = rand_image(480, 960)
     got, want = _eq_both(ctx, orc, src, ring_views(6, 200, HFOV_12MM))
     _assert_same(got, want, "cfg2-shaped ring on 960x480")
-    # which kernel ran: the source-major one when forced (left to itself the library takes it from 3 texels per pixel; here 2.3)
+    # which kernel ran: the source-major one when forced (left to itself the library takes it for calls of >= 2 frames; this is one)
     assert ctx.get_option("last_eq_kernel") == {"srcmajor": 2, "staged": 1}.get(lanemap, 0)
 
 

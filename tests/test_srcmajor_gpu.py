@@ -100,13 +100,33 @@ def test_shapes_it_must_leave_to_the_gather_kernels(forced, orc):
 
 
 def test_auto_selection(ctx, orc):
-    """left to itself the library takes it for strongly minified rings only (>= 3 source texels per output pixel)"""
-    src = rand_image(960, 1920, seed=260)
+    """left to itself the library takes it for rings of >= 6 views from 1.5 source texels per output pixel (5 views: from 2.25; 4: never)
+    and only for calls of at least two frames (profiles/r05/srcmajor_ring_sweep.txt)"""
+    frames = [rand_image(960, 1920, seed=260 + f) for f in range(2)]
+    d_src = [ctx.to_device(f) for f in frames]
+
+    def kernel_for(specs, n_frames):
+        d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(n_frames) for s in specs]
+        ctx.equirect_views_dev(d_src[:n_frames], 1920, 960, 3, [gs360.View.make(*s) for s in specs], d_out)
+        ctx.sync(0)
+        want = orc.equirect_views_u8(frames[n_frames - 1], [orc.make_view(*s) for s in specs], threads=0)
+        for k, s in enumerate(specs):
+            assert np.array_equal(ctx.download(d_out[(n_frames - 1) * len(specs) + k], (s[5], s[4], 3)), want[k])
+        for b in d_out:
+            ctx.free(b)
+        return ctx.get_option("last_eq_kernel")
     with ctx.options(srcmajor=-1):
-        _check(ctx, orc, src, ring_views(6, 200, HFOV_12MM), "step 4.6: source-major", expect_kernel=2)
-        _check(ctx, orc, src, ring_views(6, 400, HFOV_12MM), "step 2.3: gather", expect_kernel=0)
+        assert kernel_for(ring_views(6, 200, HFOV_12MM), 2) == 2          # 4.6 texels per pixel
+        assert kernel_for(ring_views(6, 400, HFOV_12MM), 2) == 2          # 2.3
+        assert kernel_for(ring_views(6, 200, HFOV_12MM), 1) == 0          # a single frame: gather kernels
+        assert kernel_for(ring_views(6, 800, HFOV_12MM), 2) == 0          # 1.15: below 1.5
+        assert kernel_for(ring_views(5, 440, HFOV_12MM), 2) == 0          # five views at 2.08 (1920 = 5 x 384: eligible, not chosen)
+        assert kernel_for(ring_views(5, 320, HFOV_12MM), 2) == 2          # five views at 2.86
+        assert kernel_for(ring_views(4, 200, HFOV_12MM), 2) == 0          # four views: never
     with ctx.options(srcmajor=0):
-        _check(ctx, orc, src, ring_views(6, 200, HFOV_12MM), "switched off", expect_kernel=0)
+        assert kernel_for(ring_views(6, 200, HFOV_12MM), 2) == 0
+    for b in d_src:
+        ctx.free(b)
 
 
 def test_cfg2_full_size_sixteen_frames_every_byte(ctx, orc):
