@@ -372,7 +372,11 @@ int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx
     if (!plan) {
         int rr = R, rc = 1;
         for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2)) rc = sm_build_plan(L, N, Bx, rr, lds_limit, s, &plan, herr);
-        if (rc != 0) return rc;
+        if (rc < 0) return rc;
+        if (rc == 1) {                                   // does not fit: remembered (an empty plan), or every call would plan again (tens of ms)
+            plan = new (std::nothrow) SmPlan();
+            if (!plan) { *herr = hipErrorOutOfMemory; return -1; }
+        }
         plan->W = L.W; plan->H = L.H; plan->N = N; plan->w = V.out_w; plan->h = V.out_h; plan->Bx = Bx; plan->R = R;
         plan->sxu = fbits(V.sxu); plan->syv = fbits(V.syv); plan->x0f = fbits(V.x0f32); plan->x0i = V.x0i32;
         if (cache.size() >= cap) {                       // evict the least recently used plan (its last launch is ordered before this free by hipFree's sync)
@@ -386,6 +390,7 @@ int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx
     uint64_t newest = 0;
     for (SmPlan* p : cache) newest = std::max(newest, p->stamp);
     plan->stamp = newest + 1;      // (the caller holds the context's plan lock)
+    if (plan->n_tiles == 0) return 1;                    // a geometry known not to fit: the gather kernels
     SmArgs P;
     std::memset(&P, 0, sizeof(P));
     for (int f = 0; f < L.n_frames; ++f) P.src[f] = L.src[f];

@@ -99,6 +99,28 @@ def test_shapes_it_must_leave_to_the_gather_kernels(forced, orc):
     _check(forced, orc, src, [(i * 360.0 / 7, 0.0, 100.0, 100.0, 96, 64) for i in range(7)], "count 7", expect_kernel=0)
 
 
+def test_geometry_that_does_not_fit_is_remembered(forced, orc):
+    """a ring whose plan entries + tile buffers exceed the LDS budget even at 8 source rows per tile falls back to the gather kernels --
+    and is not planned again on the next call (planning costs tens of milliseconds)"""
+    import time
+    src = rand_image(1024, 2048, seed=270)
+    specs = ring_views(8, 2048, 150.0)                  # 0.6 source texels per output pixel: 20 x the entries of cfg2 per tile
+    _check(forced, orc, src, specs, "oversized plan", expect_kernel=0)
+    views = [gs360.View.make(*s) for s in specs]
+    d_src = forced.to_device(src)
+    d_out = [forced.alloc(2048 * 2048 * 3) for _ in specs]
+    forced.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
+    forced.sync(0)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        forced.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
+    forced.sync(0)
+    per_call = (time.perf_counter() - t0) / 5
+    assert forced.get_option("last_eq_kernel") == 0 and per_call < 0.02, per_call       # (planning alone took ~0.1 s for this shape)
+    for b in [d_src] + d_out:
+        forced.free(b)
+
+
 def test_auto_selection(ctx, orc):
     """left to itself the library takes it for rings of >= 6 views from 1.5 source texels per output pixel (5 views: from 2.25; 4: never)
     and only for calls of at least two frames (profiles/r05/srcmajor_ring_sweep.txt)"""
