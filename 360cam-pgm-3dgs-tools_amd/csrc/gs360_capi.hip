@@ -46,7 +46,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 // context options: name, default, range, environment seed (user switches only)
 enum Opt { kOptLanemap, kOptStage, kOptRing, kOptXcdGroup, kOptEqPersist, kOptTablePersist, kOptLanczosTable, kOptTableRows, kOptColorCube,
-           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptCount };
+           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptCount };
 struct OptDesc { const char* key; int def, lo, hi; const char* env; };
 const OptDesc kOpts[kOptCount] = {
     {"lanemap", -1, -1, 1, "GS360_LANEMAP"},          // -1 auto (per view, by minification), 0 rows, 1 blocked       (env: rows | blocked)
@@ -61,6 +61,7 @@ const OptDesc kOpts[kOptCount] = {
     {"srcmajor", -1, -1, 1, "GS360_SRCMAJOR"},        // source-major kernel: -1 auto (strongly minified level rings), 0 never, 1 whenever eligible
     {"srcmajor_bx", 768, 256, 4032, nullptr},         // its tile: bytes per box row (multiple of 16) ...
     {"srcmajor_rows", 32, 8, 128, nullptr},           // ... and source rows
+    {"srcmajor_images", 0, 0, 12, nullptr},           // images of a tile one workgroup walks (0 auto; must divide twice the ring size)
 };
 
 struct Staging {  // per-slot device staging used by the *_host conveniences
@@ -685,11 +686,13 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     }
     // Source-major kernel (gs360_srcmajor.hip): a call that is ONE level yaw ring filling its circle (`--count N`, PC:794; the `default`
     // preset) streams every source tile once for all views instead of gathering per view.  Where it wins (profiles/r05/srcmajor_ring_sweep.txt,
-    // 8K sources, N views, s source texels per output pixel): N >= 6 at every s measured (1.5 .. 4.6: -8 % .. -39 %; cfg2 19.3 -> 15.2 us per
-    // frame, cfg1 40.3 -> 35.9), N = 5 from s = 2.25, N = 4 never (neighbours overlap by a quarter of their field only: +14 .. +44 %), and
-    // only when the call carries at least two frames (a single frame is too few workgroups for its two-deep pipeline: +7 .. +11 %).  Option
-    // "srcmajor": 0 never, 1 whenever the geometry fits (tests, probes).  Decided before the ring grouping below (which keeps blocked views
-    // apart); a geometry that does not fit the plan format falls through to the gather kernels.
+    // 8K sources, N views, s source texels per output pixel): N >= 6 at every s measured (1.5 .. 4.6: -8 % .. -42 %; cfg2 19.0 -> 14.9 us per
+    // frame, cfg1 47.9 -> 33.6 at 16 frames), N = 5 from s = 2.25, N = 4 never (neighbours overlap by a quarter of their field only: +14 ..
+    // +44 %), and only when the call carries at least two frames: one frame is few workgroups for a two-deep pipeline, and even with the
+    // images-per-workgroup rule of sm_launch it is a coin toss (-23 % .. +9 % over ten rings; two frames: -25 % .. +1 %).  The engine and the
+    // stream pipeline hand over one frame per call, so they keep the gather kernels; the multi-frame entry point is what batch callers use.
+    // Option "srcmajor": 0 never, 1 whenever the geometry fits (tests, probes).  Decided before the ring grouping below (which keeps blocked
+    // views apart); a geometry that does not fit the plan format falls through to the gather kernels.
     if (opt_srcmajor != 0 && !mask_frames && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 &&
         n_views <= GS360_MAX_VIEWS) {
         bool ring = ev[0].level != 0;
@@ -726,7 +729,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             {
                 std::lock_guard<std::mutex> lock(c->sm_mutex);
                 rc = sm_launch(Ls[i], c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
-                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he);
+                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he);
             }
             if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));
             if (rc == 1 && i == 0) ring = false;         // the geometry does not fit the plan format (decided by the first chunk: nothing launched yet)

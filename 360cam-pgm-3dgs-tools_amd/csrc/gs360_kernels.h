@@ -206,7 +206,7 @@ struct SmTile { int32_t x0, y0, nrows, wch, eoff, nq, pad0, pad1; };   // box of
 struct SmPlan;
 void sm_plan_free(SmPlan* p);
 bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked);
-int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr);
+int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 void build_coef1d(float* out);             // host: the float32 1-D phase tables (linear, cubic, lanczos4) of the CV_16U samplers, 448

@@ -303,7 +303,6 @@ __device__ __forceinline__ void eq_cubic_blend(const EqCubicTaps& t, const int16
     for (int c = 0; c < 3; ++c) out[c] = (uint32_t)min(max(acc[c] >> 15, 0), 255);
 }
 
-// generic cubic sample: columns wrap, rows clamp (any channel count; also the repair path of the RGB fast path)
 
 // the taps of one bilinear pixel (two rows, raw or shifted into place) and their exact-integer blend; shared with cv_blend_fast
 template <int C>

@@ -361,7 +361,7 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked) {
 
 // Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
 // Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr) {
+int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr) {
     const EqView& V = L.view[0];
     const int N = L.n_views;
     *herr = hipSuccess;
@@ -397,11 +397,21 @@ int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx
     for (int i = 0; i < L.n_frames * N; ++i) P.dst[i] = L.dst[i];
     P.tiles = plan->d_tiles; P.entries = plan->d_entries;
     P.W = L.W; P.H = L.H; P.N = N; P.w = V.out_w; P.h = V.out_h; P.PB = plan->PB;
-    // images per workgroup: as many as divide 2 N (the plan entries are copied once per workgroup and the copy of image g + 1 hides behind
-    // image g), but a small job -- the product path renders one frame per call -- keeps at least four workgroups per CU's worth of them
+    // Images per workgroup G (a divisor of the tile's 2 N images).  A workgroup takes about G + 1 image times (its first copy is not
+    // hidden) and the job runs in ceil(workgroups / resident workgroups) rounds, so G minimises rounds x (G + 1); ties go to the larger G
+    // (the plan entries are copied once per workgroup).  Measured (cfg2, one frame per call as the product path launches it): G = 6 -> 19.3 us,
+    // 3 -> 21.6, 2 -> 23.4, 4 -> 24.9, 12 -> 31.1 (189 workgroups for 256 CUs); sixteen frames: G = 12 (profiles/r05/srcmajor_images_sweep.txt).
+    const size_t lds_wg = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes + 2048;
+    const long long resident = (long long)n_cu * std::max<size_t>(1, (160 * 1024) / lds_wg);
+    const long long items = (long long)plan->n_tiles * 2 * N * L.n_frames;
     int G = 1;
-    for (int g = 1; g <= kSmMaxImages; ++g)
-        if ((2 * N) % g == 0 && (g == 1 || (long long)plan->n_tiles * (2 * N / g) * L.n_frames >= 4ll * n_cu)) G = g;
+    long long best = -1;
+    for (int g = 1; g <= kSmMaxImages; ++g) {
+        if ((2 * N) % g) continue;
+        const long long wgs = items / g, rounds = (wgs + resident - 1) / resident, cost = rounds * (g + 1);
+        if (best < 0 || cost <= best) { best = cost; G = g; }
+    }
+    if (G_opt > 0 && G_opt <= kSmMaxImages && (2 * N) % G_opt == 0) G = G_opt;          // option "srcmajor_images" (probes)
     P.G = G; P.groups_per_tile = 2 * N / G; P.groups_per_frame = plan->n_tiles * P.groups_per_tile;
     P.total_groups = P.groups_per_frame * L.n_frames; P.gchunk = (P.total_groups + 7) / 8;
     P.buf_bytes = plan->buf_bytes; P.ent_bytes = plan->ent_bytes;
