@@ -695,15 +695,15 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     // views apart); a geometry that does not fit the plan format falls through to the gather kernels.
     if (opt_srcmajor != 0 && !mask_frames && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 &&
         n_views <= GS360_MAX_VIEWS) {
-        bool ring = ev[0].level != 0;
-        if (ring && opt_srcmajor < 0) {
+        bool ring = true;
+        if (opt_srcmajor < 0) {
             const double hf = clampd(views[0].hfov_deg, 1e-3, 179.9) * kPi / 180.0;
             const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[0].width;
-            ring = n_frames >= 2 && n_views >= 5 && step >= (n_views >= 6 ? 1.5 : 2.25);
+            bool level = true;
+            for (int k = 0; k < n_views; ++k) level = level && ev[k].level;
+            ring = level && n_frames >= 2 && n_views >= 5 && step >= (n_views >= 6 ? 1.5 : 2.25);
         }
-        for (int k = 0; k < n_views && ring; ++k)
-            ring = ev[k].sxu == ev[0].sxu && ev[k].syv == ev[0].syv && ev[k].sp == ev[0].sp && ev[k].cp == ev[0].cp && ev[k].x0f32 == ev[0].x0f32 &&
-                   ev[k].out_w == ev[0].out_w && ev[k].out_h == ev[0].out_h && ev[k].level;
+        SmShape shape;
         std::vector<EqLaunch> Ls;
         for (int f0 = 0; f0 < n_frames && ring; f0 += GS360_MAX_FRAMES) {
             const int nf = n_frames - f0 < GS360_MAX_FRAMES ? n_frames - f0 : GS360_MAX_FRAMES;
@@ -720,7 +720,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             L.W = W; L.H = H; L.y0i32 = 16 * H - 16;
             L.n_views = n_views; L.n_frames = nf;
             L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
-            ring = sm_eligible(L, C, esize, interp, false);
+            ring = sm_eligible(L, C, esize, interp, false, &shape);     // (the shape depends on the views only: the same for every chunk)
             Ls.push_back(L);
         }
         for (size_t i = 0; i < Ls.size() && ring; ++i) {
@@ -728,7 +728,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             int rc;
             {
                 std::lock_guard<std::mutex> lock(c->sm_mutex);
-                rc = sm_launch(Ls[i], c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
+                rc = sm_launch(Ls[i], shape, c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
                                c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he);
             }
             if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));

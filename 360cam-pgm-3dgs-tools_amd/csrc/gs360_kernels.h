@@ -205,8 +205,15 @@ hipError_t launch_equirect_cubic(const EqLaunch& L, int C, hipStream_t s);
 struct SmTile { int32_t x0, y0, nrows, wch, eoff, nq, pad0, pad1; };   // box of a plan tile: first byte (in the period) / row, rows, 16-byte chunks per row; entries
 struct SmPlan;
 void sm_plan_free(SmPlan* p);
-bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked);
-int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr);
+struct SmShape {                         // how a call's views fall into yaw rings of one size (filled by sm_eligible)
+    int N, n_rings;                      // members per ring, rings
+    int ref[GS360_MAX_VIEWS];            // ring -> view index of the member at the ring's origin
+    int partner[GS360_MAX_VIEWS];        // ring -> the ring at minus its pitch (itself for a level ring)
+    int qmap[GS360_MAX_VIEWS];           // ring * N + position -> view index
+};
+bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, SmShape* S);
+int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, size_t lds_limit, int n_cu, hipStream_t s,
+              hipError_t* herr);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 void build_coef1d(float* out);             // host: the float32 1-D phase tables (linear, cubic, lanczos4) of the CV_16U samplers, 448

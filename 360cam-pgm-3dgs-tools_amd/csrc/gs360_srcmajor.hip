@@ -43,9 +43,9 @@ typedef const __attribute__((address_space(1))) void global_void_t;
 constexpr int kSmConsumers = 8;                         // consumer wavefronts per workgroup (+ one loader)
 constexpr int kSmMaxImages = 12;                        // images of a tile one workgroup walks (G)
 
-// ---- plan coordinates: EQ-SPEC v1 for the upper half of the ring's first member, every column by the general formula ----------------
-__global__ __launch_bounds__(256) void eq_plan_coords_kernel(const EqLaunch L, int2* __restrict__ out, int rows) {
-    const EqView& V = L.view[0];
+// ---- plan coordinates: EQ-SPEC v1 for the first `rows` rows of view `vi` (a ring's reference member), every column by the general formula
+__global__ __launch_bounds__(256) void eq_plan_coords_kernel(const EqLaunch L, int vi, int2* __restrict__ out, int rows) {
+    const EqView& V = L.view[vi];
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     const int ic = min(i, V.out_w - 1);                  // (every lane evaluates: eq_sqrt's fallback branch is wave-uniform)
     const float x = (float)(2 * ic + 1 - V.out_w) * V.sxu;
@@ -66,10 +66,11 @@ struct SmArgs {
     uint8_t* dst[GS360_MAX_FRAMES * GS360_MAX_VIEWS];
     const SmTile* tiles;
     const uint32_t* entries;
-    int32_t W, H, N, w, h, PB;
+    int32_t W, H, N, NV, w, h, PB;        // N = members per ring (periods of the source), NV = views of the call (rings x N)
     int32_t G, groups_per_tile, groups_per_frame, total_groups, gchunk;
     int32_t buf_bytes, ent_bytes;
-    int32_t qmap[GS360_MAX_VIEWS];        // ring position -> view index of the call
+    int32_t qmap[GS360_MAX_VIEWS];        // ring * N + ring position -> view index of the call
+    int32_t partner[GS360_MAX_VIEWS];     // ring -> the ring its upside-down images render (itself: level; the ring at minus its pitch otherwise)
     int64_t src_stride, dst_stride;
 };
 static_assert(sizeof(SmArgs) <= 4096, "SmArgs travels as a kernel argument");
@@ -90,11 +91,13 @@ __global__ __launch_bounds__(64 * (kSmConsumers + 1)) void eq_srcmajor_kernel(co
     const int G = P.G;
     uint8_t* const s_ent = s_lds;                        // [headers: nq dwords][pixel words: 4 nq dwords]
     uint8_t* const s_tile = s_lds + P.ent_bytes;         // two tile buffers of buf_bytes
-    if (tid < G * P.N) {                                 // destination of (image, relative view): period k renders view (rel + k) mod N
-        const int g = tid / P.N, v = tid - g * P.N;
-        int q = v + ((g0 + g) >> 1);
+    if (tid < G * P.NV) {                                // destination of (image, plan view = ring * N + relative member): period k renders
+        const int g = tid / P.NV, v = tid - g * P.NV;    // member (rel + k) mod N, of the ring itself or -- upside down -- of its mirror ring
+        const int c = v / P.N, img = g0 + g;
+        int q = v - c * P.N + (img >> 1);
         if (q >= P.N) q -= P.N;
-        s_dst[g * GS360_MAX_VIEWS + v] = P.dst[f * P.N + P.qmap[q]];
+        const int c2 = (img & 1) ? P.partner[c] : c;
+        s_dst[g * GS360_MAX_VIEWS + v] = P.dst[f * P.NV + P.qmap[c2 * P.N + q]];
     }
     const uint8_t* __restrict__ src = P.src[f];
     const int rowbytes = 3 * P.W;
@@ -196,9 +199,9 @@ __global__ __launch_bounds__(64 * (kSmConsumers + 1)) void eq_srcmajor_kernel(co
 // ---- host side: the plan ------------------------------------------------------------------------------------------------------------
 struct SmPlan {
     // key
-    int W = 0, H = 0, N = 0, w = 0, h = 0, Bx = 0, R = 0;
-    uint32_t sxu = 0, syv = 0, x0f = 0;    // float bits
-    int x0i = 0;
+    int W = 0, H = 0, N = 0, n_rings = 0, w = 0, h = 0, Bx = 0, R = 0;
+    uint32_t sxu = 0, syv = 0;             // float bits
+    uint32_t ring_key[GS360_MAX_VIEWS][4]; // per ring: sp, cp, x0f32 (float bits), x0i32 of its reference member
     // contents
     SmTile* d_tiles = nullptr;
     uint32_t* d_entries = nullptr;
@@ -217,104 +220,124 @@ namespace {
 
 uint32_t fbits(float v) { uint32_t b; std::memcpy(&b, &v, 4); return b; }
 
-struct Quad { int32_t tid, vrel, j, i0; int32_t xr[4], iy[4], ph[4]; };
+struct Quad { int32_t tid, vslot, j, i0; int32_t xr[4], iy[4], ph[4]; };
+
+constexpr int kSmQuadCap = 1632;                        // quads of one plan tile (32 KiB of entries); a denser tile is cut into several
 
 // 0: plan built; 1: this geometry does not fit the kernel (caller falls back to the gather kernels); < 0: HIP error in *herr
-int sm_build_plan(const EqLaunch& L0, int N, int Bx, int R, size_t lds_limit, hipStream_t s, SmPlan** out, hipError_t* herr) {
+int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smallest, size_t lds_limit, hipStream_t s, SmPlan** out, hipError_t* herr) {
     const EqView& V = L0.view[0];
-    const int W = L0.W, w = V.out_w, h = V.out_h;
-    const int hh = (h + 1) / 2;
+    const int W = L0.W, H = L0.H, N = S.N, w = V.out_w, h = V.out_h;
     const int PB = 3 * (W / N), rowbytes = 3 * W;
-    int2* d_xy = nullptr;
-    std::vector<int2> xy((size_t)hh * w);
-    if ((*herr = hipMalloc((void**)&d_xy, xy.size() * sizeof(int2))) != hipSuccess) return -1;
-    hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, hh), dim3(256), 0, s, L0, d_xy, hh);
-    *herr = hipGetLastError();
-    if (*herr == hipSuccess) *herr = hipMemcpyAsync(xy.data(), d_xy, xy.size() * sizeof(int2), hipMemcpyDeviceToHost, s);
-    if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
-    (void)hipFree(d_xy);
-    if (*herr != hipSuccess) return -1;
-
-    int ytop = 1 << 30;
-    for (const int2& q : xy) ytop = std::min(ytop, q.y >> 5);
-    if (ytop < 0) return 1;                              // a view that reaches the pole row: the gather kernels' clamp path
     const int ntx = (PB + Bx - 1) / Bx;
     const int nqx = w / 4;
-    std::vector<Quad> quads((size_t)hh * nqx);
-    for (int j = 0; j < hh; ++j)
-        for (int qx = 0; qx < nqx; ++qx) {
-            Quad& Q = quads[(size_t)j * nqx + qx];
-            const int2* p = &xy[(size_t)j * w + 4 * qx];
-            const int xb0 = 3 * (p[0].x >> 5);
-            const int p0 = xb0 / PB;
-            Q.vrel = (N - p0 % N) % N;
-            Q.j = j; Q.i0 = 4 * qx;
-            for (int k = 0; k < 4; ++k) {
-                int dx = 3 * (p[k].x >> 5) - xb0;        // longitude grows with the column; unwrap across the seam
-                if (dx < 0) dx += rowbytes;
-                if (dx > rowbytes / 2) return 1;         // (not a monotone quad: cannot happen for fov < 180, refuse rather than trust)
-                Q.xr[k] = xb0 - p0 * PB + dx;            // relative to the QUAD's period (may run past its end: the copy wraps)
-                Q.iy[k] = p[k].y >> 5;
-                Q.ph[k] = (p[k].x & 31) | ((p[k].y & 31) << 5);
+    const int centre = 16 * H - 16;
+    // A quad belongs to the plan when its first pixel looks at or above the equator (sy <= 16 H - 16): the upside-down images then render
+    // exactly the others (sy' = 32 H - 32 - sy is the mirror ring's pixel (i, h - 1 - j)); quads ON the equator are rendered twice, same
+    // bytes to the same place.  For a level ring that is the upper half of its rows.
+    int2* d_xy = nullptr;
+    std::vector<int2> xy((size_t)h * w);
+    std::vector<Quad> quads;
+    if ((*herr = hipMalloc((void**)&d_xy, xy.size() * sizeof(int2))) != hipSuccess) return -1;
+    int ytop = 1 << 30, fit = 0;
+    for (int c = 0; c < S.n_rings && fit == 0; ++c) {
+        const bool level = L0.view[S.ref[c]].level != 0;
+        const int rows = level ? (h + 1) / 2 : h;
+        hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, rows), dim3(256), 0, s, L0, S.ref[c], d_xy, rows);
+        *herr = hipGetLastError();
+        if (*herr == hipSuccess) *herr = hipMemcpyAsync(xy.data(), d_xy, (size_t)rows * w * sizeof(int2), hipMemcpyDeviceToHost, s);
+        if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
+        if (*herr != hipSuccess) break;
+        quads.reserve(quads.size() + (size_t)rows * nqx / (level ? 1 : 2) + 1024);
+        for (int j = 0; j < rows && fit == 0; ++j)
+            for (int qx = 0; qx < nqx; ++qx) {
+                const int2* p = &xy[(size_t)j * w + 4 * qx];
+                if (p[0].y > centre) continue;
+                Quad Q;
+                const int xb0 = 3 * (p[0].x >> 5);
+                const int p0 = xb0 / PB;
+                Q.vslot = c * N + (N - p0 % N) % N;
+                Q.j = j; Q.i0 = 4 * qx;
+                for (int k = 0; k < 4; ++k) {
+                    int dx = 3 * (p[k].x >> 5) - xb0;        // longitude grows with the column; unwrap across the seam
+                    if (dx < 0) dx += rowbytes;
+                    if (dx > rowbytes / 2) { fit = 1; break; }   // (not a monotone quad: a view over a pole; refuse rather than trust)
+                    Q.xr[k] = xb0 - p0 * PB + dx;            // relative to the QUAD's period (may run past its end: the copy wraps)
+                    Q.iy[k] = p[k].y >> 5;
+                    Q.ph[k] = (p[k].x & 31) | ((p[k].y & 31) << 5);
+                    ytop = std::min(ytop, Q.iy[k]);
+                }
+                if (fit) break;
+                quads.push_back(Q);
             }
-            Q.tid = ((Q.iy[0] - ytop) / R) * ntx + Q.xr[0] / Bx;
-        }
+    }
+    (void)hipFree(d_xy);
+    if (*herr != hipSuccess) return -1;
+    if (fit || ytop < 0 || quads.empty()) return 1;      // (a view that reaches the pole row: the gather kernels' clamp path)
+    for (Quad& Q : quads) Q.tid = ((Q.iy[0] - ytop) / R) * ntx + Q.xr[0] / Bx;
     std::sort(quads.begin(), quads.end(), [](const Quad& a, const Quad& b) {
         if (a.tid != b.tid) return a.tid < b.tid;
-        if (a.vrel != b.vrel) return a.vrel < b.vrel;
+        if (a.vslot != b.vslot) return a.vslot < b.vslot;
         if (a.j != b.j) return a.j < b.j;
         return a.i0 < b.i0;
     });
     std::vector<SmTile> tiles;
     std::vector<uint32_t> ent;
-    int buf_bytes = 0, ent_bytes = 0;
+    std::vector<const Quad*> list;
+    int buf_bytes = 0, ent_bytes = 0, n_boxes = 0;
     for (size_t a = 0; a < quads.size();) {
         size_t b = a;
-        int xmin = 1 << 30, xmax = 0, ymin = 1 << 30, ymax = 0;
-        while (b < quads.size() && quads[b].tid == quads[a].tid) {
-            for (int k = 0; k < 4; ++k) {
-                xmin = std::min(xmin, quads[b].xr[k]); xmax = std::max(xmax, quads[b].xr[k]);
-                ymin = std::min(ymin, quads[b].iy[k]); ymax = std::max(ymax, quads[b].iy[k]);
-            }
-            ++b;
-        }
-        SmTile T;
-        T.x0 = xmin & ~15;
-        T.wch = (xmax + 6 - T.x0 + 15) / 16;
-        T.y0 = ymin;
-        T.nrows = ymax - ymin + 2;
+        while (b < quads.size() && quads[b].tid == quads[a].tid) ++b;
         // entries in (view, row, column) order, every VIEW GROUP padded to whole wavefront turns (16 quads = 64 pixels) with copies of its
         // last quad -- same values to the same addresses -- so that a turn never mixes views (the consumers keep the destination base in
         // scalar registers)
-        std::vector<const Quad*> list;
+        list.clear();
         for (size_t q = a; q < b; ++q) {
             list.push_back(&quads[q]);
-            if (q + 1 == b || quads[q + 1].vrel != quads[q].vrel)
+            if (q + 1 == b || quads[q + 1].vslot != quads[q].vslot)
                 while (list.size() % 16) list.push_back(&quads[q]);
         }
-        const int nqp = (int)list.size();
-        T.eoff = (int32_t)ent.size();
-        T.nq = nqp;
-        T.pad0 = T.pad1 = 0;
-        const int pitch = T.wch * 16;
-        if ((size_t)T.nrows * pitch >= (1u << 17) || T.x0 >= PB || T.wch * 16 > rowbytes) return 1;
-        ent.resize(ent.size() + 5 * (size_t)nqp);
-        uint32_t* hdr = ent.data() + T.eoff;
-        uint32_t* px = hdr + nqp;
-        for (int q = 0; q < nqp; ++q) {
-            const Quad& Q = *list[q];
-            hdr[q] = (uint32_t)Q.i0 | ((uint32_t)Q.j << 12) | ((uint32_t)Q.vrel << 24);
-            for (int k = 0; k < 4; ++k)
-                px[4 * q + k] = (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0)) | ((uint32_t)Q.ph[k] << 17);
+        ++n_boxes;
+        // a tile many views look at closely (weak minification, or a pitched ring's rows near the pole) is cut into plan tiles of at most
+        // kSmQuadCap quads, each with the box of ITS quads
+        for (size_t c0 = 0; c0 < list.size(); c0 += kSmQuadCap) {
+            const int nqp = (int)std::min<size_t>(kSmQuadCap, list.size() - c0);
+            int xmin = 1 << 30, xmax = 0, ymin = 1 << 30, ymax = 0;
+            for (int q = 0; q < nqp; ++q)
+                for (int k = 0; k < 4; ++k) {
+                    xmin = std::min(xmin, list[c0 + q]->xr[k]); xmax = std::max(xmax, list[c0 + q]->xr[k]);
+                    ymin = std::min(ymin, list[c0 + q]->iy[k]); ymax = std::max(ymax, list[c0 + q]->iy[k]);
+                }
+            SmTile T;
+            T.x0 = xmin & ~15;
+            T.wch = (xmax + 6 - T.x0 + 15) / 16;
+            T.y0 = ymin;
+            T.nrows = ymax - ymin + 2;
+            T.eoff = (int32_t)ent.size();
+            T.nq = nqp;
+            T.pad0 = T.pad1 = 0;
+            const int pitch = T.wch * 16;
+            if ((size_t)T.nrows * pitch >= (1u << 17) || T.x0 >= PB || T.wch * 16 > rowbytes) return 1;
+            ent.resize(ent.size() + 5 * (size_t)nqp);
+            uint32_t* hdr = ent.data() + T.eoff;
+            uint32_t* px = hdr + nqp;
+            for (int q = 0; q < nqp; ++q) {
+                const Quad& Q = *list[c0 + q];
+                hdr[q] = (uint32_t)Q.i0 | ((uint32_t)Q.j << 12) | ((uint32_t)Q.vslot << 24);
+                for (int k = 0; k < 4; ++k)
+                    px[4 * q + k] = (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0)) | ((uint32_t)Q.ph[k] << 17);
+            }
+            buf_bytes = std::max(buf_bytes, T.nrows * pitch);
+            ent_bytes = std::max(ent_bytes, 20 * nqp);
+            tiles.push_back(T);
         }
-        buf_bytes = std::max(buf_bytes, T.nrows * pitch);
-        ent_bytes = std::max(ent_bytes, 20 * nqp);
-        tiles.push_back(T);
         a = b;
     }
     buf_bytes = (buf_bytes + 63) & ~63;
     ent_bytes = (ent_bytes + 63) & ~63;
     if ((size_t)ent_bytes + 2 * (size_t)buf_bytes > lds_limit) return 1;
+    // most boxes cut in two or more: the tile is too tall for this geometry (every cut copies much of the box again), a smaller one serves better
+    if (!smallest && tiles.size() > (size_t)n_boxes + (size_t)n_boxes / 4) return 1;
     SmPlan* p = new (std::nothrow) SmPlan();
     if (!p) { *herr = hipErrorOutOfMemory; return -1; }
     p->n_tiles = (int)tiles.size(); p->buf_bytes = buf_bytes; p->ent_bytes = ent_bytes; p->PB = PB;
@@ -328,57 +351,106 @@ int sm_build_plan(const EqLaunch& L0, int N, int Bx, int R, size_t lds_limit, hi
     return 0;
 }
 
+void sm_ring_key(const EqLaunch& L, const SmShape& S, uint32_t (*key)[4]) {
+    for (int c = 0; c < S.n_rings; ++c) {
+        const EqView& V = L.view[S.ref[c]];
+        key[c][0] = fbits(V.sp); key[c][1] = fbits(V.cp); key[c][2] = fbits(V.x0f32); key[c][3] = (uint32_t)V.x0i32;
+    }
+}
+
 }  // namespace
 
-// Can this launch (one ring, already grouped by the caller) take the source-major kernel?  Checks only; builds nothing.
-bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked) {
+// Can this launch take the source-major kernel?  Checks only; builds nothing.  Fills *S: how the views fall into yaw rings.
+// The views must be rings of ONE size N (N equally spaced members, every position taken) with one view geometry, each ring level or
+// accompanied by the ring at minus its pitch on the same yaws (`full360coverage`: a level ring of four and the +30 / -30 pair;
+// `fisheyelike`: five rings of two; PC:616-680, :794-822).
+bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, SmShape* S) {
     if (C != 3 || esize != 1 || interp != GS360_INTERP_LINEAR || masked) return false;
-    if (L.n_rings != 1 || L.ring_count[0] != L.n_views) return false;
-    const int N = L.n_views;
+    const int NV = L.n_views;
     const EqView& V = L.view[0];
-    if (N < 2 || N > GS360_MAX_VIEWS || !V.level || V.fish) return false;
-    if (L.W % N || (3 * L.W) % 16 || (3 * (L.W / N)) % 16) return false;
+    if (NV < 2 || NV > GS360_MAX_VIEWS) return false;
     if (V.out_w % 4 || V.out_w >= 4096 || V.out_h >= 4096 || V.out_w < 8 || V.out_h < 2) return false;
-    if (L.src_stride % 16) return false;
+    if ((3 * L.W) % 16 || L.src_stride % 16) return false;
     const int64_t dstride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
     if (dstride % 4 || dstride >= (1 << 22) || dstride * V.out_h >= ((int64_t)1 << 31)) return false;    // (24-bit multiply-adds form the row offsets)
     for (int f = 0; f < L.n_frames; ++f)
         if ((uintptr_t)L.src[f] & 15) return false;
-    for (int i = 0; i < L.n_frames * N; ++i)
+    for (int i = 0; i < L.n_frames * NV; ++i)
         if ((uintptr_t)L.dst[i] & 3) return false;
-    // every ring position taken exactly once: member offsets are distinct whole multiples of d = W / N texels
-    const int d32 = 32 * (L.W / N);
-    int seen = 0;
-    for (int k = 0; k < N; ++k) {
-        if (L.view[k].flip) return false;
-        int off = L.view[k].x0i32 - V.x0i32;
-        if (off < 0) off += 32 * L.W;
-        if (off % d32) return false;
-        seen |= 1 << (off / d32);
+    for (int k = 0; k < NV; ++k) {
+        const EqView& A = L.view[k];
+        if (A.fish || A.flip || fbits(A.sxu) != fbits(V.sxu) || fbits(A.syv) != fbits(V.syv) || A.out_w != V.out_w || A.out_h != V.out_h) return false;
     }
-    return seen == (1 << N) - 1;
+    // The largest ring size N the views fall into: a ring = the views of one pitch whose yaws differ by whole multiples of 360 / N degrees
+    // (x0i32 by whole multiples of d = W / N texels, x0f32 equal), every one of its N positions taken once.  A member's position is
+    // ABSOLUTE (x0i32 / 32 d), so a ring and its mirror ring number their members alike.
+    for (int N = NV; N >= 2; --N) {
+        if (NV % N || L.W % N || (3 * (L.W / N)) % 16) continue;
+        const int d32 = 32 * (L.W / N);
+        int seen[GS360_MAX_VIEWS];
+        S->N = N; S->n_rings = 0;
+        bool ok = true;
+        for (int k = 0; k < NV && ok; ++k) {
+            const EqView& A = L.view[k];
+            int c = 0;
+            for (; c < S->n_rings; ++c) {
+                const EqView& B = L.view[S->ref[c]];
+                if (fbits(B.sp) == fbits(A.sp) && fbits(B.cp) == fbits(A.cp) && fbits(B.x0f32) == fbits(A.x0f32) && B.x0i32 % d32 == A.x0i32 % d32) break;
+            }
+            if (c == S->n_rings) {
+                if (S->n_rings == NV / N) { ok = false; break; }
+                S->ref[c] = k; seen[c] = 0; ++S->n_rings;
+            }
+            const int pos = A.x0i32 / d32;
+            if (pos < 0 || pos >= N || (seen[c] >> pos & 1)) { ok = false; break; }
+            seen[c] |= 1 << pos;
+            S->qmap[c * N + pos] = k;
+        }
+        if (!ok || S->n_rings != NV / N) continue;           // (rings x N == NV and no position taken twice: every ring is full)
+        // the mirror ring: a level ring mirrors itself (sp == +0.0f: make_eq_view's level form), a pitched one needs the ring at minus its pitch
+        for (int c = 0; c < S->n_rings && ok; ++c) {
+            const EqView& A = L.view[S->ref[c]];
+            S->partner[c] = A.level ? c : -1;
+            for (int e = 0; e < S->n_rings && !A.level; ++e) {
+                const EqView& B = L.view[S->ref[e]];
+                if (!B.level && fbits(B.cp) == fbits(A.cp) && fbits(B.sp) == (fbits(A.sp) ^ 0x80000000u) && fbits(B.x0f32) == fbits(A.x0f32) &&
+                    B.x0i32 % d32 == A.x0i32 % d32) S->partner[c] = e;
+            }
+            if (S->partner[c] < 0) ok = false;
+        }
+        if (!ok) continue;
+        for (int c = 0; c < S->n_rings; ++c) S->ref[c] = S->qmap[c * N];      // the member at position 0: the plan's coordinates are its coordinates
+        return true;
+    }
+    return false;
 }
 
 // Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
 // Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr) {
+int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, size_t lds_limit, int n_cu, hipStream_t s,
+              hipError_t* herr) {
     const EqView& V = L.view[0];
-    const int N = L.n_views;
+    const int N = S.N, NV = L.n_views;
     *herr = hipSuccess;
+    uint32_t key[GS360_MAX_VIEWS][4];
+    sm_ring_key(L, S, key);
     SmPlan* plan = nullptr;
     for (SmPlan* p : cache)
-        if (p->W == L.W && p->H == L.H && p->N == N && p->w == V.out_w && p->h == V.out_h && p->Bx == Bx && p->R == R && p->sxu == fbits(V.sxu) &&
-            p->syv == fbits(V.syv) && p->x0f == fbits(V.x0f32) && p->x0i == V.x0i32) { plan = p; break; }
+        if (p->W == L.W && p->H == L.H && p->N == N && p->n_rings == S.n_rings && p->w == V.out_w && p->h == V.out_h && p->Bx == Bx && p->R == R &&
+            p->sxu == fbits(V.sxu) && p->syv == fbits(V.syv) && std::memcmp(p->ring_key, key, sizeof(key[0]) * S.n_rings) == 0) { plan = p; break; }
     if (!plan) {
         int rr = R, rc = 1;
-        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2)) rc = sm_build_plan(L, N, Bx, rr, lds_limit, s, &plan, herr);
+        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2))
+            rc = sm_build_plan(L, S, Bx, rr, attempt == 2 || rr == 8, lds_limit, s, &plan, herr);
         if (rc < 0) return rc;
         if (rc == 1) {                                   // does not fit: remembered (an empty plan), or every call would plan again (tens of ms)
             plan = new (std::nothrow) SmPlan();
             if (!plan) { *herr = hipErrorOutOfMemory; return -1; }
         }
-        plan->W = L.W; plan->H = L.H; plan->N = N; plan->w = V.out_w; plan->h = V.out_h; plan->Bx = Bx; plan->R = R;
-        plan->sxu = fbits(V.sxu); plan->syv = fbits(V.syv); plan->x0f = fbits(V.x0f32); plan->x0i = V.x0i32;
+        plan->W = L.W; plan->H = L.H; plan->N = N; plan->n_rings = S.n_rings; plan->w = V.out_w; plan->h = V.out_h; plan->Bx = Bx; plan->R = R;
+        plan->sxu = fbits(V.sxu); plan->syv = fbits(V.syv);
+        std::memset(plan->ring_key, 0, sizeof(plan->ring_key));
+        std::memcpy(plan->ring_key, key, sizeof(key[0]) * S.n_rings);
         if (cache.size() >= cap) {                       // evict the least recently used plan (its last launch is ordered before this free by hipFree's sync)
             size_t lru = 0;
             for (size_t i = 1; i < cache.size(); ++i) if (cache[i]->stamp < cache[lru]->stamp) lru = i;
@@ -394,9 +466,9 @@ int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx
     SmArgs P;
     std::memset(&P, 0, sizeof(P));
     for (int f = 0; f < L.n_frames; ++f) P.src[f] = L.src[f];
-    for (int i = 0; i < L.n_frames * N; ++i) P.dst[i] = L.dst[i];
+    for (int i = 0; i < L.n_frames * NV; ++i) P.dst[i] = L.dst[i];
     P.tiles = plan->d_tiles; P.entries = plan->d_entries;
-    P.W = L.W; P.H = L.H; P.N = N; P.w = V.out_w; P.h = V.out_h; P.PB = plan->PB;
+    P.W = L.W; P.H = L.H; P.N = N; P.NV = NV; P.w = V.out_w; P.h = V.out_h; P.PB = plan->PB;
     // Images per workgroup G (a divisor of the tile's 2 N images).  A workgroup takes about G + 1 image times (its first copy is not
     // hidden) and the job runs in ceil(workgroups / resident workgroups) rounds, so G minimises rounds x (G + 1); ties go to the larger G
     // (the plan entries are copied once per workgroup).  Measured (cfg2, one frame per call as the product path launches it): G = 6 -> 19.3 us,
@@ -415,12 +487,8 @@ int sm_launch(const EqLaunch& L, std::vector<SmPlan*>& cache, size_t cap, int Bx
     P.G = G; P.groups_per_tile = 2 * N / G; P.groups_per_frame = plan->n_tiles * P.groups_per_tile;
     P.total_groups = P.groups_per_frame * L.n_frames; P.gchunk = (P.total_groups + 7) / 8;
     P.buf_bytes = plan->buf_bytes; P.ent_bytes = plan->ent_bytes;
-    const int d32 = 32 * (L.W / N);
-    for (int k = 0; k < N; ++k) {
-        int off = L.view[k].x0i32 - V.x0i32;
-        if (off < 0) off += 32 * L.W;
-        P.qmap[off / d32] = k;
-    }
+    for (int i = 0; i < NV; ++i) P.qmap[i] = S.qmap[i];
+    for (int c = 0; c < S.n_rings; ++c) P.partner[c] = S.partner[c];
     P.src_stride = L.src_stride;
     P.dst_stride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
     const size_t lds = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes;

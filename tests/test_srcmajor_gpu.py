@@ -1,13 +1,14 @@
 """-m gpu: the source-major equirect kernel (gs360_srcmajor.hip) through the C ABI against the CPU oracle, every byte.
 
-It takes calls that are ONE level yaw ring filling its circle (`--count N`, gs360_360PerspCut.py:794; one ffmpeg v360 process per
-(frame, view) in the reference, PC:310-314).  Forced on with the context option "srcmajor" = 1 so that weakly minified rings run through
-it too; `last_eq_kernel` proves which kernel a call launched."""
+It takes calls whose views are yaw rings of one size filling their circle (`--count N`, gs360_360PerspCut.py:794; one ffmpeg v360
+process per (frame, view) in the reference, PC:310-314), each ring level or paired with the ring at minus its pitch (the
+`full360coverage` and `fisheyelike` presets, PC:616-680).  Forced on with the context option "srcmajor" = 1 so that weakly minified
+rings run through it too; `last_eq_kernel` proves which kernel a call launched."""
 import numpy as np
 import pytest
 
 import gs360
-from util import HFOV_12MM, rand_image, ring_views
+from util import HFOV_12MM, HFOV_14MM, HFOV_17MM, PRESET_FISHEYELIKE, PRESET_FULL360, rand_image, ring_views
 
 pytestmark = pytest.mark.gpu
 
@@ -99,26 +100,97 @@ def test_shapes_it_must_leave_to_the_gather_kernels(forced, orc):
     _check(forced, orc, src, [(i * 360.0 / 7, 0.0, 100.0, 100.0, 96, 64) for i in range(7)], "count 7", expect_kernel=0)
 
 
-def test_geometry_that_does_not_fit_is_remembered(forced, orc):
-    """a ring whose plan entries + tile buffers exceed the LDS budget even at 8 source rows per tile falls back to the gather kernels --
-    and is not planned again on the next call (planning costs tens of milliseconds)"""
+def test_geometry_that_does_not_fit_is_remembered(ctx, orc):
+    """a tile whose two buffers exceed the LDS budget even at a quarter of the asked rows falls back to the gather kernels -- and is not
+    planned again on the next call (planning costs tens of milliseconds)"""
     import time
     src = rand_image(1024, 2048, seed=270)
-    specs = ring_views(8, 2048, 150.0)                  # 0.6 source texels per output pixel: 20 x the entries of cfg2 per tile
-    _check(forced, orc, src, specs, "oversized plan", expect_kernel=0)
-    views = [gs360.View.make(*s) for s in specs]
-    d_src = forced.to_device(src)
-    d_out = [forced.alloc(2048 * 2048 * 3) for _ in specs]
-    forced.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
-    forced.sync(0)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        forced.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
-    forced.sync(0)
-    per_call = (time.perf_counter() - t0) / 5
-    assert forced.get_option("last_eq_kernel") == 0 and per_call < 0.02, per_call       # (planning alone took ~0.1 s for this shape)
+    specs = ring_views(8, 512, 100.0)
+    with ctx.options(srcmajor=1, srcmajor_bx=4032, srcmajor_rows=128):
+        _check(ctx, orc, src, specs, "oversized tiles", expect_kernel=0)
+        views = [gs360.View.make(*s) for s in specs]
+        d_src = ctx.to_device(src)
+        d_out = [ctx.alloc(512 * 512 * 3) for _ in specs]
+        ctx.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
+        ctx.sync(0)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
+        ctx.sync(0)
+        per_call = (time.perf_counter() - t0) / 5
+        assert ctx.get_option("last_eq_kernel") == 0 and per_call < 0.01, per_call
     for b in [d_src] + d_out:
+        ctx.free(b)
+
+
+def _family(pairs, hfov, size):
+    return [(float(y), float(p), hfov, hfov, size, size) for y, p in pairs]
+
+
+RING_FAMILIES = {
+    "full360coverage": (1920, 960, _family(PRESET_FULL360, HFOV_14MM, 200)),                 # a level ring of 4 + the +30 / -30 pair
+    "fisheyelike": (1920, 960, _family(PRESET_FISHEYELIKE, HFOV_17MM, 256)),                 # 5 rings of 2
+    "mirror pair alone": (960, 480, _family([(10 + 90 * i, s * 25) for i in range(4) for s in (1, -1)], 90.0, 120)),
+    "level + two pairs, own yaw phases": (1440, 720, _family([(120 * i, 0) for i in range(3)] + [(17.5 + 120 * i, s * 20) for i in range(3) for s in (1, -1)]
+                                                              + [(60 + 120 * i, s * 50) for i in range(3) for s in (-1, 1)], 60.0, 96)),
+    "odd source height": (960, 479, _family(PRESET_FULL360, 100.0, 100)),
+    "rectangular views": (1920, 960, [(float(y), float(p), 100.0, 70.0, 160, 90) for y, p in PRESET_FULL360]),
+    "weak minification (tiles cut into several plan tiles)": (960, 480, _family(PRESET_FULL360, HFOV_14MM, 400)),
+}
+
+
+@pytest.mark.parametrize("name", list(RING_FAMILIES))
+def test_ring_families(forced, orc, name):
+    W, H, specs = RING_FAMILIES[name]
+    _check(forced, orc, rand_image(H, W, seed=400 + len(name)), specs, name)
+
+
+def test_single_ring_at_weak_minification_is_cut_not_refused(forced, orc):
+    """0.6 source texels per output pixel: twenty times cfg2's plan entries per tile -- the builder cuts such tiles into plan tiles of
+    at most 32 KiB of entries instead of giving up"""
+    _check(forced, orc, rand_image(512, 1024, seed=271), ring_views(8, 1024, 150.0), "8 x 1024^2 from 1024 x 512")
+
+
+def test_ring_family_shuffled_frames_and_row_padding(forced, orc):
+    rng = np.random.default_rng(6)
+    W, H = 1920, 960
+    base = _family(PRESET_FULL360, HFOV_14MM, 200)
+    specs = [base[k] for k in rng.permutation(len(base))]
+    NV = len(specs)
+    frames = [rand_image(H, W, seed=420 + f) for f in range(2)]
+    d_src = [forced.to_device(f) for f in frames]
+    dstride = 200 * 3 + 12
+    d_out = [forced.alloc(dstride * 200 + 64) for _ in range(2 * NV)]
+    for b in d_out:
+        forced.memset(b, 0xCD)
+    forced.equirect_views_dev(d_src, W, H, 3, [gs360.View.make(*s) for s in specs], d_out, dst_stride=dstride)
+    forced.sync(0)
+    assert forced.get_option("last_eq_kernel") == 2
+    for f in range(2):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        for k in range(NV):
+            raw = forced.download(d_out[f * NV + k], (200, dstride))
+            assert np.array_equal(raw[:, :600].reshape(200, 200, 3), want[k]), (f, k)
+            assert np.all(raw[:, 600:] == 0xCD), "row padding written"
+    for b in d_src + d_out:
         forced.free(b)
+
+
+def test_ring_families_it_must_leave_to_the_gather_kernels(forced, orc):
+    src = rand_image(480, 960, seed=251)
+    lvl = [(90.0 * i, 0.0, 100.0, 100.0, 96, 96) for i in range(4)]
+    up = [(45 + 90.0 * i, 30.0, 100.0, 100.0, 96, 96) for i in range(4)]
+    # a pitched ring without its mirror (the evenPlus30 preset's shape, PC:616-644)
+    _check(forced, orc, src, lvl + up, "level ring + unpaired +30 ring", expect_kernel=0)
+    # the mirror ring on other yaws
+    _check(forced, orc, src, up + [(90.0 * i, -30.0, 100.0, 100.0, 96, 96) for i in range(4)], "pair on different yaws", expect_kernel=0)
+    # rings of different sizes
+    _check(forced, orc, src, lvl + [(60.0 * i, s * 30.0, 100.0, 100.0, 96, 96) for i in range(6) for s in (1, -1)], "4 + 6 + 6", expect_kernel=0)
+    # views over the poles (their quads are not monotone in longitude; rows clamp)
+    _check(forced, orc, src, [(90.0 * i, s * 60.0, 100.0, 100.0, 96, 96) for i in range(4) for s in (1, -1)], "pair over the poles", expect_kernel=0)
+    # one view of the pair with another field of view
+    odd = [(45 + 90.0 * i, -30.0, 100.0, 100.0 if i else 90.0, 96, 96) for i in range(4)]
+    _check(forced, orc, src, up + odd, "one vfov differs", expect_kernel=0)
 
 
 def test_auto_selection(ctx, orc):
