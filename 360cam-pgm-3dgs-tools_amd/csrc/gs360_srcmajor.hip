@@ -19,7 +19,7 @@
 // while eight consumer wavefronts render image g), with the tile's plan entries LDS-resident for all of them.
 //
 // Ownership is per output QUAD (four pixels = 12 bytes = three dwords, all rendered by the tile that holds the first pixel's taps), so
-// every store is a dword store and no output byte is written twice.  Plan entry: per quad a header (column | row << 12 | view << 24), per
+// every store is a dword store and no output byte is written twice.  Plan entry: per quad a header (3 x column | row << 14 | view << 26), per
 // pixel (LDS byte offset of the top-left tap | fx << 17 | fy << 22).
 //
 // Measured on MI355X (profiles/r05/srcmajor/): what bounds it is bytes moved -- tiles (64 MB per frame incl. the boxes' halos) + stores
@@ -40,7 +40,7 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void global_void_t;
 
-constexpr int kSmConsumers = 8;                         // consumer wavefronts per workgroup (+ one loader)
+constexpr int kSmConsumers = 8;                         // consumer wavefronts per workgroup (+ one loader); 12 and 15 exist for probes
 constexpr int kSmMaxImages = 12;                        // images of a tile one workgroup walks (G)
 
 // ---- plan coordinates: EQ-SPEC v1 for the first `rows` rows of view `vi` (a ring's reference member), every column by the general formula
@@ -75,7 +75,8 @@ struct SmArgs {
 };
 static_assert(sizeof(SmArgs) <= 4096, "SmArgs travels as a kernel argument");
 
-__global__ __launch_bounds__(64 * (kSmConsumers + 1)) void eq_srcmajor_kernel(const SmArgs P) {
+template <int CW>
+__global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
     __shared__ uint8_t* s_dst[kSmMaxImages * GS360_MAX_VIEWS];
     // XCD-aware order: XCD x (= block % 8) walks a contiguous chunk of the (frame, tile, image group) order, so the images of a tile,
@@ -158,11 +159,9 @@ __global__ __launch_bounds__(64 * (kSmConsumers + 1)) void eq_srcmajor_kernel(co
             const int lane_off = (flip ? (P.h - 1) * dstride : 0) + 4 * min(k4, 2);           // flipped image: rows run upwards from h - 1
             int cur_vrel = -1;
             uint64_t dbase = 0;
-            const uint8_t* pxp = reinterpret_cast<const uint8_t*>(e_px) + ((wave - 1) * 64 + lane) * 4;
-            const uint8_t* hdp = reinterpret_cast<const uint8_t*>(e_hdr) + (((wave - 1) * 64 + lane) >> 2) * 4;
-            for (int i0 = (wave - 1) * 64; i0 < npx; i0 += 64 * kSmConsumers, pxp += 256 * kSmConsumers, hdp += 64 * kSmConsumers) {
-                const uint32_t pw = *reinterpret_cast<const uint32_t*>(pxp);
-                const uint32_t hd = *reinterpret_cast<const uint32_t*>(hdp);
+            auto turn = [&](const uint8_t* const pp, const uint8_t* const hp) {
+                const uint32_t pw = *reinterpret_cast<const uint32_t*>(pp);
+                const uint32_t hd = *reinterpret_cast<const uint32_t*>(hp);
                 const int fx = (pw >> 17) & 31, fy = (pw >> 22) & 31;
                 const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (pw & 0x1fffcu));
                 const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (pw & 0x1fffcu) + pitch);
@@ -172,23 +171,34 @@ __global__ __launch_bounds__(64 * (kSmConsumers + 1)) void eq_srcmajor_kernel(co
                 t1.x = __builtin_amdgcn_alignbyte(b1, b0, pw); t1.y = __builtin_amdgcn_alignbyte(b2, b1, pw);
                 uint32_t px[3];
                 blend_rgb_rows(t0, t1, fx, fy, px);
-                const uint32_t pk = px[0] | (px[1] << 8) | (px[2] << 16);
+                uint32_t pk;                             // r | g << 8 | b << 16 in two instructions (the compiler prefers two shifts and a three-way or)
+                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(pk) : "v"(px[1]), "v"(px[0]));
+                asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(pk) : "v"(px[2]), "v"(pk));
                 // lanes 4m .. 4m + 3 hold a quad: lane k cuts dword k of its 12 bytes out of pixels k and k + 1
-                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp((int)pk, (int)pk, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, true);          // quad_perm [1,2,3,3]
                 const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
                 // the turn's view (wave-uniform by construction of the plan): its destination base is reloaded only when the view changes
-                const int vrel = __builtin_amdgcn_readfirstlane((int)(hd >> 24)) & 15;
+                const int vrel = __builtin_amdgcn_readfirstlane((int)(hd >> 26));
                 if (vrel != cur_vrel) {                  // scalar compare + branch: a tile has two or three view groups
-                    const uint2 dq = *reinterpret_cast<const uint2*>(&s_dst[g * GS360_MAX_VIEWS + vrel]);
+                    const uint2 dq = *reinterpret_cast<const uint2*>(&s_dst[g * GS360_MAX_VIEWS + (vrel & 15)]);
                     dbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)dq.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)dq.x);
                     cur_vrel = vrel;
                 }
-                const int roff = __mul24((int)((hd >> 12) & 0xfffu), row_step) + lane_off;          // v_mad_i32_i24
-                const uint32_t off = __umul24(hd & 0xfffu, 3u) + (uint32_t)roff;                    // v_mad_u32_u24
+                // header: 3 x column | row << 14 | view << 26
+                const uint32_t off = (hd & 0x3fffu) + (uint32_t)(__mul24((int)((hd >> 14) & 0xfffu), row_step) + lane_off);
                 // lane 3 repeats lane 2's store (same dword, same address): an UNCONDITIONAL store keeps the loop body straight-line
-                const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp((int)dw, (int)dw, 0xA4, 0xf, 0xf, false);    // quad_perm [0,1,2,2]
-                *(__attribute__((address_space(1))) uint32_t*)(dbase + off) = dwq;             // global store, scalar base + 32-bit offset
+                const uint32_t dwq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw, 0xA4, 0xf, 0xf, true);           // quad_perm [0,1,2,2]
+                *(__attribute__((address_space(1))) uint32_t*)(dbase + off) = dwq;                 // global store, scalar base + 32-bit offset
+            };
+            // two turns per trip: the second one's entry addresses are immediate offsets of the first one's
+            const uint8_t* pxp = reinterpret_cast<const uint8_t*>(e_px) + ((wave - 1) * 64 + lane) * 4;
+            const uint8_t* hdp = reinterpret_cast<const uint8_t*>(e_hdr) + (((wave - 1) * 64 + lane) >> 2) * 4;
+            int i0 = (wave - 1) * 64;
+            for (; i0 + 64 * CW < npx; i0 += 128 * CW, pxp += 512 * CW, hdp += 128 * CW) {
+                turn(pxp, hdp);
+                turn(pxp + 256 * CW, hdp + 64 * CW);
             }
+            if (i0 < npx) turn(pxp, hdp);
         }
         __builtin_amdgcn_s_barrier();                    // image g + 1 has landed AND every consumer is done with image g's buffer
     }
@@ -323,7 +333,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
             uint32_t* px = hdr + nqp;
             for (int q = 0; q < nqp; ++q) {
                 const Quad& Q = *list[c0 + q];
-                hdr[q] = (uint32_t)Q.i0 | ((uint32_t)Q.j << 12) | ((uint32_t)Q.vslot << 24);
+                hdr[q] = (uint32_t)(3 * Q.i0) | ((uint32_t)Q.j << 14) | ((uint32_t)Q.vslot << 26);
                 for (int k = 0; k < 4; ++k)
                     px[4 * q + k] = (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0)) | ((uint32_t)Q.ph[k] << 17);
             }
@@ -427,8 +437,8 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, S
 
 // Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
 // Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, size_t lds_limit, int n_cu, hipStream_t s,
-              hipError_t* herr) {
+int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, int waves, size_t lds_limit, int n_cu,
+              hipStream_t s, hipError_t* herr) {
     const EqView& V = L.view[0];
     const int N = S.N, NV = L.n_views;
     *herr = hipSuccess;
@@ -492,9 +502,14 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
     P.src_stride = L.src_stride;
     P.dst_stride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
     const size_t lds = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes;
-    *herr = hipFuncSetAttribute((const void*)eq_srcmajor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
+    auto go = [&](auto kernel, int cw) {
+        *herr = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
+        if (*herr == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)(P.gchunk * 8)), dim3(64 * (cw + 1)), lds, s, P);
+    };
+    if (waves == 12) go(eq_srcmajor_kernel<12>, 12);
+    else if (waves == 15) go(eq_srcmajor_kernel<15>, 15);
+    else go(eq_srcmajor_kernel<kSmConsumers>, kSmConsumers);
     if (*herr != hipSuccess) return -1;
-    hipLaunchKernelGGL(eq_srcmajor_kernel, dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
     *herr = hipGetLastError();
     return *herr == hipSuccess ? 0 : -1;
 }

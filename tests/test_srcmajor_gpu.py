@@ -133,6 +133,8 @@ RING_FAMILIES = {
     "mirror pair alone": (960, 480, _family([(10 + 90 * i, s * 25) for i in range(4) for s in (1, -1)], 90.0, 120)),
     "level + two pairs, own yaw phases": (1440, 720, _family([(120 * i, 0) for i in range(3)] + [(17.5 + 120 * i, s * 20) for i in range(3) for s in (1, -1)]
                                                               + [(60 + 120 * i, s * 50) for i in range(3) for s in (-1, 1)], 60.0, 96)),
+    "rings of 4 + 6 + 6 views = eight rings of two": (960, 480, [(90.0 * i, 0.0, 100.0, 100.0, 96, 96) for i in range(4)]
+                                                       + [(60.0 * i, s * 30.0, 100.0, 100.0, 96, 96) for i in range(6) for s in (1, -1)]),
     "odd source height": (960, 479, _family(PRESET_FULL360, 100.0, 100)),
     "rectangular views": (1920, 960, [(float(y), float(p), 100.0, 70.0, 160, 90) for y, p in PRESET_FULL360]),
     "weak minification (tiles cut into several plan tiles)": (960, 480, _family(PRESET_FULL360, HFOV_14MM, 400)),
@@ -184,8 +186,8 @@ def test_ring_families_it_must_leave_to_the_gather_kernels(forced, orc):
     _check(forced, orc, src, lvl + up, "level ring + unpaired +30 ring", expect_kernel=0)
     # the mirror ring on other yaws
     _check(forced, orc, src, up + [(90.0 * i, -30.0, 100.0, 100.0, 96, 96) for i in range(4)], "pair on different yaws", expect_kernel=0)
-    # rings of different sizes
-    _check(forced, orc, src, lvl + [(60.0 * i, s * 30.0, 100.0, 100.0, 96, 96) for i in range(6) for s in (1, -1)], "4 + 6 + 6", expect_kernel=0)
+    # rings whose sizes share no divisor (4 + 3 + 3)
+    _check(forced, orc, src, lvl + [(120.0 * i, s * 30.0, 100.0, 100.0, 96, 96) for i in range(3) for s in (1, -1)], "4 + 3 + 3", expect_kernel=0)
     # views over the poles (their quads are not monotone in longitude; rows clamp)
     _check(forced, orc, src, [(90.0 * i, s * 60.0, 100.0, 100.0, 96, 96) for i in range(4) for s in (1, -1)], "pair over the poles", expect_kernel=0)
     # one view of the pair with another field of view
