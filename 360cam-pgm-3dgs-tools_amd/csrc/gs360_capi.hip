@@ -31,6 +31,8 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr size_t kSmPlanCap = 4;
 constexpr size_t kSmLdsPerGroup = 80 * 1024;   // two workgroups of the source-major kernel per CU (160 KiB of LDS)
+constexpr int kSmFamilyMinFrames = 4;          // automatic selection of the source-major kernel for calls of several rings: frames per call ...
+constexpr int kSmMaxBoxPct = 175;              // ... and tile boxes at most this large relative to their grid cells (profiles/r05/srcmajor_family_sweep.txt)
 
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \
@@ -89,6 +91,7 @@ struct gs360_ctx {
     // Options (gs360_ctx_set_option; seeded ONCE from the environment by gs360_ctx_create for the documented user switches).  The hot
     // path reads these atomics, never the environment: getenv racing a host thread's putenv is undefined behaviour.
     std::atomic<int> opt[kOptCount];
+    std::atomic<int> last_sm_box_pct{0};      // read-only option "last_srcmajor_box_pct": tile-box bytes of the last source-major plan in % of its grid cells
     std::atomic<int> last_eq_kernel{-1};      // read-only option "last_eq_kernel": 0 gather, 1 LDS-staged, 2 source-major (which kernel the last equirect call launched)
     // source-major plans of this context (gs360_srcmajor.hip), most recent calls' geometries
     std::mutex sm_mutex;
@@ -445,6 +448,10 @@ int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
         *value = c->last_eq_kernel.load(std::memory_order_relaxed);
         return GS360_OK;
     }
+    if (!std::strcmp(key, "last_srcmajor_box_pct")) {
+        *value = c->last_sm_box_pct.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
     for (int k = 0; k < kOptCount; ++k)
         if (!std::strcmp(key, kOpts[k].key)) {
             *value = c->opt[k].load(std::memory_order_relaxed);
@@ -697,13 +704,6 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     if (opt_srcmajor != 0 && !mask_frames && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 &&
         n_views <= GS360_MAX_VIEWS) {
         bool ring = true;
-        if (opt_srcmajor < 0) {
-            const double hf = clampd(views[0].hfov_deg, 1e-3, 179.9) * kPi / 180.0;
-            const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[0].width;
-            bool level = true;
-            for (int k = 0; k < n_views; ++k) level = level && ev[k].level;
-            ring = level && n_frames >= 2 && n_views >= 5 && step >= (n_views >= 6 ? 1.5 : 2.25);
-        }
         SmShape shape;
         std::vector<EqLaunch> Ls;
         for (int f0 = 0; f0 < n_frames && ring; f0 += GS360_MAX_FRAMES) {
@@ -724,13 +724,21 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             ring = sm_eligible(L, C, esize, interp, false, &shape);     // (the shape depends on the views only: the same for every chunk)
             Ls.push_back(L);
         }
+        if (ring && opt_srcmajor < 0) {
+            const double hf = clampd(views[0].hfov_deg, 1e-3, 179.9) * kPi / 180.0;
+            const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[0].width;
+            if (shape.n_rings == 1) ring = n_frames >= 2 && shape.N >= 5 && step >= (shape.N >= 6 ? 1.5 : 2.25);
+            else ring = n_frames >= kSmFamilyMinFrames && n_views >= 8 && step >= 1.75;
+        }
         for (size_t i = 0; i < Ls.size() && ring; ++i) {
             hipError_t he = hipSuccess;
-            int rc;
+            int rc, box_pct = 0;
             {
                 std::lock_guard<std::mutex> lock(c->sm_mutex);
                 rc = sm_launch(Ls[i], shape, c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
-                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), c->opt[kOptSrcMajorWaves].load(std::memory_order_relaxed), kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he);
+                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), c->opt[kOptSrcMajorWaves].load(std::memory_order_relaxed),
+                               opt_srcmajor < 0 ? kSmMaxBoxPct : 0, kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he, &box_pct);
+                c->last_sm_box_pct.store(box_pct, std::memory_order_relaxed);
             }
             if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));
             if (rc == 1 && i == 0) ring = false;         // the geometry does not fit the plan format (decided by the first chunk: nothing launched yet)

@@ -216,6 +216,7 @@ struct SmPlan {
     SmTile* d_tiles = nullptr;
     uint32_t* d_entries = nullptr;
     int n_tiles = 0, buf_bytes = 0, ent_bytes = 0, PB = 0;
+    int box_pct = 0;                       // bytes of all tile boxes in percent of the tile grid cells they stand for (halos, cut tiles)
     uint64_t stamp = 0;
 };
 
@@ -295,6 +296,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
     std::vector<uint32_t> ent;
     std::vector<const Quad*> list;
     int buf_bytes = 0, ent_bytes = 0, n_boxes = 0;
+    long long box_sum = 0;
     for (size_t a = 0; a < quads.size();) {
         size_t b = a;
         while (b < quads.size() && quads[b].tid == quads[a].tid) ++b;
@@ -338,6 +340,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
                     px[4 * q + k] = (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0)) | ((uint32_t)Q.ph[k] << 17);
             }
             buf_bytes = std::max(buf_bytes, T.nrows * pitch);
+            box_sum += (long long)T.nrows * pitch;
             ent_bytes = std::max(ent_bytes, 20 * nqp);
             tiles.push_back(T);
         }
@@ -351,6 +354,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
     SmPlan* p = new (std::nothrow) SmPlan();
     if (!p) { *herr = hipErrorOutOfMemory; return -1; }
     p->n_tiles = (int)tiles.size(); p->buf_bytes = buf_bytes; p->ent_bytes = ent_bytes; p->PB = PB;
+    p->box_pct = (int)(100 * box_sum / ((long long)n_boxes * std::min(Bx, PB) * R));
     *herr = hipMalloc((void**)&p->d_tiles, tiles.size() * sizeof(SmTile));
     if (*herr == hipSuccess) *herr = hipMalloc((void**)&p->d_entries, ent.size() * 4 + 1024);      // (slack: the entry copy reads whole 16-byte chunks)
     if (*herr == hipSuccess) *herr = hipMemcpyAsync(p->d_tiles, tiles.data(), tiles.size() * sizeof(SmTile), hipMemcpyHostToDevice, s);
@@ -437,8 +441,8 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, S
 
 // Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
 // Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, int waves, size_t lds_limit, int n_cu,
-              hipStream_t s, hipError_t* herr) {
+int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, int waves, int max_box_pct,
+              size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* box_pct) {
     const EqView& V = L.view[0];
     const int N = S.N, NV = L.n_views;
     *herr = hipSuccess;
@@ -473,6 +477,8 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
     for (SmPlan* p : cache) newest = std::max(newest, p->stamp);
     plan->stamp = newest + 1;      // (the caller holds the context's plan lock)
     if (plan->n_tiles == 0) return 1;                    // a geometry known not to fit: the gather kernels
+    *box_pct = plan->box_pct;
+    if (max_box_pct > 0 && plan->box_pct > max_box_pct) return 1;     // (automatic selection only) boxes far larger than their grid cells: views stretched towards a pole
     SmArgs P;
     std::memset(&P, 0, sizeof(P));
     for (int f = 0; f < L.n_frames; ++f) P.src[f] = L.src[f];
