@@ -32,7 +32,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr size_t kSmPlanCap = 4;
 constexpr size_t kSmLdsPerGroup = 80 * 1024;   // two workgroups of the source-major kernel per CU (160 KiB of LDS)
 constexpr int kSmFamilyMinFrames = 4;          // automatic selection of the source-major kernel for calls of several rings: frames per call ...
-constexpr int kSmMaxBoxPct = 175;              // ... and tile boxes at most this large relative to their grid cells (profiles/r05/srcmajor_family_sweep.txt)
+constexpr int kSmMaxBoxPct = 160;              // ... and tile boxes at most this large relative to their grid cells (profiles/r05/srcmajor_family_sweep.txt)
 
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \

@@ -225,6 +225,37 @@ def test_auto_selection(ctx, orc):
         ctx.free(b)
 
 
+def test_auto_selection_of_ring_families(ctx, orc):
+    """several rings in one call (profiles/r05/srcmajor_family_sweep.txt): taken from four frames per call, eight views and 1.75 source
+    texels per output pixel, unless the views reach so close to a pole that the tile boxes outgrow their grid cells"""
+    W, H = 1920, 960
+    frames = [rand_image(H, W, seed=280 + f) for f in range(4)]
+    d_src = [ctx.to_device(f) for f in frames]
+
+    def kernel_for(specs, n_frames):
+        d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(n_frames) for s in specs]
+        ctx.equirect_views_dev(d_src[:n_frames], W, H, 3, [gs360.View.make(*s) for s in specs], d_out)
+        ctx.sync(0)
+        want = orc.equirect_views_u8(frames[n_frames - 1], [orc.make_view(*s) for s in specs], threads=0)
+        for k, s in enumerate(specs):
+            assert np.array_equal(ctx.download(d_out[(n_frames - 1) * len(specs) + k], (s[5], s[4], 3)), want[k])
+        for b in d_out:
+            ctx.free(b)
+        return ctx.get_option("last_eq_kernel")
+    full = _family(PRESET_FULL360, HFOV_14MM, 400)            # 1.96 texels per pixel
+    with ctx.options(srcmajor=-1):
+        assert kernel_for(full, 4) == 2
+        assert kernel_for(full, 3) != 2                      # fewer than four frames
+        assert kernel_for(_family(PRESET_FULL360, HFOV_14MM, 520), 4) != 2                      # 1.51 texels per pixel
+        assert kernel_for(_family(PRESET_FISHEYELIKE, HFOV_17MM, 256), 4) == 2                  # five rings of two at 2.5
+        assert kernel_for(_family([(120 * i, s * 30) for i in range(3) for s in (1, -1)], 100.0, 200), 4) != 2                 # a pair of three: six views
+        poles = [(90.0 * i, 0.0, 90.0, 90.0, 256, 256) for i in range(4)] + [(45 + 90.0 * i, s * 45.0, 90.0, 90.0, 256, 256) for i in range(4) for s in (1, -1)]
+        assert kernel_for(poles, 4) != 2                     # top edges on the poles: boxes 169 % of their cells
+        assert ctx.get_option("last_srcmajor_box_pct") > 160
+    for b in d_src:
+        ctx.free(b)
+
+
 def test_cfg2_full_size_sixteen_frames_every_byte(ctx, orc):
     """BASELINE configs[1] as bench.py launches it: 16 distinct 8K frames x 6 x 800^2 in one call, every byte of all 96 views"""
     W, H, N = 7680, 3840, 6
@@ -240,6 +271,28 @@ def test_cfg2_full_size_sixteen_frames_every_byte(ctx, orc):
         want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
         for k in range(N):
             got = ctx.download(d_out[f * N + k], (800, 800, 3))
+            assert np.array_equal(got, want[k]), f"frame {f} view {k}"
+    for b in d_src + d_out:
+        ctx.free(b)
+
+
+def test_cfg3_full_size_four_frames_every_byte(ctx, orc):
+    """BASELINE configs[2]'s view set as the resident-job bench launches it: 8K frames x full360coverage 12 x 1600^2 (a level ring of
+    four and the +30 / -30 pair), automatic selection, every byte of all 48 views"""
+    W, H = 7680, 3840
+    specs = _family(PRESET_FULL360, HFOV_14MM, 1600)
+    NV = len(specs)
+    frames = [rand_image(H, W, seed=320 + f) for f in range(4)]
+    d_src = [ctx.to_device(f) for f in frames]
+    d_out = [ctx.alloc(1600 * 1600 * 3) for _ in range(4 * NV)]
+    with ctx.options(srcmajor=-1):
+        ctx.equirect_views_dev(d_src, W, H, 3, [gs360.View.make(*s) for s in specs], d_out)
+        ctx.sync(0)
+        assert ctx.get_option("last_eq_kernel") == 2
+    for f in range(4):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        for k in range(NV):
+            got = ctx.download(d_out[f * NV + k], (1600, 1600, 3))
             assert np.array_equal(got, want[k]), f"frame {f} view {k}"
     for b in d_src + d_out:
         ctx.free(b)

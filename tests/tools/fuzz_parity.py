@@ -107,20 +107,33 @@ def fuzz_equirect(ctx, rng, case):
 
 
 def fuzz_srcmajor(ctx, rng, case):
-    """Level yaw rings that fill their circle -- the shape the source-major kernel takes (count | W, (3 W / count) % 16 == 0, view width
-    % 4 == 0): random counts, panorama sizes, fields of view (strong and weak minification), view sizes incl. odd heights, yaw offsets
-    that are NOT whole texels, view orders, several frames, padded destination rows.  The option "srcmajor" decides whether the kernel
-    is actually taken (1: whenever the geometry fits); the result must be the oracle's either way."""
-    count = int(rng.choice([2, 3, 4, 5, 6, 8, 12, 16]))
-    unit = 16 * count // int(np.gcd(16 * count, 3 * 1)) if False else 16 * count        # W multiple of 16 * count keeps both divisibility rules
+    """Yaw rings that fill their circle -- the shapes the source-major kernel takes (count | W, (3 W / count) % 16 == 0, view width
+    % 4 == 0): one level ring, or a FAMILY of rings of one size (a level ring and / or pitched rings that come with their mirror ring at
+    minus the pitch, each pair on its own yaw phase; sometimes a ring left WITHOUT its mirror: the call must then fall back).  Random
+    counts, panorama sizes, fields of view (strong and weak minification), pitches up to views that touch the poles, view sizes incl.
+    odd heights, yaw offsets that are NOT whole texels, view orders, several frames, padded destination rows.  The option "srcmajor"
+    decides whether the kernel is actually taken (1: whenever the geometry fits); the result must be the oracle's either way."""
+    family = rng.random() < 0.5
+    count = int(rng.choice([2, 3, 4, 5] if family else [2, 3, 4, 5, 6, 8, 12, 16]))
+    unit = 16 * count                                    # W multiple of 16 * count keeps both divisibility rules
     W = unit * int(rng.integers(1, max(2, 2200 // unit)))
     H = int(rng.choice([W // 2, int(rng.integers(max(2, W // 4), W))]))
     w = 4 * int(rng.integers(2, 60))
     h = int(rng.integers(2, 200))
     hf = float(rng.uniform(20, 170)); vf = float(rng.choice([hf, float(rng.uniform(20, 170))]))
     off = float(rng.choice([0.0, 0.0, 360.0 / W * int(rng.integers(0, W)), float(rng.uniform(-180, 180))]))
-    order = rng.permutation(count)
-    specs = [(off + int(q) * 360.0 / count, 0.0, hf, vf, w, h) for q in order]
+    specs = [(off + q * 360.0 / count, 0.0, hf, vf, w, h) for q in range(count)] if (not family or rng.random() < 0.6) else []
+    if family:
+        pairs = int(rng.integers(1, max(2, (16 - len(specs)) // (2 * count) + 1)))
+        for _ in range(pairs):
+            if len(specs) + 2 * count > 16:
+                break
+            pitch = float(rng.choice([30.0, float(rng.uniform(1, 85))]))
+            ph = float(rng.choice([0.0, 180.0 / count, float(rng.uniform(0, 360))]))
+            signs = (1, -1) if rng.random() < 0.9 else (1,)       # (now and then a ring without its mirror)
+            specs += [(off + ph + q * 360.0 / count, sg * pitch, hf, vf, w, h) for q in range(count) for sg in signs]
+    specs = [specs[int(q)] for q in rng.permutation(len(specs))]
+    count = len(specs)
     nf = int(rng.choice([1, 1, 2, 3]))
     frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(nf)]
     d_src = [ctx.to_device(f) for f in frames]
