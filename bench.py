@@ -308,7 +308,8 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
                        "parallelism": f"frames sharded x{world}, no collective", "parity_vs_oracle": parity,
                        "frames_per_s": round(args.job_frames / elapsed, 1), "per_rank_seconds": per_rank,
                        "seconds_incl_closing_barrier": round(with_barrier, 6),
-                       "rank0_kernel_us_per_frame": round(kernel_ms * 1e3 / max(1, len(mine)), 2)},
+                       "rank0_kernel_us_per_frame": round(kernel_ms * 1e3 / max(1, len(mine)), 2),
+                       "rank0_eq_kernel": EQ_KERNEL_NAMES.get(ctx.get_option("last_eq_kernel"), "?")},
             "roofline": None, "cpu_baseline": None,
         })
 

@@ -82,6 +82,7 @@ def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LI
     else:
         fp_call = ctx.make_equirect_call(d_fr, W, H, 3, views, d_out, slot=0, interp=interp)
     ms = time_steps(ctx, fp_call, steps)
+    eq_kernel = {0: "gather", 1: "lds-staged", 2: "source-major"}.get(ctx.get_option("last_eq_kernel"), "?")
     # parity of one view of frame 0, algorithmic bytes from the oracle
     k = len(specs) // 2
     got = ctx.download(d_out[k], (specs[k][5], specs[k][4], 3))
@@ -96,7 +97,7 @@ def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LI
             "ms_per_launch": round(ms, 4), "us_per_frame": round(ms / n_frames * 1e3, 1),
             "MPix_per_s": round(out_px * n_frames / ms / 1e3, 0), "algorithmic_MB_per_frame": round(algo / n_frames / 1e6, 1),
             "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
-            "parity_vs_oracle": bool(np.array_equal(got, want))}
+            "eq_kernel": eq_kernel, "parity_vs_oracle": bool(np.array_equal(got, want))}
 
 
 def equirect_u16_cfg(ctx, name, W, H, specs, n_frames, steps, interp):
