@@ -48,7 +48,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 // context options: name, default, range, environment seed (user switches only)
 enum Opt { kOptLanemap, kOptStage, kOptRing, kOptXcdGroup, kOptEqPersist, kOptTablePersist, kOptLanczosTable, kOptTableRows, kOptColorCube,
-           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptSrcMajorWaves, kOptCount };
+           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptCount };
 struct OptDesc { const char* key; int def, lo, hi; const char* env; };
 const OptDesc kOpts[kOptCount] = {
     {"lanemap", -1, -1, 1, "GS360_LANEMAP"},          // -1 auto (per view, by minification), 0 rows, 1 blocked       (env: rows | blocked)
@@ -64,7 +64,6 @@ const OptDesc kOpts[kOptCount] = {
     {"srcmajor_bx", 768, 256, 4032, nullptr},         // its tile: bytes per box row (multiple of 16) ...
     {"srcmajor_rows", 32, 8, 128, nullptr},           // ... and source rows
     {"srcmajor_images", 0, 0, 12, nullptr},           // images of a tile one workgroup walks (0 auto; must divide twice the ring size)
-    {"srcmajor_waves", 8, 8, 15, nullptr},            // consumer wavefronts per workgroup (8; 12 and 15 are built for probes)
 };
 
 struct Staging {  // per-slot device staging used by the *_host conveniences
@@ -736,7 +735,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             {
                 std::lock_guard<std::mutex> lock(c->sm_mutex);
                 rc = sm_launch(Ls[i], shape, c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
-                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), c->opt[kOptSrcMajorWaves].load(std::memory_order_relaxed),
+                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed),
                                opt_srcmajor < 0 ? kSmMaxBoxPct : 0, kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he, &box_pct);
                 c->last_sm_box_pct.store(box_pct, std::memory_order_relaxed);
             }

@@ -40,7 +40,8 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void global_void_t;
 
-constexpr int kSmConsumers = 8;                         // consumer wavefronts per workgroup (+ one loader); 12 and 15 exist for probes
+constexpr int kSmConsumers = 8;                         // consumer wavefronts per workgroup (+ one loader).  12: +14 .. +25 %, 15: no change
+                                                        // (cfg1 / cfg2 / cfg3, profiles/r05/srcmajor/run32_consumer_waves.log)
 constexpr int kSmMaxImages = 12;                        // images of a tile one workgroup walks (G)
 
 // ---- plan coordinates: EQ-SPEC v1 for the first `rows` rows of view `vi` (a ring's reference member), every column by the general formula
@@ -441,7 +442,7 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, S
 
 // Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
 // Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, int waves, int max_box_pct,
+int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, int max_box_pct,
               size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* box_pct) {
     const EqView& V = L.view[0];
     const int N = S.N, NV = L.n_views;
@@ -508,14 +509,9 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
     P.src_stride = L.src_stride;
     P.dst_stride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
     const size_t lds = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes;
-    auto go = [&](auto kernel, int cw) {
-        *herr = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
-        if (*herr == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)(P.gchunk * 8)), dim3(64 * (cw + 1)), lds, s, P);
-    };
-    if (waves == 12) go(eq_srcmajor_kernel<12>, 12);
-    else if (waves == 15) go(eq_srcmajor_kernel<15>, 15);
-    else go(eq_srcmajor_kernel<kSmConsumers>, kSmConsumers);
+    *herr = hipFuncSetAttribute((const void*)eq_srcmajor_kernel<kSmConsumers>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
     if (*herr != hipSuccess) return -1;
+    hipLaunchKernelGGL(eq_srcmajor_kernel<kSmConsumers>, dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
     *herr = hipGetLastError();
     return *herr == hipSuccess ? 0 : -1;
 }

@@ -100,8 +100,7 @@ int gs360_device_pci_bus_id(gs360_ctx *ctx, char *buf, size_t buf_len);
  *   "srcmajor"       -1 auto | 0 never | 1 always       source-major equirect kernel (yaw rings of one size, level or in +/- pitch pairs:
  *                                                       the default / full360coverage / fisheyelike presets); "srcmajor_bx" (bytes per tile row,
  *                                                       multiple of 16), "srcmajor_rows" (source rows per tile), "srcmajor_images"
- *                                                       (0 auto | 1..12 dividing twice the ring size: images of a tile one workgroup walks),
- *                                                       "srcmajor_waves" (8 | 12 | 15 consumer wavefronts per workgroup: probes)
+ *                                                       (0 auto | 1..12 dividing twice the ring size: images of a tile one workgroup walks)
  *   "ring"           0 auto | n                         at most n views share one coordinate evaluation
  *   "xcd_group"      -2 auto | -1 chunks | g            tile order across the XCDs
  *   "eq_persist", "table_persist"                       grid caps of the persistent kernels (table_persist: -1 auto)

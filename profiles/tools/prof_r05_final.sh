@@ -40,6 +40,7 @@ python bench.py --mode job > $OUT/bench_job600_1gpu.json 2> $OUT/bench_job.err
 python profiles/tools/srcmajor/sweep_capi.py > $OUT/srcmajor_tile_sweep.txt 2>&1
 python profiles/tools/srcmajor/sweep_rings.py > $OUT/srcmajor_other_rings.txt 2>&1
 python profiles/tools/srcmajor/sweep_frames.py > $OUT/srcmajor_frames_sweep.txt 2>&1
+python profiles/tools/srcmajor/sweep_families.py 4 16 > $OUT/srcmajor_family_sweep.txt 2>&1
 (for spec in "" "lanemap=0" "lanemap=1" "ring=1" "lanemap=0 stage=1" "lanemap=0 stage=1 ring=2" "srcmajor=1" "srcmajor=1 --only srcmajor"; do
    args=""; for o in $spec; do case $o in --only) args="$args --only";; srcmajor) args="$args srcmajor";; *=*) args="$args --option $o";; esac; done
    echo "== options: ${spec:-defaults}"; timeout 400 python tests/tools/fuzz_parity.py --seconds 90 --seed 5$RANDOM $args | tail -1; done) > $OUT/fuzz_campaign.txt 2>&1
