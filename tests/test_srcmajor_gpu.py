@@ -178,6 +178,26 @@ def test_ring_family_shuffled_frames_and_row_padding(forced, orc):
         forced.free(b)
 
 
+@pytest.mark.parametrize("shape", ["ring", "family"])
+def test_more_frames_than_one_launch_holds(forced, orc, shape):
+    """18 frames in one call: the library cuts them into launches of GS360_MAX_FRAMES (16 + 2), one plan"""
+    W, H = 960, 480
+    specs = ring_views(6, 64, 100.0) if shape == "ring" else _family(PRESET_FULL360, 100.0, 64)
+    NV, nf = len(specs), 18
+    frames = [rand_image(H, W, seed=500 + f) for f in range(nf)]
+    d_src = [forced.to_device(f) for f in frames]
+    d_out = [forced.alloc(64 * 64 * 3) for _ in range(nf * NV)]
+    forced.equirect_views_dev(d_src, W, H, 3, [gs360.View.make(*s) for s in specs], d_out)
+    forced.sync(0)
+    assert forced.get_option("last_eq_kernel") == 2
+    for f in range(nf):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        for k in range(NV):
+            assert np.array_equal(forced.download(d_out[f * NV + k], (64, 64, 3)), want[k]), (f, k)
+    for b in d_src + d_out:
+        forced.free(b)
+
+
 def test_ring_families_it_must_leave_to_the_gather_kernels(forced, orc):
     src = rand_image(480, 960, seed=251)
     lvl = [(90.0 * i, 0.0, 100.0, 100.0, 96, 96) for i in range(4)]
