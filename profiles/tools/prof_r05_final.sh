@@ -44,4 +44,6 @@ python profiles/tools/srcmajor/sweep_families.py 4 16 > $OUT/srcmajor_family_swe
 (for spec in "" "lanemap=0" "lanemap=1" "ring=1" "lanemap=0 stage=1" "lanemap=0 stage=1 ring=2" "srcmajor=1" "srcmajor=1 --only srcmajor"; do
    args=""; for o in $spec; do case $o in --only) args="$args --only";; srcmajor) args="$args srcmajor";; *=*) args="$args --option $o";; esac; done
    echo "== options: ${spec:-defaults}"; timeout 400 python tests/tools/fuzz_parity.py --seconds 90 --seed 5$RANDOM $args | tail -1; done) > $OUT/fuzz_campaign.txt 2>&1
+bash profiles/tools/srcmajor/pmc_cfg.sh cfg3 1 > $OUT/pmc_cfg3_srcmajor.txt 2>&1
+bash profiles/tools/srcmajor/pmc_cfg.sh cfg3 0 > $OUT/pmc_cfg3_staged.txt 2>&1
 cat $OUT/kernel_stats.csv | cut -c1-160; head -c 600 $OUT/bench_plain.json; echo; cat $OUT/fuzz_campaign.txt
