@@ -461,6 +461,8 @@ def main():
     # settle: the same launches, untimed, until the device has been busy for --settle-ms (clocks ramp over the first ~100 ms of
     # load: with 5 warm-up steps = 1.6 ms alone the 20 timed steps that follow run 6 % slower than in steady state), then the
     # caller's W warm-up steps
+    step()                                     # (first call apart: it builds the source-major plan on the host)
+    ctx.sync(0)
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         for _ in range(8):

@@ -43,6 +43,8 @@ SETTLE_MS = float(os.environ.get("GS360_BENCH_SETTLE_MS", "100"))
 
 
 def time_steps(ctx, call, steps, warmup=5):
+    call()                                      # first call apart: it may build a plan on the host (source-major: up to 0.2 s), which must
+    ctx.sync(-1)                                # not count as device-busy time of the settle phase
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < SETTLE_MS:
         for _ in range(4):
