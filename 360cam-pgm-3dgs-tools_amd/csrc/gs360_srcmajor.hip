@@ -1,29 +1,34 @@
-// gs360_srcmajor.hip -- source-major equirect kernel for strongly minified level yaw rings (BASELINE cfg2: 8K -> 6 x 800^2).
+// gs360_srcmajor.hip -- source-major equirect kernel for calls whose views are yaw rings: BASELINE cfg2 (8K -> 6 x 800^2), the `default`
+// preset's ring of eight, `full360coverage`'s level ring of four with its +30 / -30 rings (PC:616-680, PC:794-822).
 //
-// The gather kernels (gs360_kernels.hip) fetch, per view, every 128-byte source line a view's taps touch: at 4.6 source texels per
+// The gather kernels (gs360_kernels.hip) fetch, per view, every 128-byte source line a view's taps touch: at cfg2's 4.6 source texels per
 // output pixel that is 718 k lines per 8K frame for six views whose UNION is 413 k lines (a view uses 6 of every 14 bytes of a line and
 // neighbouring views of a ring overlap by half their field).  Here the work is cut along the SOURCE instead: a workgroup owns a tile of
-// the panorama (a box of ~768 bytes x ~32 rows), streams it ONCE into LDS with global_load_lds_dwordx4 and renders, for every view that
+// the panorama (a box of ~768 bytes x 16-32 rows), streams it ONCE into LDS with global_load_lds_dwordx4 and renders, for every view that
 // looks at it, the output pixels whose tap pair starts inside it -- from a static plan.  Replaces the same call sites as the gather
-// kernel (one `ffmpeg -vf v360` process per (frame, view), gs360_360PerspCut.py:310-314; the yaw ring of PC:794 is what makes views
-// overlap), results bit-identical: coordinates come from the EQ-SPEC functions themselves (eq_plan_coords_kernel), the blend is the
-// gather kernels' blend.
+// kernel (one `ffmpeg -vf v360` process per (frame, view), gs360_360PerspCut.py:310-314), results bit-identical: coordinates come from
+// the EQ-SPEC functions themselves (eq_plan_coords_kernel), the blend is the gather kernels' blend.
 //
 // What makes one plan serve a whole call:
-//   * a level ring of N equally spaced views is periodic in the source: member q sees what member 0 sees, d = W / N texels further
-//     (x0i32 differs by whole multiples of 32 d, everything else is equal), so the plan lists only period 0 -- source bytes [0, 3 d) of
-//     every row -- with the view index relative to the period; period k renders view (rel + k) mod N;
-//   * the lower half of a level view is the upper half upside down, exactly (sy' = 32 H - 32 - sy: rint is odd, no additive constant
-//     inside it): the same plan with the tile's rows copied in reverse order and the output row mirrored.
+//   * a ring of N equally spaced views of one pitch is periodic in the source: the member at position q sees what the member at
+//     position 0 sees, q d texels further, d = W / N (x0i32 differs by whole multiples of 32 d, everything else is equal), so the plan
+//     lists only period 0 -- source bytes [0, 3 d) of every row -- with the member index relative to the period; period k renders member
+//     (rel + k) mod N;
+//   * latitude mirror: pixel (i, j) of a view at pitch p and pixel (i, h - 1 - j) of the view at pitch -p on the same yaw look at
+//     mirrored points, exactly (sy' = 32 H - 32 - sy: rint is odd, no additive constant inside it; the pitch enters as +-sp).  The plan
+//     lists the quads that look at or above the equator; the same entries with the tile's rows copied in reverse order and the output
+//     row mirrored render the others -- of the same ring when it is level, of the ring at minus its pitch otherwise.
 // A tile therefore has 2 N images; a workgroup walks G of them (two alternating LDS buffers: one loader wavefront copies image g + 1
-// while eight consumer wavefronts render image g), with the tile's plan entries LDS-resident for all of them.
+// while eight consumer wavefronts render image g), with the tile's plan entries LDS-resident for all of them.  A call may hold several
+// rings of ONE size (sm_eligible): every pitched ring must come with its mirror ring.
 //
 // Ownership is per output QUAD (four pixels = 12 bytes = three dwords, all rendered by the tile that holds the first pixel's taps), so
 // every store is a dword store and no output byte is written twice.  Plan entry: per quad a header (3 x column | row << 14 | view << 26), per
 // pixel (LDS byte offset of the top-left tap | fx << 17 | fy << 22).
 //
-// Measured on MI355X (profiles/r05/srcmajor/): what bounds it is bytes moved -- tiles (64 MB per frame incl. the boxes' halos) + stores
-// -- at the ~5.5 TB/s the memory system sustains for this mix; arithmetic, LDS and the texture-address path all hide under the stream.
+// Measured on MI355X (profiles/r05/): cfg2 14.1-15.5 us per frame against 18.7-19.6 for the gather kernel -- bound by the copies (the L1's
+// ~64 read requests per CU in flight at ~1,000 cycles each; 70 MB per frame move where the union of lines + the stores is 64 MB); cfg3
+// 58-63 us against 75-79 (LDS-staged kernel), cfg1 32-36 against 41-48: copies, stores, LDS and vector ALU each 55-70 % busy.
 #include <algorithm>
 #include <cstring>
 #include <new>
