@@ -31,6 +31,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr size_t kSmPlanCap = 4;
 constexpr size_t kSmLdsPerGroup = 80 * 1024;   // two workgroups of the source-major kernel per CU (160 KiB of LDS)
+constexpr double kSmMinPixels = 3.5e6;           // automatic selection of the source-major kernel: output pixels of the call (smaller calls are launch-bound)
 constexpr int kSmFamilyMinFrames = 4;          // automatic selection of the source-major kernel for calls of several rings: frames per call ...
 constexpr int kSmMaxBoxPct = 160;              // ... and tile boxes at most this large relative to their grid cells (profiles/r05/srcmajor_family_sweep.txt)
 
@@ -48,7 +49,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 // context options: name, default, range, environment seed (user switches only)
 enum Opt { kOptLanemap, kOptStage, kOptRing, kOptXcdGroup, kOptEqPersist, kOptTablePersist, kOptLanczosTable, kOptTableRows, kOptColorCube,
-           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptCount };
+           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptSrcMajorAdapt, kOptCount };
 struct OptDesc { const char* key; int def, lo, hi; const char* env; };
 const OptDesc kOpts[kOptCount] = {
     {"lanemap", -1, -1, 1, "GS360_LANEMAP"},          // -1 auto (per view, by minification), 0 rows, 1 blocked       (env: rows | blocked)
@@ -64,6 +65,7 @@ const OptDesc kOpts[kOptCount] = {
     {"srcmajor_bx", 768, 256, 4032, nullptr},         // its tile: bytes per box row (multiple of 16) ...
     {"srcmajor_rows", 32, 8, 128, nullptr},           // ... and source rows
     {"srcmajor_images", 0, 0, 12, nullptr},           // images of a tile one workgroup walks (0 auto; must divide twice the ring size)
+    {"srcmajor_adapt", 1, 0, 1, nullptr},             // 1: jobs that do not fill the GPU take tiles of half the height; 0: srcmajor_rows as given (probes)
 };
 
 struct Staging {  // per-slot device staging used by the *_host conveniences
@@ -90,6 +92,7 @@ struct gs360_ctx {
     // Options (gs360_ctx_set_option; seeded ONCE from the environment by gs360_ctx_create for the documented user switches).  The hot
     // path reads these atomics, never the environment: getenv racing a host thread's putenv is undefined behaviour.
     std::atomic<int> opt[kOptCount];
+    std::atomic<int> last_sm_rows{0}, last_sm_images{0};   // read-only "last_srcmajor_rows" / "last_srcmajor_images": tile rows and images per workgroup of that launch
     std::atomic<int> last_sm_box_pct{0};      // read-only option "last_srcmajor_box_pct": tile-box bytes of the last source-major plan in % of its grid cells
     std::atomic<int> last_eq_kernel{-1};      // read-only option "last_eq_kernel": 0 gather, 1 LDS-staged, 2 source-major (which kernel the last equirect call launched)
     // source-major plans of this context (gs360_srcmajor.hip), most recent calls' geometries
@@ -451,6 +454,14 @@ int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
         *value = c->last_sm_box_pct.load(std::memory_order_relaxed);
         return GS360_OK;
     }
+    if (!std::strcmp(key, "last_srcmajor_rows")) {
+        *value = c->last_sm_rows.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
+    if (!std::strcmp(key, "last_srcmajor_images")) {
+        *value = c->last_sm_images.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
     for (int k = 0; k < kOptCount; ++k)
         if (!std::strcmp(key, kOpts[k].key)) {
             *value = c->opt[k].load(std::memory_order_relaxed);
@@ -691,13 +702,16 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         ev[k].flip = 0;
         if (esize == 2) ev[k].blocked = 0;   // 16-bit samples: row-per-slot lane map only
     }
-    // Source-major kernel (gs360_srcmajor.hip): a call that is ONE level yaw ring filling its circle (`--count N`, PC:794; the `default`
-    // preset) streams every source tile once for all views instead of gathering per view.  Where it wins (profiles/r05/srcmajor_ring_sweep.txt,
-    // 8K sources, N views, s source texels per output pixel): N >= 6 at every s measured (1.5 .. 4.6: -8 % .. -42 %; cfg2 19.0 -> 14.9 us per
-    // frame, cfg1 47.9 -> 33.6 at 16 frames), N = 5 from s = 2.25, N = 4 never (neighbours overlap by a quarter of their field only: +14 ..
-    // +44 %), and only when the call carries at least two frames: one frame is few workgroups for a two-deep pipeline, and even with the
-    // images-per-workgroup rule of sm_launch it is a coin toss (-23 % .. +9 % over ten rings; two frames: -25 % .. +1 %).  The engine and the
-    // stream pipeline hand over one frame per call, so they keep the gather kernels; the multi-frame entry point is what batch callers use.
+    // Source-major kernel (gs360_srcmajor.hip): a call whose views are yaw rings of one size filling their circle (`--count N`, PC:794; the
+    // presets' pitched ring pairs, PC:616-680) streams every source tile once for all views instead of gathering per view.  Where it wins
+    // (8K sources, N views per ring, s source texels per output pixel):
+    //   * ONE level ring (profiles/r05/srcmajor_ring_sweep.txt, srcmajor_small_jobs.txt): N >= 6 at every s measured (1.5 .. 4.6) and every
+    //     number of frames per call -- sixteen frames -8 .. -42 % (cfg2 19.0 -> 14.9 us per frame, cfg1 47.9 -> 33.6), one frame -3 .. -26 %
+    //     (cfg2 21.7 -> 16.0: what the drop-in engine launches) -- as long as the call has work to fill the GPU (>= 3.5 M output pixels; a
+    //     4K -> 6 x 400^2 frame is launch-bound either way); N = 5 from s = 2.25 and two frames; N = 4 never (neighbours overlap by a
+    //     quarter of their field only: +14 .. +44 %);
+    //   * SEVERAL rings (srcmajor_family_sweep.txt): from four frames per call, eight views and s = 1.75, unless the views reach so close to
+    //     a pole that the tile boxes outgrow their grid cells (kSmMaxBoxPct).
     // Option "srcmajor": 0 never, 1 whenever the geometry fits (tests, probes).  Decided before the ring grouping below (which keeps blocked
     // views apart); a geometry that does not fit the plan format falls through to the gather kernels.
     if (opt_srcmajor != 0 && !mask_frames && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 &&
@@ -726,18 +740,21 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         if (ring && opt_srcmajor < 0) {
             const double hf = clampd(views[0].hfov_deg, 1e-3, 179.9) * kPi / 180.0;
             const double step = (double)W / (2.0 * kPi) * 2.0 * std::tan(hf * 0.5) / (double)views[0].width;
-            if (shape.n_rings == 1) ring = n_frames >= 2 && shape.N >= 5 && step >= (shape.N >= 6 ? 1.5 : 2.25);
+            const double out_px = (double)n_frames * n_views * views[0].width * views[0].height;
+            if (shape.n_rings == 1) ring = out_px >= kSmMinPixels && (shape.N >= 6 ? step >= 1.5 : shape.N == 5 && n_frames >= 2 && step >= 2.25);
             else ring = n_frames >= kSmFamilyMinFrames && n_views >= 8 && step >= 1.75;
         }
         for (size_t i = 0; i < Ls.size() && ring; ++i) {
             hipError_t he = hipSuccess;
-            int rc, box_pct = 0;
+            int rc, info[3] = {0, 0, 0};
             {
                 std::lock_guard<std::mutex> lock(c->sm_mutex);
                 rc = sm_launch(Ls[i], shape, c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
-                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed),
-                               opt_srcmajor < 0 ? kSmMaxBoxPct : 0, kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he, &box_pct);
-                c->last_sm_box_pct.store(box_pct, std::memory_order_relaxed);
+                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), c->opt[kOptSrcMajorAdapt].load(std::memory_order_relaxed) != 0,
+                               opt_srcmajor < 0 ? kSmMaxBoxPct : 0, kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he, info);
+                c->last_sm_box_pct.store(info[0], std::memory_order_relaxed);
+                c->last_sm_rows.store(info[1], std::memory_order_relaxed);
+                c->last_sm_images.store(info[2], std::memory_order_relaxed);
             }
             if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));
             if (rc == 1 && i == 0) ring = false;         // the geometry does not fit the plan format (decided by the first chunk: nothing launched yet)

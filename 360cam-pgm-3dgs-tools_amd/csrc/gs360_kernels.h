@@ -212,8 +212,8 @@ struct SmShape {                         // how a call's views fall into yaw rin
     int qmap[GS360_MAX_VIEWS];           // ring * N + position -> view index
 };
 bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, SmShape* S);
-int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, int max_box_pct,
-              size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* box_pct);
+int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, bool adapt, int max_box_pct,
+              size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* info /* [3]: box overhead %, tile rows, images per workgroup */);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 void build_coef1d(float* out);             // host: the float32 1-D phase tables (linear, cubic, lanczos4) of the CV_16U samplers, 448

@@ -222,6 +222,7 @@ struct SmPlan {
     SmTile* d_tiles = nullptr;
     uint32_t* d_entries = nullptr;
     int n_tiles = 0, buf_bytes = 0, ent_bytes = 0, PB = 0;
+    int rows = 0;                          // tile rows the builder ended with (R, or a half / quarter of it when R did not fit)
     int box_pct = 0;                       // bytes of all tile boxes in percent of the tile grid cells they stand for (halos, cut tiles)
     uint64_t stamp = 0;
 };
@@ -445,13 +446,15 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, S
     return false;
 }
 
-// Renders the launch through the source-major kernel.  `cache` holds the context's plans (most recently used first, at most `cap`).
-// Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, int max_box_pct,
-              size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* box_pct) {
+namespace {
+
+// The plan of (launch geometry, tile shape) from the context's cache (`cache`: at most `cap`, least recently used evicted), built on a miss.
+// Returns nullptr with *herr == hipSuccess for a geometry that does not fit (remembered as an empty plan, or every call would plan again:
+// tens of ms), nullptr with *herr set on a HIP error.
+SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, hipStream_t s,
+                    hipError_t* herr) {
     const EqView& V = L.view[0];
-    const int N = S.N, NV = L.n_views;
-    *herr = hipSuccess;
+    const int N = S.N;
     uint32_t key[GS360_MAX_VIEWS][4];
     sm_ring_key(L, S, key);
     SmPlan* plan = nullptr;
@@ -459,15 +462,18 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
         if (p->W == L.W && p->H == L.H && p->N == N && p->n_rings == S.n_rings && p->w == V.out_w && p->h == V.out_h && p->Bx == Bx && p->R == R &&
             p->sxu == fbits(V.sxu) && p->syv == fbits(V.syv) && std::memcmp(p->ring_key, key, sizeof(key[0]) * S.n_rings) == 0) { plan = p; break; }
     if (!plan) {
-        int rr = R, rc = 1;
-        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2))
+        int rr = R, rc = 1, built = R;
+        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2)) {
+            built = rr;
             rc = sm_build_plan(L, S, Bx, rr, attempt == 2 || rr == 8, lds_limit, s, &plan, herr);
-        if (rc < 0) return rc;
-        if (rc == 1) {                                   // does not fit: remembered (an empty plan), or every call would plan again (tens of ms)
+        }
+        if (rc < 0) return nullptr;
+        if (rc == 1) {
             plan = new (std::nothrow) SmPlan();
-            if (!plan) { *herr = hipErrorOutOfMemory; return -1; }
+            if (!plan) { *herr = hipErrorOutOfMemory; return nullptr; }
         }
         plan->W = L.W; plan->H = L.H; plan->N = N; plan->n_rings = S.n_rings; plan->w = V.out_w; plan->h = V.out_h; plan->Bx = Bx; plan->R = R;
+        plan->rows = built;
         plan->sxu = fbits(V.sxu); plan->syv = fbits(V.syv);
         std::memset(plan->ring_key, 0, sizeof(plan->ring_key));
         std::memcpy(plan->ring_key, key, sizeof(key[0]) * S.n_rings);
@@ -482,8 +488,58 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
     uint64_t newest = 0;
     for (SmPlan* p : cache) newest = std::max(newest, p->stamp);
     plan->stamp = newest + 1;      // (the caller holds the context's plan lock)
-    if (plan->n_tiles == 0) return 1;                    // a geometry known not to fit: the gather kernels
-    *box_pct = plan->box_pct;
+    return plan->n_tiles ? plan : nullptr;
+}
+
+// Images per workgroup G (a divisor of the tile's 2 N images).  A workgroup takes about G + 1 image times (its first copy is not hidden)
+// and the job runs in ceil(workgroups / resident workgroups) rounds, so G minimises rounds x (G + 1); ties go to the larger G (the plan
+// entries are copied once per workgroup).  Measured (cfg2, one frame per call, 32-row tiles): G = 6 -> 19.3 us, 3 -> 21.6, 2 -> 23.4,
+// 4 -> 24.9, 12 -> 31.1 (189 workgroups for 256 CUs); sixteen frames: G = 12 (profiles/r05/srcmajor_images_sweep.txt).
+struct SmPick { int G; long long wgs, rounds, resident; };
+SmPick sm_pick_images(const SmPlan& plan, int N, int n_frames, int n_cu) {
+    const size_t lds_wg = (size_t)plan.ent_bytes + 2 * (size_t)plan.buf_bytes + 2048;
+    SmPick k;
+    k.resident = (long long)n_cu * (long long)std::max<size_t>(1, (160 * 1024) / lds_wg);
+    const long long items = (long long)plan.n_tiles * 2 * N * n_frames;
+    long long best = -1;
+    k.G = 1; k.wgs = items; k.rounds = 1;
+    for (int g = 1; g <= kSmMaxImages; ++g) {
+        if ((2 * N) % g) continue;
+        const long long wgs = items / g, rounds = (wgs + k.resident - 1) / k.resident, c = rounds * (g + 1);
+        if (best < 0 || c <= best) { best = c; k.G = g; k.wgs = wgs; k.rounds = rounds; }
+    }
+    return k;
+}
+
+}  // namespace
+
+// Renders the launch through the source-major kernel.  `cache` holds the context's plans.
+// Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
+int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, bool adapt, int max_box_pct,
+              size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* info) {
+    int* const box_pct = info;                           // info[0..2]: the plan's box overhead in percent, its tile rows, images per workgroup
+    const EqView& V = L.view[0];
+    const int N = S.N, NV = L.n_views;
+    *herr = hipSuccess;
+    SmPlan* plan = sm_get_plan(L, S, cache, cap, Bx, R, lds_limit, s, herr);
+    if (!plan) return *herr == hipSuccess ? 1 : -1;
+    SmPick pick = sm_pick_images(*plan, N, L.n_frames, n_cu);
+    // A job that cannot fill the GPU once even with the longest workgroups (cfg2: 188 tiles x 12 images / 12 = 188 workgroups per frame for
+    // 512 places) runs faster on tiles of half the height -- twice the workgroups, each half as long, and the smaller LDS footprint lets
+    // three of them share a CU: cfg2 19.2 -> 16.0 us for one frame per call, 16.1 -> 13.3 for two; from three frames on the tall tiles
+    // win again (16.1 against 16.5, four: 15.0 against 17.2: the boxes' halo bytes), and 16-row tiles are never halved (8K -> 6 x 1200^2,
+    // 8 x 1600^2, 12 x 800^2 at one frame: +8 .. +22 %).  profiles/r05/srcmajor_small_jobs.txt
+    if (adapt && G_opt == 0 && plan->rows >= 32) {
+        int gmax = 1;
+        for (int g = 1; g <= kSmMaxImages; ++g) if ((2 * N) % g == 0) gmax = g;
+        const long long coarsest = (long long)plan->n_tiles * 2 * N * L.n_frames / gmax;
+        if (coarsest * 10 < pick.resident * 9) {
+            SmPlan* half = sm_get_plan(L, S, cache, cap, Bx, plan->rows / 2, lds_limit, s, herr);
+            if (!half && *herr != hipSuccess) return -1;
+            if (half) { plan = half; pick = sm_pick_images(*half, N, L.n_frames, n_cu); }
+        }
+    }
+    box_pct[0] = plan->box_pct; box_pct[1] = plan->rows; box_pct[2] = pick.G;
     if (max_box_pct > 0 && plan->box_pct > max_box_pct) return 1;     // (automatic selection only) boxes far larger than their grid cells: views stretched towards a pole
     SmArgs P;
     std::memset(&P, 0, sizeof(P));
@@ -491,21 +547,9 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
     for (int i = 0; i < L.n_frames * NV; ++i) P.dst[i] = L.dst[i];
     P.tiles = plan->d_tiles; P.entries = plan->d_entries;
     P.W = L.W; P.H = L.H; P.N = N; P.NV = NV; P.w = V.out_w; P.h = V.out_h; P.PB = plan->PB;
-    // Images per workgroup G (a divisor of the tile's 2 N images).  A workgroup takes about G + 1 image times (its first copy is not
-    // hidden) and the job runs in ceil(workgroups / resident workgroups) rounds, so G minimises rounds x (G + 1); ties go to the larger G
-    // (the plan entries are copied once per workgroup).  Measured (cfg2, one frame per call as the product path launches it): G = 6 -> 19.3 us,
-    // 3 -> 21.6, 2 -> 23.4, 4 -> 24.9, 12 -> 31.1 (189 workgroups for 256 CUs); sixteen frames: G = 12 (profiles/r05/srcmajor_images_sweep.txt).
-    const size_t lds_wg = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes + 2048;
-    const long long resident = (long long)n_cu * std::max<size_t>(1, (160 * 1024) / lds_wg);
-    const long long items = (long long)plan->n_tiles * 2 * N * L.n_frames;
-    int G = 1;
-    long long best = -1;
-    for (int g = 1; g <= kSmMaxImages; ++g) {
-        if ((2 * N) % g) continue;
-        const long long wgs = items / g, rounds = (wgs + resident - 1) / resident, cost = rounds * (g + 1);
-        if (best < 0 || cost <= best) { best = cost; G = g; }
-    }
+    int G = pick.G;
     if (G_opt > 0 && G_opt <= kSmMaxImages && (2 * N) % G_opt == 0) G = G_opt;          // option "srcmajor_images" (probes)
+    box_pct[2] = G;
     P.G = G; P.groups_per_tile = 2 * N / G; P.groups_per_frame = plan->n_tiles * P.groups_per_tile;
     P.total_groups = P.groups_per_frame * L.n_frames; P.gchunk = (P.total_groups + 7) / 8;
     P.buf_bytes = plan->buf_bytes; P.ent_bytes = plan->ent_bytes;

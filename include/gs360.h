@@ -100,14 +100,16 @@ int gs360_device_pci_bus_id(gs360_ctx *ctx, char *buf, size_t buf_len);
  *   "srcmajor"       -1 auto | 0 never | 1 always       source-major equirect kernel (yaw rings of one size, level or in +/- pitch pairs:
  *                                                       the default / full360coverage / fisheyelike presets); "srcmajor_bx" (bytes per tile row,
  *                                                       multiple of 16), "srcmajor_rows" (source rows per tile), "srcmajor_images"
- *                                                       (0 auto | 1..12 dividing twice the ring size: images of a tile one workgroup walks)
+ *                                                       (0 auto | 1..12 dividing twice the ring size: images of a tile one workgroup walks),
+ *                                                       "srcmajor_adapt" (1 | 0: calls too small to fill the GPU take tiles of half the height)
  *   "ring"           0 auto | n                         at most n views share one coordinate evaluation
  *   "xcd_group"      -2 auto | -1 chunks | g            tile order across the XCDs
  *   "eq_persist", "table_persist"                       grid caps of the persistent kernels (table_persist: -1 auto)
  *   "lanczos_table", "table_rows"                       0 | 1: A/B references of the Lanczos-4 weight rebuild and the flat spans
  *   "color_cube"     -1 / 1 tabulate | 0 per pixel      8-bit colour stage (read by gs360_color_plan_create)
  * Read-only (get): "last_eq_kernel" -- which kernel the last equirect call launched: 0 gather, 1 LDS-staged, 2 source-major, -1 none yet;
- * "last_srcmajor_box_pct" -- tile-box bytes of the last source-major plan in percent of the grid cells they stand for.
+ * "last_srcmajor_box_pct" -- tile-box bytes of the last source-major plan in percent of the grid cells they stand for;
+ * "last_srcmajor_rows", "last_srcmajor_images" -- tile rows and images per workgroup of the last source-major launch.
  * Unknown keys and out-of-range values are GS360_ERR_ARG.  Thread-safe; a change applies to calls that start after it. */
 int gs360_ctx_set_option(gs360_ctx *ctx, const char *key, int value);
 int gs360_ctx_get_option(gs360_ctx *ctx, const char *key, int *value);

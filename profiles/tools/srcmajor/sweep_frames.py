@@ -22,10 +22,11 @@ def bench(W, H, F, specs, label):
             ctx.sync(0)
             ctx.event_record(0, 0); run(40); ctx.event_record(0, 1)
             res.append(ctx.event_elapsed_ms(0, 0, 1) / 40 * 1e3 / F)
-    print(f"{label} N={len(specs)} step {step:.2f} F={F}: gather {res[0]:.2f} srcmajor {res[1]:.2f} ratio {res[1]/res[0]:.2f}", flush=True)
+            shape = (ctx.get_option("last_srcmajor_rows"), ctx.get_option("last_srcmajor_images"))
+    print(f"{label} N={len(specs)} step {step:.2f} F={F}: gather {res[0]:.2f} srcmajor {res[1]:.2f} ratio {res[1]/res[0]:.2f}  (tile rows {shape[0]}, images {shape[1]})", flush=True)
     for b in frames + dsts: ctx.free(b)
 W, H = 7680, 3840
-for F in (1, 2, 16):
+for F in (int(a) for a in (sys.argv[1:] or ["1", "2", "3", "4", "16"])):
     for n, size in ((6, 800), (6, 1200), (6, 1600), (6, 2096), (8, 1024), (8, 1600), (12, 800), (5, 1224)):
         if F == 16 and n * size * size > 6 * 1700 * 1700: continue
         bench(W, H, F, ring_views(n, size, HFOV_12MM), f"8K->{n}x{size}")

@@ -75,8 +75,18 @@ def test_shuffled_view_order_and_frames(forced, orc):
 @pytest.mark.parametrize("bx,rows", [(256, 8), (512, 16), (768, 48), (1024, 24), (2048, 8)])
 def test_tile_shapes(ctx, orc, bx, rows):
     src = rand_image(960, 1920, seed=230)
-    with ctx.options(srcmajor=1, srcmajor_bx=bx, srcmajor_rows=rows):
+    with ctx.options(srcmajor=1, srcmajor_bx=bx, srcmajor_rows=rows, srcmajor_adapt=0):      # (exactly this shape: no half-height tiles)
         _check(ctx, orc, src, ring_views(6, 240, HFOV_12MM), f"tile {bx} x {rows}")
+
+
+def test_small_jobs_take_half_height_tiles(ctx, orc):
+    """a call that does not fill the GPU once is rendered from tiles of half the height (a second plan of the same geometry); the
+    result is the same bytes either way, and both plans stay cached next to each other"""
+    src = rand_image(1920, 3840, seed=231)
+    specs = ring_views(6, 400, HFOV_12MM)
+    for adapt in (1, 0, 1):
+        with ctx.options(srcmajor=1, srcmajor_adapt=adapt):
+            _check(ctx, orc, src, specs, f"adapt {adapt}")
 
 
 def test_plan_cache_eviction_and_reuse(forced, orc):
@@ -216,14 +226,19 @@ def test_ring_families_it_must_leave_to_the_gather_kernels(forced, orc):
 
 
 def test_auto_selection(ctx, orc):
-    """left to itself the library takes it for rings of >= 6 views from 1.5 source texels per output pixel (5 views: from 2.25; 4: never)
-    and only for calls of at least two frames (profiles/r05/srcmajor_ring_sweep.txt)"""
-    frames = [rand_image(960, 1920, seed=260 + f) for f in range(2)]
-    d_src = [ctx.to_device(f) for f in frames]
+    """left to itself the library takes it for ONE level ring of >= 6 views from 1.5 source texels per output pixel at any number of frames
+    (5 views: from 2.25 and two frames; 4: never) once the call writes >= 3.5 M pixels (profiles/r05/srcmajor_ring_sweep.txt,
+    srcmajor_small_jobs.txt)"""
+    small = [rand_image(960, 1920, seed=260 + f) for f in range(15)]
+    big = [rand_image(1920, 3840, seed=290 + f) for f in range(2)]
+    d_small = [ctx.to_device(f) for f in small]
+    d_big = [ctx.to_device(f) for f in big]
 
-    def kernel_for(specs, n_frames):
+    def kernel_for(specs, n_frames, big_source=False):
+        frames, d_src = (big, d_big) if big_source else (small, d_small)
+        H, W = frames[0].shape[:2]
         d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(n_frames) for s in specs]
-        ctx.equirect_views_dev(d_src[:n_frames], 1920, 960, 3, [gs360.View.make(*s) for s in specs], d_out)
+        ctx.equirect_views_dev(d_src[:n_frames], W, H, 3, [gs360.View.make(*s) for s in specs], d_out)
         ctx.sync(0)
         want = orc.equirect_views_u8(frames[n_frames - 1], [orc.make_view(*s) for s in specs], threads=0)
         for k, s in enumerate(specs):
@@ -232,16 +247,21 @@ def test_auto_selection(ctx, orc):
             ctx.free(b)
         return ctx.get_option("last_eq_kernel")
     with ctx.options(srcmajor=-1):
-        assert kernel_for(ring_views(6, 200, HFOV_12MM), 2) == 2          # 4.6 texels per pixel
-        assert kernel_for(ring_views(6, 400, HFOV_12MM), 2) == 2          # 2.3
-        assert kernel_for(ring_views(6, 200, HFOV_12MM), 1) == 0          # a single frame: gather kernels
-        assert kernel_for(ring_views(6, 800, HFOV_12MM), 2) == 0          # 1.15: below 1.5
-        assert kernel_for(ring_views(5, 440, HFOV_12MM), 2) == 0          # five views at 2.08 (1920 = 5 x 384: eligible, not chosen)
-        assert kernel_for(ring_views(5, 320, HFOV_12MM), 2) == 2          # five views at 2.86
-        assert kernel_for(ring_views(4, 200, HFOV_12MM), 2) == 0          # four views: never
+        assert kernel_for(ring_views(6, 200, HFOV_12MM), 15) == 2         # 4.6 texels per pixel, 3.6 M pixels
+        assert kernel_for(ring_views(6, 200, HFOV_12MM), 14) == 0         # 3.36 M pixels: too small a call
+        assert kernel_for(ring_views(6, 400, HFOV_12MM), 4) == 2          # 2.3 texels
+        assert kernel_for(ring_views(6, 800, HFOV_12MM), 1) == 0          # 1.15: below 1.5
+        assert kernel_for(ring_views(6, 800, HFOV_12MM), 1, True) == 2    # ONE frame (what the engine hands over): 2.3 texels, 3.84 M pixels
+        assert ctx.get_option("last_srcmajor_rows") == 16                 # ... on tiles of half the height (the job does not fill the GPU)
+        assert kernel_for(ring_views(6, 800, HFOV_12MM), 2, True) == 2
+        five = [(72.0 * i, 0.0, 130.0, 130.0, 840, 840) for i in range(5)]
+        assert kernel_for(five, 1, True) == 0                             # five views at 3.1 texels: from two frames
+        assert kernel_for(five, 2, True) == 2
+        assert kernel_for([(72.0 * i, 0.0, 112.0, 112.0, 900, 900) for i in range(5)], 2, True) == 0    # five views at 2.0
+        assert kernel_for(ring_views(4, 400, HFOV_12MM), 8) == 0          # four views: never
     with ctx.options(srcmajor=0):
-        assert kernel_for(ring_views(6, 200, HFOV_12MM), 2) == 0
-    for b in d_src:
+        assert kernel_for(ring_views(6, 200, HFOV_12MM), 15) == 0
+    for b in d_small + d_big:
         ctx.free(b)
 
 
