@@ -29,7 +29,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-constexpr size_t kSmPlanCap = 4;
+constexpr size_t kSmPlanCap = 8;          // source-major plans a context keeps (a geometry may hold two: full- and half-height tiles)
 constexpr size_t kSmLdsPerGroup = 80 * 1024;   // two workgroups of the source-major kernel per CU (160 KiB of LDS)
 constexpr double kSmMinPixels = 3.5e6;           // automatic selection of the source-major kernel: output pixels of the call (smaller calls are launch-bound)
 constexpr int kSmFamilyMinFrames = 4;          // automatic selection of the source-major kernel for calls of several rings: frames per call ...
