@@ -208,6 +208,40 @@ def test_more_frames_than_one_launch_holds(forced, orc, shape):
         forced.free(b)
 
 
+def test_concurrent_callers_share_the_plan_cache(orc):
+    """four host threads, each on its own stream slot, render different ring geometries through one context at the same time (plans are
+    built, looked up and evicted under the context's plan lock)"""
+    import threading
+    ctx4 = gs360.Context(0, n_slots=4)
+    src = rand_image(480, 960, seed=520)
+    d_src = ctx4.to_device(src)
+    geoms = [[(i * 60.0 + 3 * t, 0.0, 90.0 + 5 * t, 90.0, 96 + 8 * t, 80) for i in range(6)] for t in range(4)]
+    geoms[3] = _family(PRESET_FULL360, 100.0, 64)
+    wants = [orc.equirect_views_u8(src, [orc.make_view(*s) for s in g], threads=0) for g in geoms]
+    errors = []
+
+    def work(t):
+        try:
+            g = geoms[t]
+            d_out = [ctx4.alloc(s[4] * s[5] * 3) for s in g]
+            for _ in range(20):
+                ctx4.equirect_views_dev([d_src], 960, 480, 3, [gs360.View.make(*s) for s in g], d_out, slot=t)
+            ctx4.sync(t)
+            for k, s in enumerate(g):
+                if not np.array_equal(ctx4.download(d_out[k], (s[5], s[4], 3), slot=t), wants[t][k]):
+                    errors.append((t, k))
+        except Exception as e:      # noqa: BLE001
+            errors.append((t, repr(e)))
+    with ctx4.options(srcmajor=1):
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    ctx4.close()
+    assert not errors, errors
+
+
 def test_ring_families_it_must_leave_to_the_gather_kernels(forced, orc):
     src = rand_image(480, 960, seed=251)
     lvl = [(90.0 * i, 0.0, 100.0, 100.0, 96, 96) for i in range(4)]
