@@ -714,8 +714,26 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
     //     a pole that the tile boxes outgrow their grid cells (kSmMaxBoxPct).
     // Option "srcmajor": 0 never, 1 whenever the geometry fits (tests, probes).  Decided before the ring grouping below (which keeps blocked
     // views apart); a geometry that does not fit the plan format falls through to the gather kernels.
-    if (opt_srcmajor != 0 && !mask_frames && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 &&
-        n_views <= GS360_MAX_VIEWS) {
+    // keep-masks: thresholded once per launch into bit images (the kernels only test `< 128`), behind the caller's upload on the launch
+    // stream: a streaming pass over W x H bytes per frame, ~7 us for an 8K mask.  (The previous launch on this stream may still read the
+    // images: a reallocation's hipFree synchronises the device.)
+    const int mask_pitch_dw = (W + 1 + 31) / 32;
+    const size_t mask_bits_bytes = (size_t)mask_pitch_dw * 4 * (size_t)(H + 1);
+    auto pack_masks = [&](int f0, int nf) -> int {
+        Staging& st = c->stage[slot];
+        if (int rc = ensure(c, &st.d_maskbits, &st.maskbits_cap, mask_bits_bytes * (size_t)nf)) return rc;
+        MaskPack P;
+        std::memset(&P, 0, sizeof(P));
+        for (int f = 0; f < nf; ++f) {
+            P.src[f] = (const uint8_t*)mask_frames[f0 + f];
+            P.dst[f] = (uint32_t*)((uint8_t*)st.d_maskbits + mask_bits_bytes * (size_t)f);
+        }
+        P.W = W; P.H = H; P.pitch_dw = mask_pitch_dw; P.n = nf;
+        P.stride = (int64_t)mask_stride;
+        HIP_TRY(launch_mask_pack(P, c->stream[slot]));
+        return GS360_OK;
+    };
+    if (opt_srcmajor != 0 && esize == 1 && C == 3 && interp == GS360_INTERP_LINEAR && !fish && n_views >= 2 && n_views <= GS360_MAX_VIEWS) {
         bool ring = true;
         SmShape shape;
         std::vector<EqLaunch> Ls;
@@ -734,7 +752,7 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             L.W = W; L.H = H; L.y0i32 = 16 * H - 16;
             L.n_views = n_views; L.n_frames = nf;
             L.src_stride = (int64_t)src_stride; L.dst_stride = (int64_t)dst_stride;
-            ring = sm_eligible(L, C, esize, interp, false, &shape);     // (the shape depends on the views only: the same for every chunk)
+            ring = sm_eligible(L, C, esize, interp, mask_frames != nullptr, &shape);     // (the shape depends on the views only: the same for every chunk)
             Ls.push_back(L);
         }
         if (ring && opt_srcmajor < 0) {
@@ -747,6 +765,11 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         for (size_t i = 0; i < Ls.size() && ring; ++i) {
             hipError_t he = hipSuccess;
             int rc, info[3] = {0, 0, 0};
+            if (mask_frames) {                           // (packed per chunk of frames: the staging images are reused)
+                if (int prc = pack_masks((int)i * GS360_MAX_FRAMES, Ls[i].n_frames)) return prc;
+                for (int f = 0; f < Ls[i].n_frames; ++f) Ls[i].mask[f] = (const uint8_t*)c->stage[slot].d_maskbits + mask_bits_bytes * (size_t)f;
+                Ls[i].mask_stride = (int64_t)mask_pitch_dw * 4;
+            }
             {
                 std::lock_guard<std::mutex> lock(c->sm_mutex);
                 rc = sm_launch(Ls[i], shape, c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
@@ -875,23 +898,10 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             // with one tile per workgroup, 35.5 / 90.2 / 177.5 with 2048 persistent ones; profiles/r03/persistent_cubic_ab.txt).
             // The cv2 table kernel, 1024 pixels per tile, gains 12 % from it (launch_table_batch).
             L.persist_blocks = c->opt[kOptEqPersist].load(std::memory_order_relaxed);      // option "eq_persist" (probes): grid cap
-            // keep-masks: thresholded once per launch into bit images (the kernels only test `< 128`), behind the caller's upload
-            // on the launch stream: a streaming pass over W x H bytes per frame, ~7 us for an 8K mask
-            const int pitch_dw = (W + 1 + 31) / 32;
-            const size_t bits_bytes = (size_t)pitch_dw * 4 * (size_t)(H + 1);
+            const size_t bits_bytes = mask_bits_bytes;
+            const int pitch_dw = mask_pitch_dw;
             if (mask_frames && (r0 == 0 || n_frames > GS360_MAX_FRAMES)) {   // (one frame chunk: later ring groups reuse the images)
-                Staging& st = c->stage[slot];
-                // the previous launch on this stream may still read the images: the reallocation's hipFree synchronises the device
-                if (int rc = ensure(c, &st.d_maskbits, &st.maskbits_cap, bits_bytes * (size_t)nf)) return rc;
-                MaskPack P;
-                std::memset(&P, 0, sizeof(P));
-                for (int f = 0; f < nf; ++f) {
-                    P.src[f] = (const uint8_t*)mask_frames[f0 + f];
-                    P.dst[f] = (uint32_t*)((uint8_t*)st.d_maskbits + bits_bytes * (size_t)f);
-                }
-                P.W = W; P.H = H; P.pitch_dw = pitch_dw; P.n = nf;
-                P.stride = (int64_t)mask_stride;
-                HIP_TRY(launch_mask_pack(P, c->stream[slot]));
+                if (int rc = pack_masks(f0, nf)) return rc;
             }
             for (int f = 0; f < nf; ++f) {
                 L.src[f] = (const uint8_t*)src_frames[f0 + f];

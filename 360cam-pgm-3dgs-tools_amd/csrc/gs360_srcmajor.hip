@@ -78,10 +78,16 @@ struct SmArgs {
     int32_t qmap[GS360_MAX_VIEWS];        // ring * N + ring position -> view index of the call
     int32_t partner[GS360_MAX_VIEWS];     // ring -> the ring its upside-down images render (itself: level; the ring at minus its pitch otherwise)
     int64_t src_stride, dst_stride;
+    // masked calls: the frames' keep-BIT images (mask_pack_kernel: bit x of row y, mask_stride bytes per row, W / 32 dwords carry the W bits)
+    const uint8_t* mask[GS360_MAX_FRAMES];
+    int32_t mask_stride, mask_dw, mbuf_bytes, pad_;
 };
 static_assert(sizeof(SmArgs) <= 4096, "SmArgs travels as a kernel argument");
 
-template <int CW>
+constexpr int kSmMaskedPitch = 1024;                    // masked plans: at most this many bytes per box row (the pixel word holds row and byte apart)
+constexpr int kSmMaskRowBytes = 64;                     // ... and per row of the keep-bit box (16 dwords = 512 texels)
+
+template <int CW, bool MASKED>
 __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
     __shared__ uint8_t* s_dst[kSmMaxImages * GS360_MAX_VIEWS];
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
     const int G = P.G;
     uint8_t* const s_ent = s_lds;                        // [headers: nq dwords][pixel words: 4 nq dwords]
     uint8_t* const s_tile = s_lds + P.ent_bytes;         // two tile buffers of buf_bytes
+    uint8_t* const s_mask = s_tile + 2 * P.buf_bytes;    // (MASKED) two keep-bit boxes of mbuf_bytes
     if (tid < G * P.NV) {                                // destination of (image, plan view = ring * N + relative member): period k renders
         const int g = tid / P.NV, v = tid - g * P.NV;    // member (rel + k) mod N, of the ring itself or -- upside down -- of its mirror ring
         const int c = v / P.N, img = g0 + g;
@@ -126,6 +133,24 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
                     const int yc = min(max(y, 0), P.H - 1);                 // EQ-SPEC clamps tap rows to [0, H - 1]
                     const uint8_t* rowp = src + (size_t)yc * P.src_stride;
                     __builtin_amdgcn_global_load_lds((global_void_t*)(rowp + (uint32_t)x), (lds_void_t*)(buf + row * pitch + cb * 16), 16, 0, 0);
+                }
+            }
+        }
+        if constexpr (MASKED) {
+            // the keep bits of the box: the nearest texel of a pixel is one of its four taps, so rows [y0, y0 + nrows) x the box's texels
+            // hold every bit this image can ask for.  Four box rows per copy instruction (a dword per lane, 16 dwords per row); the bit
+            // image wraps at W bits = W / 32 dwords (W % 32 == 0), the box's first bit sits at (x0 / 3) % 32 in every period (d % 32 == 0).
+            uint8_t* const mbuf = s_mask + (buf != s_tile ? P.mbuf_bytes : 0);
+            const uint8_t* __restrict__ mk = P.mask[f];
+            const int mdw = T.pad1;                      // dwords per box row that hold its bits
+            int d = ((T.x0 / 3 + k * (P.PB / 3)) >> 5) + (lane & 15);
+            if (d >= P.mask_dw) d -= P.mask_dw;
+            if ((lane & 15) < mdw) {
+                const int r4 = lane >> 4;
+                for (int row0 = 0; row0 < T.nrows; row0 += 4) {               // (the buffer holds whole groups of four rows)
+                    const int y = flip ? P.H - 1 - T.y0 - (row0 + r4) : T.y0 + row0 + r4;
+                    const int yc = min(max(y, 0), P.H - 1);
+                    __builtin_amdgcn_global_load_lds((global_void_t*)(mk + (size_t)yc * (size_t)P.mask_stride + (size_t)d * 4), (lds_void_t*)(mbuf + row0 * kSmMaskRowBytes), 4, 0, 0);
                 }
             }
         }
@@ -165,12 +190,18 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
             const int lane_off = (flip ? (P.h - 1) * dstride : 0) + 4 * min(k4, 2);           // flipped image: rows run upwards from h - 1
             int cur_vrel = -1;
             uint64_t dbase = 0;
+            const uint8_t* const cur_mask = s_mask + (g & 1) * P.mbuf_bytes;
+            const uint32_t msh = T.pad0 & 255u, x0m3 = T.pad0 >> 8;
+            const int fy_up = flip ? 17 : 16;
             auto turn = [&](const uint8_t* const pp, const uint8_t* const hp) {
                 const uint32_t pw = *reinterpret_cast<const uint32_t*>(pp);
                 const uint32_t hd = *reinterpret_cast<const uint32_t*>(hp);
                 const int fx = (pw >> 17) & 31, fy = (pw >> 22) & 31;
-                const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + (pw & 0x1fffcu));
-                const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + (pw & 0x1fffcu) + pitch);
+                // tap offset: unmasked plans hold it whole; masked ones box row (7 bits) and byte in the row (10 bits) apart, for the keep lookup
+                const uint32_t xbyte = pw & (kSmMaskedPitch - 1), rho = (pw >> 10) & 127u;
+                const uint32_t toff = MASKED ? (__umul24(rho, (uint32_t)pitch) + xbyte) & ~3u : pw & 0x1fffcu;
+                const uint32_t* qa = reinterpret_cast<const uint32_t*>(cur_buf + toff);
+                const uint32_t* qb = reinterpret_cast<const uint32_t*>(cur_buf + toff + pitch);
                 const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
                 uint2 t0, t1;                            // rows iy, iy + 1: bytes r0 g0 b0 r1 | g1 b1 . .
                 t0.x = __builtin_amdgcn_alignbyte(a1, a0, pw); t0.y = __builtin_amdgcn_alignbyte(a2, a1, pw);
@@ -180,6 +211,16 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
                 uint32_t pk;                             // r | g << 8 | b << 16 in two instructions (the compiler prefers two shifts and a three-way or)
                 asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(pk) : "v"(px[1]), "v"(px[0]));
                 asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(pk) : "v"(px[2]), "v"(pk));
+                if constexpr (MASKED) {
+                    // keep bit of the NEAREST texel ((sx + 16) >> 5, (sy + 16) >> 5): column = the tap's texel + (fx >= 16); row = the tap row
+                    // + (fy >= 16) -- in an upside-down image + (fy > 16): there the mirrored coordinate 32 H - 32 - sy is what gets rounded,
+                    // and exactly half-way both round up.
+                    const uint32_t tx = __umul24(xbyte + x0m3, 0xAAABu) >> 17;          // / 3, exact below 2^16
+                    const uint32_t bitpos = msh + tx + (fx >= 16 ? 1u : 0u);
+                    const uint32_t rr = rho + (fy >= fy_up ? 1u : 0u);
+                    const uint32_t kw = *reinterpret_cast<const uint32_t*>(cur_mask + rr * kSmMaskRowBytes + ((bitpos >> 5) << 2));
+                    pk &= (uint32_t)__builtin_amdgcn_sbfe((int)kw, bitpos & 31u, 1u);         // 0 or all ones
+                }
                 // lanes 4m .. 4m + 3 hold a quad: lane k cuts dword k of its 12 bytes out of pixels k and k + 1
                 const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9, 0xf, 0xf, true);          // quad_perm [1,2,3,3]
                 const uint32_t dw = __builtin_amdgcn_perm(nxt, pk, sel);
@@ -216,12 +257,13 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
 struct SmPlan {
     // key
     int W = 0, H = 0, N = 0, n_rings = 0, w = 0, h = 0, Bx = 0, R = 0;
+    bool masked = false;                   // plan of masked calls: fixed LDS pitch, keep-bit boxes
     uint32_t sxu = 0, syv = 0;             // float bits
     uint32_t ring_key[GS360_MAX_VIEWS][4]; // per ring: sp, cp, x0f32 (float bits), x0i32 of its reference member
     // contents
     SmTile* d_tiles = nullptr;
     uint32_t* d_entries = nullptr;
-    int n_tiles = 0, buf_bytes = 0, ent_bytes = 0, PB = 0;
+    int n_tiles = 0, buf_bytes = 0, ent_bytes = 0, mbuf_bytes = 0, PB = 0;
     int rows = 0;                          // tile rows the builder ended with (R, or a half / quarter of it when R did not fit)
     int box_pct = 0;                       // bytes of all tile boxes in percent of the tile grid cells they stand for (halos, cut tiles)
     uint64_t stamp = 0;
@@ -243,7 +285,7 @@ struct Quad { int32_t tid, vslot, j, i0; int32_t xr[4], iy[4], ph[4]; };
 constexpr int kSmQuadCap = 1632;                        // quads of one plan tile (32 KiB of entries); a denser tile is cut into several
 
 // 0: plan built; 1: this geometry does not fit the kernel (caller falls back to the gather kernels); < 0: HIP error in *herr
-int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smallest, size_t lds_limit, hipStream_t s, SmPlan** out, hipError_t* herr) {
+int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool masked, bool smallest, size_t lds_limit, hipStream_t s, SmPlan** out, hipError_t* herr) {
     const EqView& V = L0.view[0];
     const int W = L0.W, H = L0.H, N = S.N, w = V.out_w, h = V.out_h;
     const int PB = 3 * (W / N), rowbytes = 3 * W;
@@ -302,7 +344,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
     std::vector<SmTile> tiles;
     std::vector<uint32_t> ent;
     std::vector<const Quad*> list;
-    int buf_bytes = 0, ent_bytes = 0, n_boxes = 0;
+    int buf_bytes = 0, ent_bytes = 0, mbuf_bytes = 0, n_boxes = 0;
     long long box_sum = 0;
     for (size_t a = 0; a < quads.size();) {
         size_t b = a;
@@ -337,6 +379,14 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
             T.pad0 = T.pad1 = 0;
             const int pitch = T.wch * 16;
             if ((size_t)T.nrows * pitch >= (1u << 17) || T.x0 >= PB || T.wch * 16 > rowbytes) return 1;
+            if (masked) {                                // first bit of the box in its first keep dword | first byte's offset in its texel; keep dwords per row
+                if (T.wch * 16 > kSmMaskedPitch || T.nrows > 127) return 1;
+                const int msh = (T.x0 / 3) & 31;
+                T.pad0 = msh | ((T.x0 % 3) << 8);
+                T.pad1 = (msh + (T.wch * 16 + 2) / 3 + 1 + 31) / 32;            // (taps reach one texel past a box byte's own: + 1)
+                if (T.pad1 > kSmMaskRowBytes / 4) return 1;
+                mbuf_bytes = std::max(mbuf_bytes, ((T.nrows + 3) & ~3) * kSmMaskRowBytes);
+            }
             ent.resize(ent.size() + 5 * (size_t)nqp);
             uint32_t* hdr = ent.data() + T.eoff;
             uint32_t* px = hdr + nqp;
@@ -344,10 +394,11 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
                 const Quad& Q = *list[c0 + q];
                 hdr[q] = (uint32_t)(3 * Q.i0) | ((uint32_t)Q.j << 14) | ((uint32_t)Q.vslot << 26);
                 for (int k = 0; k < 4; ++k)
-                    px[4 * q + k] = (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0)) | ((uint32_t)Q.ph[k] << 17);
+                    px[4 * q + k] = (masked ? (uint32_t)(Q.xr[k] - T.x0) | ((uint32_t)(Q.iy[k] - T.y0) << 10)
+                                            : (uint32_t)((Q.iy[k] - T.y0) * pitch + (Q.xr[k] - T.x0))) | ((uint32_t)Q.ph[k] << 17);
             }
             buf_bytes = std::max(buf_bytes, T.nrows * pitch);
-            box_sum += (long long)T.nrows * pitch;
+            box_sum += (long long)T.nrows * T.wch * 16;
             ent_bytes = std::max(ent_bytes, 20 * nqp);
             tiles.push_back(T);
         }
@@ -355,12 +406,12 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool smal
     }
     buf_bytes = (buf_bytes + 63) & ~63;
     ent_bytes = (ent_bytes + 63) & ~63;
-    if ((size_t)ent_bytes + 2 * (size_t)buf_bytes > lds_limit) return 1;
+    if ((size_t)ent_bytes + 2 * (size_t)buf_bytes + 2 * (size_t)mbuf_bytes > lds_limit) return 1;
     // most boxes cut in two or more: the tile is too tall for this geometry (every cut copies much of the box again), a smaller one serves better
     if (!smallest && tiles.size() > (size_t)n_boxes + (size_t)n_boxes / 4) return 1;
     SmPlan* p = new (std::nothrow) SmPlan();
     if (!p) { *herr = hipErrorOutOfMemory; return -1; }
-    p->n_tiles = (int)tiles.size(); p->buf_bytes = buf_bytes; p->ent_bytes = ent_bytes; p->PB = PB;
+    p->n_tiles = (int)tiles.size(); p->buf_bytes = buf_bytes; p->ent_bytes = ent_bytes; p->mbuf_bytes = mbuf_bytes; p->PB = PB;
     p->box_pct = (int)(100 * box_sum / ((long long)n_boxes * std::min(Bx, PB) * R));
     *herr = hipMalloc((void**)&p->d_tiles, tiles.size() * sizeof(SmTile));
     if (*herr == hipSuccess) *herr = hipMalloc((void**)&p->d_entries, ent.size() * 4 + 1024);      // (slack: the entry copy reads whole 16-byte chunks)
@@ -386,7 +437,8 @@ void sm_ring_key(const EqLaunch& L, const SmShape& S, uint32_t (*key)[4]) {
 // accompanied by the ring at minus its pitch on the same yaws (`full360coverage`: a level ring of four and the +30 / -30 pair;
 // `fisheyelike`: five rings of two; PC:616-680, :794-822).
 bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, SmShape* S) {
-    if (C != 3 || esize != 1 || interp != GS360_INTERP_LINEAR || masked) return false;
+    if (C != 3 || esize != 1 || interp != GS360_INTERP_LINEAR) return false;
+    if (masked && L.W % 32) return false;                // (the keep-bit image wraps at whole dwords; the ring period is checked below)
     const int NV = L.n_views;
     const EqView& V = L.view[0];
     if (NV < 2 || NV > GS360_MAX_VIEWS) return false;
@@ -406,7 +458,7 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, S
     // (x0i32 by whole multiples of d = W / N texels, x0f32 equal), every one of its N positions taken once.  A member's position is
     // ABSOLUTE (x0i32 / 32 d), so a ring and its mirror ring number their members alike.
     for (int N = NV; N >= 2; --N) {
-        if (NV % N || L.W % N || (3 * (L.W / N)) % 16) continue;
+        if (NV % N || L.W % N || (3 * (L.W / N)) % 16 || (masked && (L.W / N) % 32)) continue;
         const int d32 = 32 * (L.W / N);
         int seen[GS360_MAX_VIEWS];
         S->N = N; S->n_rings = 0;
@@ -451,8 +503,8 @@ namespace {
 // The plan of (launch geometry, tile shape) from the context's cache (`cache`: at most `cap`, least recently used evicted), built on a miss.
 // Returns nullptr with *herr == hipSuccess for a geometry that does not fit (remembered as an empty plan, or every call would plan again:
 // tens of ms), nullptr with *herr set on a HIP error.
-SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, size_t lds_limit, hipStream_t s,
-                    hipError_t* herr) {
+SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, bool masked, size_t lds_limit,
+                    hipStream_t s, hipError_t* herr) {
     const EqView& V = L.view[0];
     const int N = S.N;
     uint32_t key[GS360_MAX_VIEWS][4];
@@ -460,12 +512,12 @@ SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& c
     SmPlan* plan = nullptr;
     for (SmPlan* p : cache)
         if (p->W == L.W && p->H == L.H && p->N == N && p->n_rings == S.n_rings && p->w == V.out_w && p->h == V.out_h && p->Bx == Bx && p->R == R &&
-            p->sxu == fbits(V.sxu) && p->syv == fbits(V.syv) && std::memcmp(p->ring_key, key, sizeof(key[0]) * S.n_rings) == 0) { plan = p; break; }
+            p->masked == masked && p->sxu == fbits(V.sxu) && p->syv == fbits(V.syv) && std::memcmp(p->ring_key, key, sizeof(key[0]) * S.n_rings) == 0) { plan = p; break; }
     if (!plan) {
         int rr = R, rc = 1, built = R;
         for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2)) {
             built = rr;
-            rc = sm_build_plan(L, S, Bx, rr, attempt == 2 || rr == 8, lds_limit, s, &plan, herr);
+            rc = sm_build_plan(L, S, Bx, rr, masked, attempt == 2 || rr == 8, lds_limit, s, &plan, herr);
         }
         if (rc < 0) return nullptr;
         if (rc == 1) {
@@ -473,7 +525,7 @@ SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& c
             if (!plan) { *herr = hipErrorOutOfMemory; return nullptr; }
         }
         plan->W = L.W; plan->H = L.H; plan->N = N; plan->n_rings = S.n_rings; plan->w = V.out_w; plan->h = V.out_h; plan->Bx = Bx; plan->R = R;
-        plan->rows = built;
+        plan->rows = built; plan->masked = masked;
         plan->sxu = fbits(V.sxu); plan->syv = fbits(V.syv);
         std::memset(plan->ring_key, 0, sizeof(plan->ring_key));
         std::memcpy(plan->ring_key, key, sizeof(key[0]) * S.n_rings);
@@ -497,7 +549,7 @@ SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& c
 // 4 -> 24.9, 12 -> 31.1 (189 workgroups for 256 CUs); sixteen frames: G = 12 (profiles/r05/srcmajor_images_sweep.txt).
 struct SmPick { int G; long long wgs, rounds, resident; };
 SmPick sm_pick_images(const SmPlan& plan, int N, int n_frames, int n_cu) {
-    const size_t lds_wg = (size_t)plan.ent_bytes + 2 * (size_t)plan.buf_bytes + 2048;
+    const size_t lds_wg = (size_t)plan.ent_bytes + 2 * (size_t)plan.buf_bytes + 2 * (size_t)plan.mbuf_bytes + 2048;
     SmPick k;
     k.resident = (long long)n_cu * (long long)std::max<size_t>(1, (160 * 1024) / lds_wg);
     const long long items = (long long)plan.n_tiles * 2 * N * n_frames;
@@ -521,7 +573,8 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
     const EqView& V = L.view[0];
     const int N = S.N, NV = L.n_views;
     *herr = hipSuccess;
-    SmPlan* plan = sm_get_plan(L, S, cache, cap, Bx, R, lds_limit, s, herr);
+    const bool masked = L.mask[0] != nullptr;
+    SmPlan* plan = sm_get_plan(L, S, cache, cap, Bx, R, masked, lds_limit, s, herr);
     if (!plan) return *herr == hipSuccess ? 1 : -1;
     SmPick pick = sm_pick_images(*plan, N, L.n_frames, n_cu);
     // A job that cannot fill the GPU once even with the longest workgroups (cfg2: 188 tiles x 12 images / 12 = 188 workgroups per frame for
@@ -534,7 +587,7 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
         for (int g = 1; g <= kSmMaxImages; ++g) if ((2 * N) % g == 0) gmax = g;
         const long long coarsest = (long long)plan->n_tiles * 2 * N * L.n_frames / gmax;
         if (coarsest * 10 < pick.resident * 9) {
-            SmPlan* half = sm_get_plan(L, S, cache, cap, Bx, plan->rows / 2, lds_limit, s, herr);
+            SmPlan* half = sm_get_plan(L, S, cache, cap, Bx, plan->rows / 2, masked, lds_limit, s, herr);
             if (!half && *herr != hipSuccess) return -1;
             if (half) { plan = half; pick = sm_pick_images(*half, N, L.n_frames, n_cu); }
         }
@@ -557,10 +610,16 @@ int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, 
     for (int c = 0; c < S.n_rings; ++c) P.partner[c] = S.partner[c];
     P.src_stride = L.src_stride;
     P.dst_stride = L.dst_stride ? L.dst_stride : (int64_t)V.out_w * 3;
-    const size_t lds = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes;
-    *herr = hipFuncSetAttribute((const void*)eq_srcmajor_kernel<kSmConsumers>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
+    const size_t lds = (size_t)plan->ent_bytes + 2 * (size_t)plan->buf_bytes + 2 * (size_t)plan->mbuf_bytes;
+    if (masked) {
+        for (int f = 0; f < L.n_frames; ++f) P.mask[f] = L.mask[f];
+        P.mask_stride = (int32_t)L.mask_stride; P.mask_dw = L.W / 32; P.mbuf_bytes = plan->mbuf_bytes;
+    }
+    const void* const kernel = masked ? (const void*)eq_srcmajor_kernel<kSmConsumers, true> : (const void*)eq_srcmajor_kernel<kSmConsumers, false>;
+    *herr = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
     if (*herr != hipSuccess) return -1;
-    hipLaunchKernelGGL(eq_srcmajor_kernel<kSmConsumers>, dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
+    if (masked) hipLaunchKernelGGL((eq_srcmajor_kernel<kSmConsumers, true>), dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
+    else hipLaunchKernelGGL((eq_srcmajor_kernel<kSmConsumers, false>), dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
     *herr = hipGetLastError();
     return *herr == hipSuccess ? 0 : -1;
 }

@@ -242,6 +242,61 @@ def test_concurrent_callers_share_the_plan_cache(orc):
     assert not errors, errors
 
 
+def _check_masked(ctx, orc, frames, masks, W, H, specs, what, expect_kernel=2):
+    """frames / masks: lists of H x W x 3 / H x W uint8 arrays (0 = masked, 255 = keep, any value compared with 128)"""
+    nf, NV = len(frames), len(specs)
+    d_src = [ctx.to_device(f) for f in frames]
+    d_msk = [ctx.to_device(m) for m in masks]
+    d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(nf) for s in specs]
+    ctx.equirect_views_dev(d_src, W, H, 3, [gs360.View.make(*s) for s in specs], d_out, masks=d_msk)
+    ctx.sync(0)
+    assert ctx.get_option("last_eq_kernel") == expect_kernel, f"{what}: kernel {ctx.get_option('last_eq_kernel')}"
+    for f in range(nf):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0, mask=masks[f])
+        for k, s in enumerate(specs):
+            got = ctx.download(d_out[f * NV + k], (s[5], s[4], 3))
+            if not np.array_equal(got, want[k]):
+                bad = np.argwhere(got != want[k])
+                raise AssertionError(f"{what}: frame {f} view {k}: {len(bad)} mismatching bytes, first at {bad[0].tolist()}")
+    for b in d_src + d_msk + d_out:
+        ctx.free(b)
+
+
+def _noise_mask(H, W, seed, p_keep=0.5):
+    """per-texel noise: any error in WHICH texel is the nearest one shows"""
+    return np.where(np.random.default_rng(seed).random((H, W)) < p_keep, 255, 0).astype(np.uint8)
+
+
+MASKED_SHAPES = {
+    "ring of 6": (1920, 960, ring_views(6, 200, HFOV_12MM)),
+    "ring of 6, weak minification": (960, 480, ring_views(6, 240, 100.0)),
+    "ring of 4 rotated off the texel grid": (1280, 640, [(7.3 + 90.0 * i, 0.0, 110.0, 110.0, 160, 121) for i in range(4)]),
+    "full360coverage": (1920, 960, _family(PRESET_FULL360, HFOV_14MM, 200)),
+    "fisheyelike": (1920, 960, _family(PRESET_FISHEYELIKE, HFOV_17MM, 256)),
+    "odd source height": (1920, 959, _family(PRESET_FULL360, 100.0, 120)),
+}
+
+
+@pytest.mark.parametrize("name", list(MASKED_SHAPES))
+def test_masked_calls(forced, orc, name):
+    """the fused keep-mask (BASELINE config 5's fusion, gs360_equirect_views_masked_u8) through the source-major kernel: the keep bits of
+    a tile box are staged next to its texels; nearest texel incl. the half-way rows of upside-down images"""
+    W, H, specs = MASKED_SHAPES[name]
+    frames = [rand_image(H, W, seed=600 + f) for f in range(2)]
+    masks = [_noise_mask(H, W, 610 + f) for f in range(2)]
+    _check_masked(forced, orc, frames, masks, W, H, specs, name)
+
+
+def test_masked_calls_it_must_leave_to_the_gather_kernels(forced, orc):
+    # ring period not a whole number of keep dwords for any ring size the views fall into (2400 / 4 = 600, / 2 = 1200 texels); source
+    # width not a multiple of 32
+    for W, n in ((2400, 4), (1200, 3)):
+        H = W // 2
+        specs = [(i * 360.0 / n, 0.0, 100.0, 100.0, 96, 80) for i in range(n)]
+        assert (W // n) % 32 or W % 32
+        _check_masked(forced, orc, [rand_image(H, W, seed=620)], [_noise_mask(H, W, 621)], W, H, specs, f"{W} / {n}", expect_kernel=0)
+
+
 def test_ring_families_it_must_leave_to_the_gather_kernels(forced, orc):
     src = rand_image(480, 960, seed=251)
     lvl = [(90.0 * i, 0.0, 100.0, 100.0, 96, 96) for i in range(4)]

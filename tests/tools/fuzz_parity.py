@@ -137,16 +137,21 @@ def fuzz_srcmajor(ctx, rng, case):
     nf = int(rng.choice([1, 1, 2, 3]))
     frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(nf)]
     d_src = [ctx.to_device(f) for f in frames]
+    # a third of the cases with fused keep-masks (per-texel noise or blobs; source-major only when W and the ring period are whole keep dwords)
+    masks = d_msk = None
+    if rng.random() < 0.33:
+        masks = [np.where(rng.random((H, W)) < rng.choice([0.5, 0.9]), 255, int(rng.integers(0, 128))).astype(np.uint8) for _ in range(nf)]
+        d_msk = [ctx.to_device(m) for m in masks]
     views = [gs360.View.make(*s) for s in specs]
     dpad = int(rng.choice([0, 0, 4, 8, 3]))
     dstride = w * 3 + dpad if dpad else 0
     d_out = [ctx.alloc((dstride or w * 3) * h + 64) for _ in range(nf * count)]
     for b in d_out:
         ctx.memset(b, 0xAB)
-    ctx.equirect_views_dev(d_src, W, H, 3, views, d_out, dst_stride=dstride)
+    ctx.equirect_views_dev(d_src, W, H, 3, views, d_out, dst_stride=dstride, masks=d_msk)
     ok = True
     for f in range(nf):
-        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0, mask=masks[f] if masks else None)
         for k, s in enumerate(specs):
             raw = ctx.download(d_out[f * count + k], (h, dstride or w * 3))
             got = raw[:, :w * 3].reshape(h, w, 3)
@@ -157,7 +162,7 @@ def fuzz_srcmajor(ctx, rng, case):
             if dstride and not np.all(raw[:, w * 3:] == 0xAB):
                 ok = False
                 print(f"[srcmajor] case {case}: view {k} wrote into the row padding")
-    for b in d_out + d_src:
+    for b in d_out + d_src + (d_msk or []):
         ctx.free(b)
     return ok
 
