@@ -26,6 +26,10 @@
 // every store is a dword store and no output byte is written twice.  Plan entry: per quad a header (3 x column | row << 14 | view << 26), per
 // pixel (LDS byte offset of the top-left tap | fx << 17 | fy << 22).
 //
+// Masked calls (gs360_equirect_views_masked_u8: BASELINE config 5's fused keep-mask) stage the keep BITS of a tile box next to its texels
+// (the nearest texel of a pixel is one of its four taps); their plans hold box row and byte of a tap apart so that the bit position
+// follows from the pixel word.  cfg3 + mask 98-104 -> 81-92 us per frame (profiles/r05/srcmajor_masked.txt).
+//
 // Measured on MI355X (profiles/r05/): cfg2 14.1-15.5 us per frame against 18.7-19.6 for the gather kernel -- bound by the copies (the L1's
 // ~64 read requests per CU in flight at ~1,000 cycles each; 70 MB per frame move where the union of lines + the stores is 64 MB); cfg3
 // 58-63 us against 75-79 (LDS-staged kernel), cfg1 32-36 against 41-48: copies, stores, LDS and vector ALU each 55-70 % busy.
