@@ -388,13 +388,15 @@ def secondary_rows(ctx, steps=20):
         ("cfg5", "8K -> fisheyelike 10x2048^2, linear", 7680, 3840, fishlike, gs360.INTERP_LINEAR, False),
         ("cfg5+mask", "8K -> fisheyelike 10x2048^2, linear, fused keep-mask (threshold + pack pass inside the timed region)", 7680, 3840,
          fishlike, gs360.INTERP_LINEAR, True),
+        ("cfg3+mask", "8K -> full360coverage 12x1600^2, linear, fused keep-mask (pack pass inside the timed region)", 7680, 3840,
+         full360, gs360.INTERP_LINEAR, True),
     ]
     out = []
     for key, name, w, h, specs, interp, with_mask in plan:
         # frames per launch as in the full rows of main(): 8 for the 5.7K / 6 x 800^2 shapes, 4 for the 8K large-view presets
         r = equirect_cfg(ctx, name, w, h, specs, 8 if key in ("cfg1", "cfg1-cubic", "cfg2-cubic") else 4, steps, interp=interp, with_mask=with_mask)
         out.append({"config": key, "workload": name, "unit": "frame", "us_per_unit": r["us_per_frame"], "frac": r["frac_of_8TBps"],
-                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "parity_vs_oracle": r["parity_vs_oracle"]})
+                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "eq_kernel": r["eq_kernel"], "parity_vs_oracle": r["parity_vs_oracle"]})
     for key, name, interp in (("cfg2-u16", "8K rgb48 (uint16) -> 6x800^2, linear", gs360.INTERP_LINEAR),
                               ("cfg2-u16-cubic", "8K rgb48 (uint16) -> 6x800^2, cubic", gs360.INTERP_CUBIC)):
         r = equirect_u16_cfg(ctx, name, 7680, 3840, ring_views(6, 800, HFOV_12MM), 4, steps, interp)
