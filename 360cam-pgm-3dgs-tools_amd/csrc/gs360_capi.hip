@@ -33,6 +33,7 @@ constexpr size_t kSmPlanCap = 8;          // source-major plans a context keeps 
 constexpr size_t kSmLdsPerGroup = 80 * 1024;   // two workgroups of the source-major kernel per CU (160 KiB of LDS)
 constexpr double kSmMinPixels = 3.5e6;           // automatic selection of the source-major kernel: output pixels of the call (smaller calls are launch-bound)
 constexpr int kSmFamilyMinFrames = 4;          // automatic selection of the source-major kernel for calls of several rings: frames per call ...
+constexpr int kTsBoxBudget = 26 * 1024 - 64;     // largest tile box of the LDS-staged table kernel: two of them per workgroup, three workgroups per CU
 constexpr int kSmMaxBoxPct = 160;              // ... and tile boxes at most this large relative to their grid cells (profiles/r05/srcmajor_family_sweep.txt)
 
 #define HIP_TRY(expr)                                                                           \
@@ -49,7 +50,8 @@ constexpr double kPi = 3.14159265358979323846;
 
 // context options: name, default, range, environment seed (user switches only)
 enum Opt { kOptLanemap, kOptStage, kOptRing, kOptXcdGroup, kOptEqPersist, kOptTablePersist, kOptLanczosTable, kOptTableRows, kOptColorCube,
-           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptSrcMajorAdapt, kOptCount };
+           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptSrcMajorAdapt, kOptTableStage, kOptTableStageRows,
+           kOptTableStageWgs, kOptCount };
 struct OptDesc { const char* key; int def, lo, hi; const char* env; };
 const OptDesc kOpts[kOptCount] = {
     {"lanemap", -1, -1, 1, "GS360_LANEMAP"},          // -1 auto (per view, by minification), 0 rows, 1 blocked       (env: rows | blocked)
@@ -66,6 +68,9 @@ const OptDesc kOpts[kOptCount] = {
     {"srcmajor_rows", 32, 8, 128, nullptr},           // ... and source rows
     {"srcmajor_images", 0, 0, 12, nullptr},           // images of a tile one workgroup walks (0 auto; must divide twice the ring size)
     {"srcmajor_adapt", 1, 0, 1, nullptr},             // 1: jobs that do not fill the GPU take tiles of half the height; 0: srcmajor_rows as given (probes)
+    {"table_stage", -1, -1, 1, "GS360_TABLE_STAGE"},  // LDS-staged table kernel (bilinear RGB through map plans): -1 auto, 0 never, 1 every job that can
+    {"table_stage_rows", 32, 8, 32, nullptr},         // its output tile: rows (multiple of 8) of 64 pixels
+    {"table_stage_wgs", 0, 0, 4, nullptr},            // workgroups per CU (0 auto: what the LDS holds, at most three)
 };
 
 struct Staging {  // per-slot device staging used by the *_host conveniences
@@ -95,6 +100,8 @@ struct gs360_ctx {
     std::atomic<int> last_sm_rows{0}, last_sm_images{0};   // read-only "last_srcmajor_rows" / "last_srcmajor_images": tile rows and images per workgroup of that launch
     std::atomic<int> last_sm_box_pct{0};      // read-only option "last_srcmajor_box_pct": tile-box bytes of the last source-major plan in % of its grid cells
     std::atomic<int> last_eq_kernel{-1};      // read-only option "last_eq_kernel": 0 gather, 1 LDS-staged, 2 source-major (which kernel the last equirect call launched)
+    std::atomic<int> last_table_kernel{-1};   // read-only option "last_table_kernel": jobs of the last 8-bit table call that took the LDS-staged kernel (-1 none yet)
+    std::atomic<int> last_table_slow{0};      // read-only option "last_table_stage_slow_tiles": tiles of those jobs' stage plans without a box (redone from memory)
     // source-major plans of this context (gs360_srcmajor.hip), most recent calls' geometries
     std::mutex sm_mutex;
     std::vector<gs360::SmPlan*> sm_plans;
@@ -438,6 +445,7 @@ int gs360_ctx_set_option(gs360_ctx* c, const char* key, int value) {
             if (value < kOpts[k].lo || value > kOpts[k].hi)
                 return fail(GS360_ERR_ARG, "option %s: %d outside [%d, %d]", key, value, kOpts[k].lo, kOpts[k].hi);
             if (k == kOptSrcMajorBx && value % 16) return fail(GS360_ERR_ARG, "option srcmajor_bx must be a multiple of 16");
+            if (k == kOptTableStageRows && value % 8) return fail(GS360_ERR_ARG, "option table_stage_rows must be a multiple of 8");
             c->opt[k].store(value, std::memory_order_relaxed);
             return GS360_OK;
         }
@@ -448,6 +456,14 @@ int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
     if (!c || !key || !value) return fail(GS360_ERR_ARG, "NULL argument");
     if (!std::strcmp(key, "last_eq_kernel")) {
         *value = c->last_eq_kernel.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
+    if (!std::strcmp(key, "last_table_kernel")) {
+        *value = c->last_table_kernel.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
+    if (!std::strcmp(key, "last_table_stage_slow_tiles")) {
+        *value = c->last_table_slow.load(std::memory_order_relaxed);
         return GS360_OK;
     }
     if (!std::strcmp(key, "last_srcmajor_box_pct")) {
@@ -948,6 +964,9 @@ struct gs360_map_plan {         // float maps packed once (gs360_kernels.hip, ma
     int has_valid = 0;
     uint32_t* d_packed = nullptr;
     uint8_t* d_hi = nullptr;
+    // stage plans of this map (gs360_tablestage.hip), one per (source size, tile rows, valid bit applied): built at the first call that asks
+    mutable std::mutex ts_mutex;
+    mutable std::vector<gs360::TsPlan*> ts_plans;
 };
 
 namespace {
@@ -1032,6 +1051,7 @@ int gs360_map_plan_destroy(gs360_ctx* c, gs360_map_plan* p) {
     HIP_TRY(hipDeviceSynchronize());
     if (p->d_packed) HIP_TRY(hipFree(p->d_packed));
     if (p->d_hi) HIP_TRY(hipFree(p->d_hi));
+    for (gs360::TsPlan* t : p->ts_plans) gs360::ts_plan_free(t);
     delete p;
     return GS360_OK;
 }
@@ -1064,12 +1084,54 @@ static int remap_batches_u8(gs360_ctx* c, const gs360_remap_job* jobs, const gs3
         B.n_jobs = 0;
         B.persist_blocks = c->prop.multiProcessorCount * 8;      // two rounds of the four workgroups a CU holds (bicubic RGB)
         if (const int v = c->opt[kOptTablePersist].load(std::memory_order_relaxed); v >= 0) B.persist_blocks = v;   // option "table_persist" (probes): 0 = one tile per workgroup
+        // LDS-staged kernel (gs360_tablestage.hip) for the jobs that can take it: bilinear RGB through a map plan, dword-aligned source rows,
+        // an output whose quads start on dword boundaries (tight, or rows of whole dwords).  Their stage plans are built at the first call
+        // (one launch + one synchronisation of the slot's stream per map plan and source size).  Option "table_stage": 0 never, 1 every job
+        // that can, -1 (default) those whose plan has boxes for at least 7/8 of its tiles (a map that scatters its taps -- random test maps --
+        // would be redone pixel by pixel from memory).
+        TsLaunch S;
+        std::memset(&S, 0, sizeof(S));
+        const int opt_stage = c->opt[kOptTableStage].load(std::memory_order_relaxed);
+        S.R = c->opt[kOptTableStageRows].load(std::memory_order_relaxed);
+        S.wg_per_cu = c->opt[kOptTableStageWgs].load(std::memory_order_relaxed);
+        int slow_tiles = 0;
         for (int j = j0; j < n_jobs && j < j0 + GS360_MAX_VIEWS; ++j) {
             if (jobs[j].h == 0 || jobs[j].w == 0) continue;
-            if (int rc = fill_table_job(c, jobs[j], plans ? plans[j] : nullptr, C, interp, border_value, &B.job[B.n_jobs])) return rc;
+            TableLaunch& L = B.job[B.n_jobs];
+            if (int rc = fill_table_job(c, jobs[j], plans ? plans[j] : nullptr, C, interp, border_value, &L)) return rc;
+            const gs360_map_plan* plan = plans ? plans[j] : nullptr;
+            const bool quads_ok = ((uintptr_t)L.dst & 3) == 0 && (L.dst_stride == (int64_t)3 * L.w ? ((int64_t)L.h * L.w) % 4 == 0 : (L.w % 4 == 0 && L.dst_stride % 4 == 0));
+            if (opt_stage != 0 && plan && C == 3 && interp == GS360_INTERP_LINEAR && L.pipelined && quads_ok && ((uintptr_t)L.src & 3) == 0 &&
+                L.src_stride % 4 == 0 && (int64_t)L.H * L.src_stride < ((int64_t)1 << 31) && (int64_t)L.h * L.dst_stride < ((int64_t)1 << 32) &&
+                (int64_t)L.h * L.w < ((int64_t)1 << 30)) {
+                TsPlan* tp = nullptr;
+                {
+                    std::lock_guard<std::mutex> lock(plan->ts_mutex);
+                    for (TsPlan* q : plan->ts_plans)
+                        if (q->W == L.W && q->H == L.H && q->R == S.R && q->use_valid == L.use_valid) { tp = q; break; }
+                    if (!tp) {
+                        hipError_t he = hipSuccess;
+                        tp = ts_build_plan(plan->d_packed, plan->d_hi, L.h, L.w, L.W, L.H, S.R, L.use_valid, kTsBoxBudget,
+                                           c->stream[slot], &he);
+                        if (!tp) return fail(he == hipSuccess || he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "stage plan setup failed: %s", hipGetErrorString(he));
+                        plan->ts_plans.push_back(tp);
+                    }
+                }
+                if (opt_stage == 1 || tp->slow_tiles * 8 <= tp->n_tiles) {
+                    TsJobDesc& D = S.job[S.n_jobs++];
+                    D.src = L.src; D.dst = L.dst; D.packed = L.packed; D.packed_hi = L.packed_hi; D.plan = tp;
+                    D.src_stride = L.src_stride; D.dst_stride = L.dst_stride; D.fill = L.fill;
+                    for (int k = 0; k < 4; ++k) S.cval[k] = L.cval[k];
+                    slow_tiles += tp->slow_tiles;
+                    continue;                            // (B.job[B.n_jobs] is overwritten by the next job)
+                }
+            }
             ++B.n_jobs;
         }
+        if (S.n_jobs) HIP_TRY(ts_launch(S, c->prop.multiProcessorCount, 160 * 1024, c->stream[slot]));
         if (B.n_jobs) HIP_TRY(launch_table_batch(B, C, c->stream[slot]));
+        c->last_table_kernel.store(S.n_jobs, std::memory_order_relaxed);
+        c->last_table_slow.store(slow_tiles, std::memory_order_relaxed);
     }
     return GS360_OK;
 }

@@ -238,6 +238,36 @@ __device__ __forceinline__ void planned_coords(const uint32_t P, const uint32_t 
 
 hipError_t launch_map_pack(const float* map_x, const float* map_y, const uint8_t* valid, int64_t n, int nearest,
                            uint32_t* packed, uint8_t* packed_hi, hipStream_t s);
+// LDS-staged table kernel (gs360_tablestage.hip): bilinear RGB u8 through a map plan's STAGE PLAN -- per source size the output cut into
+// tiles of 64 pixels x R rows, per tile the box of source texels its taps touch, per pixel one dword (LDS offset | phases), tile-major
+struct TsTile { int32_t x0b, y0, nrows, wch, magic, chunks, ty, tx; };       // box of a tile: first byte of a source row, first row, rows, 16-byte chunks
+                                                                              // per row; ceil(2^20 / wch); chunks of the box; tile row / column in the output
+struct TsPlan {
+    int W = 0, H = 0, R = 0, h = 0, w = 0, use_valid = 0;            // key: source size, tile rows, whether the valid bit is applied
+    uint8_t* d_recs = nullptr;                                        // per tile: 64-byte head (TsTile) + R x 64 plan words
+    int n_tiles = 0, tiles_x = 0;
+    int max_box = 0;                                                  // bytes of the largest box
+    int slow_tiles = 0;                                               // tiles whose box exceeded the budget (every pixel redone from memory)
+};
+void ts_plan_free(TsPlan* p);
+TsPlan* ts_build_plan(const uint32_t* d_packed, const uint8_t* d_hi, int h, int w, int W, int H, int R, int use_valid, int box_budget, hipStream_t s,
+                      hipError_t* herr);
+struct TsJobDesc {
+    const uint8_t* src;
+    uint8_t* dst;
+    const uint32_t* packed;
+    const uint8_t* packed_hi;
+    const TsPlan* plan;
+    int64_t src_stride, dst_stride;
+    int32_t fill;
+};
+struct TsLaunch {
+    TsJobDesc job[GS360_MAX_VIEWS];
+    int32_t n_jobs, R;
+    int32_t wg_per_cu;                   // 0 auto (probes)
+    uint8_t cval[4];
+};
+hipError_t ts_launch(const TsLaunch& L, int n_cu, size_t lds_per_cu, hipStream_t s);
 hipError_t launch_table_batch(TableBatch& B, int C, hipStream_t s);   // all jobs share C and interp (job[0].interp)
 hipError_t launch_fisheye(const FeLaunch& L, int C, hipStream_t s);
 
