@@ -1,18 +1,28 @@
 // gs360_tablestage.hip -- LDS-staged, plan-driven cv2.remap for the dual-fisheye tool's hot call: INTER_LINEAR, BORDER_CONSTANT, 8-bit RGB,
 // `out[~valid] = mask_value` (cli_tools/gs360_DualFisheyeDistortionCalibration.py:2001-2014; the maps are those of DF:1759-1823, applied to
 // every lens pair of a run, DF:2582-2592).  north_star's shape for this half of the path: one output tile per workgroup turn, source
-// texels staged in LDS, nothing but the stores on the consumers' memory path.
+// texels staged in LDS.
 //
 // table_remap_kernel (gs360_table.hip) gathers per pixel: through a map plan it reads 5 plan bytes and two 12-byte tap windows per pixel
 // from memory -- at cfg4's 1.26 source texels per output pixel that is five vector-memory instructions per 64 pixels on the texture path
-// (72 % busy) next to ~95 vector-ALU instructions of coordinate unpacking, border tests and address arithmetic (72 % busy).  Here a map
-// plan grows a STAGE PLAN per source size (built on the GPU at the first call, table_stage_plan_kernel): the output is cut into tiles of 64
-// pixels x R rows; per tile the box of source texels its pixels' taps touch (first byte, first row, rows, 16-byte chunks per row) and per
-// pixel ONE dword -- LDS byte offset of the top-left tap | fx << 17 | fy << 22 -- stored tile-major, so that a tile's words are one
-// contiguous run.  A workgroup (one loader wavefront + eight consumer wavefronts, two alternating LDS buffers) walks a run of tiles: the
-// loader copies words and box of tile g + 1 with global_load_lds_dwordx4 while the consumers render tile g -- plan word and both tap windows
-// from LDS, the gather kernels' exact-integer blend (gs360_blend.h), a quad's four 24-bit pixels re-sliced into three dwords by two DPP
-// moves, one dword store per lane.  No coordinate arithmetic, no border test, no map read in the loop.
+// (72 % busy) next to ~85 vector-ALU instructions of coordinate unpacking, border tests and address arithmetic.  Here a map plan grows a
+// STAGE PLAN per source size (built on the GPU at the first call, table_stage_plan_kernel): the output is cut into tiles of 64 pixels x R
+// rows; per tile a RECORD -- a head (the box of source texels its pixels' taps touch: first byte, first row, rows, 16-byte chunks per
+// row) and per pixel ONE dword, LDS byte offset of the top-left tap | fx << 17 | fy << 22, tile-major.  A workgroup of eight wavefronts
+// walks a run of tiles; everything a tile needs is requested one tile AHEAD by ordinary loads into registers -- its head, each wavefront's
+// plan words (four row slots) and each wavefront's share of the box (16 bytes per lane) -- and the box is written to the other LDS buffer
+// after the current tile's rendering: two tap windows per pixel from LDS, the gather kernels' exact-integer blend (gs360_blend.h), a
+// quad's four 24-bit pixels re-sliced into three dwords by two DPP moves, one dword store per lane.  No coordinate arithmetic, no border
+// test, no map read in the loop.
+//
+// Measured (MI355X, cfg4 = 2 x 4000^2 -> 6 x 1750^2 through plans, four pairs in turn, HBM-cold; profiles/r06/table_stage/): 64-65 us per
+// pair against 69-71 for the gather kernel in the same runs (177 + 59 MB moved instead of 196 + 60, 19.8 M instead of 24.2 M vector
+// instructions).  What was tried on the way and why it lost: LDS copies (global_load_lds) by a loader wavefront -- a CU takes one 1 KiB copy
+// instruction per ~100 cycles whatever issues it (25 GB/s per CU: the boxes and words alone 29 us), one wavefront one per ~390 cycles, and
+// beside consumers that read LDS the loaders' issue slows to ~1000 cycles per instruction (91 us per pair with one loader, 78 with three);
+// every wavefront copying its share before rendering (the copy issue and the rendering then alternate: 100 us); thinner tiles (a row segment
+// of a yawed or pitched view runs diagonally through the fisheye image: the bounding boxes of 64 x 8 tiles hold 2.6x their texels, those
+// of 64 x 32 tiles 1.6x).
 //
 // Pixels the loop cannot serve carry bit 31 and a kind: the valid fill (DF:2009-2014), the border constant (all four taps outside), and
 // SLOW ones -- a tap pair that straddles the image border, or any pixel of a tile whose box exceeds the LDS budget (arbitrary maps) --
@@ -31,26 +41,10 @@ namespace gs360 {
 
 namespace {
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void global_void_t;
-
 constexpr int kTsWaves = 8;                             // wavefronts per workgroup
 constexpr int kTsRecHead = 64;                          // bytes of a tile record in front of its plan words (TsTile + padding)
 constexpr uint32_t kTsSpecial = 0x80000000u;            // plan word: bit 31 = not served by the loop; bits 29-30 = kind
 constexpr uint32_t kTsFill = 0u << 29, kTsBorder = 1u << 29, kTsSlow = 2u << 29;
-
-// LDS copy of 16 bytes per lane (global_load_lds_dwordx4) as an asm statement: written with the builtin, the compiler orders every later LDS
-// read of the wavefront behind the copy with s_waitcnt vmcnt(0) -- here a wavefront issues its share of the NEXT tile's copy and then
-// renders THIS tile from the other buffer, which that wait would serialise.  `lds_dst` = wave-uniform LDS byte address (the lanes' 16 bytes
-// land back to back from there), `gsrc` = each lane's source.  Completion: the kernel's own s_waitcnt vmcnt(0) + barrier per tile.
-__device__ __forceinline__ void glds16(const void* gsrc, const uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {     // wave-uniform LDS pointer -> its byte address in an SGPR
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void_t*)p);
-}
 
 // first flat pixel of row y's span (tight outputs): y w rounded up to a multiple of four; r(h) = h w
 __host__ __device__ __forceinline__ int ts_span_start(const int y, const int h, const int w) { return y < h ? (y * w + 3) & ~3 : h * w; }

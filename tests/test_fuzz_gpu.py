@@ -10,7 +10,7 @@ from conftest import ROOT
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lanemap,ring", [("", ""), ("rows", ""), ("blocked", ""), ("", "1"), ("blocked", "3"), ("staged", ""), ("staged", "2"),
-                                          ("srcmajor", ""), ("srcmajor-only", "")])
+                                          ("srcmajor", ""), ("srcmajor-only", ""), ("tablestage-only", ""), ("tablestage-forced", "")])
 def test_fuzz_parity_short(lanemap, ring):
     """lanemap forces one lane map of the equirect kernel, ring caps the members of a yaw ring (1 = no coordinate sharing); "srcmajor" forces
     the source-major kernel onto every call whose geometry fits it, "srcmajor-only" spends the whole run on such rings (context options:
@@ -23,6 +23,10 @@ def test_fuzz_parity_short(lanemap, ring):
     elif lanemap == "srcmajor-only":
         opts += ["srcmajor=1"]
         extra = ["--only", "srcmajor"]
+    elif lanemap == "tablestage-only":                 # the LDS-staged table kernel's own family (smooth maps, several jobs per call, padded outputs)
+        extra = ["--only", "tablestage"]
+    elif lanemap == "tablestage-forced":               # every family with the staged table kernel forced onto each plan job it can take (random maps: all SLOW)
+        opts += ["table_stage=1"]
     elif lanemap:
         opts += [f"lanemap={1 if lanemap == 'blocked' else 0}"]
     if ring:

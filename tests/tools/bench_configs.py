@@ -357,13 +357,15 @@ def cfg4_rows(ctx, steps, interps=((1, "linear"), (2, "cubic")), rotate=4):
                     ctx.remap_tables_dev(jobs[r], 3, interp=interp, border_value=(0, 0, 0, 0), slot=0)
             ms = time_steps(ctx, call, steps)
             last = (turn[0] - 1) % rotate
-            timed.append((interp, label + (", map plans" if planned else ""), ms, over_plan if planned else over_float, last,
-                          ctx.download(d_out[v0], (1750, 1750, 3))))
+            staged = ctx.get_option("last_table_kernel")            # jobs of the last call that took the LDS-staged kernel (tile records: 4.03 B/px)
+            over = (int(px * (4 + 64 / 2048)) if staged else over_plan) if planned else over_float
+            timed.append((interp, label + (", map plans" if planned else ""), ms, over, last,
+                          ctx.download(d_out[v0], (1750, 1750, 3)), "table_staged_kernel" if planned and staged else "table_remap_kernel"))
     res = []
-    for interp, label, ms, over, last, got in timed:
+    for interp, label, ms, over, last, got, kern in timed:
         want = orc.valid_fill(orc.remap_u8(pairs_host[last][t["lens_key"]], t["map_x"], t["map_y"], interp=interp, threads=0), t["valid"], 0)
         res.append({"config": f"cfg4 dual-fisheye 2x4000^2 -> 6x1750^2, table mode, {label}, {rotate} pairs in turn (HBM-cold)",
-                    "key": label.replace(", map plans", "-plans"),
+                    "key": label.replace(", map plans", "-plans"), "kernel": kern,
                     "ms_per_pair": round(ms, 4), "algorithmic_MB_per_pair": round(algo / 1e6, 1), "overhead_MB_per_pair": round(over / 1e6, 1),
                     "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3), "frac_incl_map_bytes": round((algo + over) / ms / 1e6 / 8000, 3),
                     "parity_vs_oracle": bool(np.array_equal(got, want))})
@@ -406,7 +408,7 @@ def secondary_rows(ctx, steps=20):
         out.append({"config": "cfg4-" + r["key"], "workload": r["config"], "unit": "lens pair",
                     "us_per_unit": round(r["ms_per_pair"] * 1e3, 1), "frac": r["frac_of_8TBps"],
                     "algorithmic_MB_per_unit": r["algorithmic_MB_per_pair"], "overhead_MB_per_unit": r["overhead_MB_per_pair"],
-                    "frac_incl_overhead": r["frac_incl_map_bytes"], "parity_vs_oracle": r["parity_vs_oracle"]})
+                    "frac_incl_overhead": r["frac_incl_map_bytes"], "kernel": r["kernel"], "parity_vs_oracle": r["parity_vs_oracle"]})
     for r in color_cfg(ctx, steps):
         kind = "color-u16" if "uint16" in r["config"] else ("color-noise" if "noise" in r["config"] else "color-smooth")
         out.append({"config": kind, "workload": r["config"], "unit": "4000^2 image", "us_per_unit": round(r["ms_per_image"] * 1e3, 1),

@@ -215,6 +215,76 @@ def fuzz_table(ctx, rng, case):
     return True
 
 
+def fuzz_tablestage(ctx, rng, case):
+    """the LDS-staged table kernel (bilinear RGB through map plans, csrc/gs360_tablestage.hip): smooth maps of random scale / rotation /
+    radial term that cross the source's borders, valid fills, 1-4 jobs per call on one source, tight outputs (any width with h w % 4 == 0)
+    and padded ones (rows of whole dwords), tiles of 8 / 16 / 32 rows; forced onto every job (option table_stage = 1)"""
+    W = 4 * int(rng.integers(2, 160))                    # rows of whole dwords: what the kernel's box loads need
+    H = int(rng.integers(2, 400))
+    src = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    d_src = ctx.to_device(src)
+    rows = int(rng.choice([8, 16, 32]))
+    bv = tuple(float(v) for v in rng.integers(0, 256, 4))
+    n_jobs = int(rng.integers(1, 5))
+    jobs, wants, plans, bufs, strides = [], [], [], [], []
+    for _ in range(n_jobs):
+        pad = int(rng.choice([0, 0, 4, 16]))
+        w = int(rng.integers(1, 70)) * 4 if pad else int(rng.integers(1, 280))
+        h = int(rng.integers(1, 120))
+        if not pad and (h * w) % 4:
+            h = 4 * ((h + 3) // 4)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        u, v = xx / max(w - 1, 1) - 0.5, yy / max(h - 1, 1) - 0.5
+        ang, sc, k2 = rng.uniform(-3.2, 3.2), rng.uniform(0.05, 1.6), rng.uniform(-0.3, 0.3)
+        kk = 1.0 + k2 * (u * u + v * v)
+        mx = (((u * np.cos(ang) - v * np.sin(ang)) * kk * sc + rng.uniform(0.2, 0.8)) * (W - 1)).astype(np.float32)
+        my = (((u * np.sin(ang) + v * np.cos(ang)) * kk * sc + rng.uniform(0.2, 0.8)) * (H - 1)).astype(np.float32)
+        if rng.random() < 0.3:                           # exact grid points: weight-zero taps on the last column / row
+            mx, my = np.rint(mx).astype(np.float32), np.rint(my).astype(np.float32)
+        valid = (rng.random((h, w)) > 0.2) if rng.random() < 0.5 else None
+        fill = int(rng.integers(0, 256))
+        d = [ctx.to_device(mx), ctx.to_device(my), ctx.to_device(valid.astype(np.uint8)) if valid is not None else None]
+        plans.append(ctx.map_plan(d[0], d[1], d[2], h, w))
+        for b in d:
+            if b is not None:
+                ctx.free(b)
+        stride = w * 3 + pad
+        dst = ctx.alloc(h * stride)
+        ctx.memset(dst, 0xAB)
+        bufs.append(dst)
+        strides.append(stride)
+        jobs.append(gs360.capi.RemapJob(d_src.ptr, H, W, 0, None, None, dst.ptr if valid is not None else None, h, w, fill, dst.ptr, stride))
+        want = orc.remap_u8(src, mx, my, interp=1, border_value=bv, threads=0)
+        wants.append((orc.valid_fill(want.copy(), valid, fill) if valid is not None else want).reshape(h, w, 3))
+    import ctypes as C
+    arr = (gs360.capi.RemapJob * n_jobs)(*jobs)
+    pl = (C.c_void_p * n_jobs)(*plans)
+    cbv = (C.c_double * 4)(*bv)
+    with ctx.options(table_stage=1, table_stage_rows=rows):
+        gs360.capi._check(ctx.L.gs360_remap_plans_u8(ctx.handle, arr, pl, n_jobs, 3, 1, cbv, 0), ctx.L)
+        ctx.sync(0)
+        staged = ctx.get_option("last_table_kernel")
+    ok = staged == n_jobs
+    if not ok:
+        print(f"[tablestage] case {case}: {staged} of {n_jobs} jobs took the staged kernel")
+    for k in range(n_jobs):
+        h, w = wants[k].shape[:2]
+        raw = ctx.download(bufs[k], (h, strides[k]))
+        got = raw[:, :w * 3].reshape(h, w, 3)
+        if not np.array_equal(got, wants[k]):
+            ok = False
+            bad = np.argwhere(got != wants[k])
+            print(f"[tablestage] case {case}: job {k} src {W}x{H} map {w}x{h} rows={rows} stride={strides[k]}: {len(bad)} bytes differ, first at {bad[0].tolist()}")
+        if strides[k] > w * 3 and not np.all(raw[:, w * 3:] == 0xAB):
+            ok = False
+            print(f"[tablestage] case {case}: job {k} wrote into the row padding")
+    for pl_ in plans:
+        ctx.map_plan_free(pl_)
+    for b in bufs + [d_src]:
+        ctx.free(b)
+    return ok
+
+
 def _remap_planned(ctx, src, mx, my, valid, interp, bv, fill, dtype):
     H, W, c = src.shape
     h, w = mx.shape
@@ -392,14 +462,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
                     help="context option (include/gs360.h: gs360_ctx_set_option), e.g. lanemap=1, stage=1, ring=3, srcmajor=1")
-    ap.add_argument("--only", default="", help="comma list of case families (equirect,table,fisheye,color,u16,srcmajor)")
+    ap.add_argument("--only", default="", help="comma list of case families (equirect,table,fisheye,color,u16,srcmajor,tablestage)")
     args = ap.parse_args()
     ctx = gs360.Context(0, n_slots=2)
     for kv in args.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
     t0 = time.time()
-    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye, "color": fuzz_color, "u16": fuzz_u16, "srcmajor": fuzz_srcmajor}
+    fns = {"equirect": fuzz_equirect, "table": fuzz_table, "fisheye": fuzz_fisheye, "color": fuzz_color, "u16": fuzz_u16, "srcmajor": fuzz_srcmajor, "tablestage": fuzz_tablestage}
     names = tuple(n for n in fns if not args.only or n in args.only.split(","))
     counts = {n: 0 for n in names}
     case, failures = 0, 0
