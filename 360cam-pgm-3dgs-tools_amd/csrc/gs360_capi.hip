@@ -3,6 +3,7 @@
 // rounding to float32) and launch batching.  No CPU compute path exists here on purpose: without a GPU
 // every entry point fails with GS360_ERR_NODEV / GS360_ERR_HIP.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -494,7 +495,24 @@ int gs360_device_pci_bus_id(gs360_ctx* c, char* buf, size_t n) {
 
 int gs360_device_info(gs360_ctx* c, char* name, size_t n, int32_t* cu_count, uint64_t* hbm_bytes) {
     if (!c) return fail(GS360_ERR_ARG, "ctx is NULL");
-    if (name && n) snprintf(name, n, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (name && n) {
+        // hipDeviceProp_t::name comes back empty on some driver stacks (the MI355X pool's): the amdgpu driver's product_name then
+        char product[128] = "";
+        std::snprintf(product, sizeof(product), "%s", c->prop.name);
+        if (!product[0]) {
+            char bus[32] = "", path[96];
+            if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->device) == hipSuccess) {
+                for (char* q = bus; *q; ++q) *q = (char)std::tolower((unsigned char)*q);
+                std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/product_name", bus);
+                if (FILE* f = std::fopen(path, "r")) {
+                    if (std::fgets(product, (int)sizeof(product), f)) product[std::strcspn(product, "\r\n")] = 0;
+                    std::fclose(f);
+                }
+            }
+            (void)hipGetLastError();
+        }
+        snprintf(name, n, "%s (%s)", product[0] ? product : "AMD GPU", c->prop.gcnArchName);
+    }
     if (cu_count) *cu_count = c->prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (uint64_t)c->prop.totalGlobalMem;
     return GS360_OK;

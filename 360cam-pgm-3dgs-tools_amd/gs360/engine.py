@@ -301,18 +301,23 @@ class Engine:
         return capi.View.make(job.fnum("yaw"), job.fnum("pitch"), job.fnum("h_fov"), job.fnum("v_fov"), job.width, job.height), 0
 
     def _launch_batch(self, st: _DeviceState, buf, H, W, C, views, interp, flags, dtype=np.uint8):
-        """One batched launch for `views` of one resident frame; returns [(array aliasing pinned memory, PinnedBuffer)]."""
+        """One batched launch for `views` of one resident frame -- or of a WINDOW of resident frames (`buf` a list: the frames of a video
+        the view jobs walk together, PC:746-749, PC:1049-1078; ring families reach the source-major kernel from four frames per call).
+        Returns [(array aliasing pinned memory, PinnedBuffer)] per view; for a window a list of those, one per frame."""
         with st.lock:
             slot = next(st.slot_cycle)
         ctx, L = st.ctx, st.ctx.L
         esz = np.dtype(dtype).itemsize
-        sizes = [v.height * v.width * C * esz for v in views]
+        window = isinstance(buf, list)
+        bufs = buf if window else [buf]
+        n_views = len(views)
+        sizes = [v.height * v.width * C * esz for v in views] * len(bufs)           # frame-major, as gs360_equirect_views_u8 writes them
         d_out = [st.take(st.dev_pool, n, ctx.alloc) for n in sizes]
         h_out = [st.take(st.pin_pool, n, ctx.pinned) for n in sizes]
         t0 = time.perf_counter()
         try:
             with ctx.slot_locks[slot]:
-                ctx.equirect_views_dev([buf], W, H, C, views, d_out, slot=slot, interp=interp, flags=flags, dtype=dtype)
+                ctx.equirect_views_dev(bufs, W, H, C, views, d_out, slot=slot, interp=interp, flags=flags, dtype=dtype)
                 for d, hb, n in zip(d_out, h_out, sizes):
                     capi._check(L.gs360_download(ctx.handle, hb.ptr, d.ptr, n, slot), L)
                 ctx.sync(slot)
@@ -325,10 +330,16 @@ class Engine:
                 st.give(st.dev_pool, d)
         with st.pool_lock:
             st.stats["launches"] += 1
-            st.stats["views"] += len(views)
+            st.stats["views"] += len(sizes)
+            st.stats["frames"] = st.stats.get("frames", 0) + len(bufs)
+            # which kernel the launch ran (the context's read-only option; another slot's launch may have overwritten it: statistics only)
+            kname = {0: "launches_gather", 1: "launches_staged", 2: "launches_srcmajor"}.get(ctx.get_option("last_eq_kernel"))
+            if kname:
+                st.stats[kname] = st.stats.get(kname, 0) + 1
             st.stats["gpu_s"] += time.perf_counter() - t0
-        return [(np.frombuffer(hb.view, dtype=dtype, count=n // esz).reshape(v.height, v.width, C), hb)
-                for hb, n, v in zip(h_out, sizes, views)]
+        flat = [(np.frombuffer(hb.view, dtype=dtype, count=n // esz).reshape(v.height, v.width, C), hb)
+                for hb, n, v in zip(h_out, sizes, views * len(bufs))]
+        return [flat[f * n_views:(f + 1) * n_views] for f in range(len(bufs))] if window else flat
 
     def _render(self, st: _DeviceState, fkey, get_frame, view, interp, flags=0, expected=1, stop_event=None):
         """Render `view` of the frame identified by `fkey`, coalesced with the other views of that frame that arrive
@@ -356,11 +367,16 @@ class Engine:
                     b.state = "running"
                     del st.open_batches[key]
                     views = list(b.views)
-                res = self._launch_batch(st, buf, H, W, C, views, interp, flags, dtype)
+                if buf is None:                   # (a video's window past its last frame)
+                    res = [None] * len(views)
+                else:
+                    res = self._launch_batch(st, buf, H, W, C, views, interp, flags, dtype)
+                    if isinstance(buf, list):     # a window: per member the list of its view's frames
+                        res = [[res[f][i] for f in range(len(buf))] for i in range(len(views))]
                 with st.batch_cond:
                     b.results = res
                     for i in b.abandoned:         # followers that were cancelled meanwhile will not come for their view
-                        st.give(st.pin_pool, res[i][1])
+                        self._give_back(st, res[i])
             except BaseException as exc:  # noqa: BLE001  (handed to every member of the batch)
                 with st.batch_cond:
                     if st.open_batches.get(key) is b:
@@ -376,7 +392,7 @@ class Engine:
                         if b.results is None:
                             b.abandoned.add(idx)  # the leader returns this view's pinned block when the launch completes
                         else:
-                            st.give(st.pin_pool, b.results[idx][1])
+                            self._give_back(st, b.results[idx])
                     raise capi.Gs360Error(-2, "cancelled")
         if b.error is not None:
             if leader:
@@ -384,8 +400,21 @@ class Engine:
             raise capi.Gs360Error(-2, f"batched launch failed: {b.error}")
         if b.results is None:
             raise capi.Gs360Error(-2, "cancelled")
-        arr, hb = b.results[idx]
+        mine = b.results[idx]
+        if mine is None:
+            return None, (lambda: None)
+        if isinstance(mine, list):                # a window of frames: [array per frame]
+            return [a for a, _hb in mine], (lambda: self._give_back(st, mine))
+        arr, hb = mine
         return arr, (lambda: st.give(st.pin_pool, hb))
+
+    @staticmethod
+    def _give_back(st, res):
+        """the pinned block(s) of one member's result go back to the pool"""
+        if res is None:
+            return
+        for _a, hb in (res if isinstance(res, list) else [res]):
+            st.give(st.pin_pool, hb)
 
     def announce(self, jobs, workers=None):
         """Optional hint from a caller that knows its whole job list (the drop-in CLI's main()): how many view jobs each
@@ -545,18 +574,29 @@ class Engine:
         written = 0
         try:
             while True:
-                fr = sess.frame(token, written)
-                if fr is None:
+                # The view jobs of a video walk its frames together, a WINDOW at a time: frames k .. k + n of every active view go out as
+                # ONE launch (the frames are resident in HBM; n = what is decoded already, at most video._WINDOW).  The batch leader takes
+                # the window from the session, the others adopt it.
+                k0 = written
+                st = sess.state_for(k0)
+                sess.advance(token, k0)
+
+                def get_window(k0=k0):
+                    win = sess.window(token, k0)
+                    if win is None:
+                        return None, 0, 0, 3, np.uint8
+                    _st, bufs, H, W, fdtype = win
+                    return bufs, H, W, 3, fdtype
+                outs, release = self._render(st, ("video", id(sess), k0), get_window, view, interp, flags,
+                                             expected=min(sess.active_jobs, expected_jobs or sess.active_jobs), stop_event=stop_event)
+                if outs is None:
                     break
-                st, buf, H, W, fdtype = fr
-                # the view jobs of a video walk its frames together: frame k of every active view goes out as one launch
-                out, release = self._render(st, ("video", id(sess), written), lambda: (buf, H, W, 3, fdtype), view, interp, flags,
-                                            expected=min(sess.active_jobs, expected_jobs or sess.active_jobs), stop_event=stop_event)
                 try:
-                    imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)
+                    for out in outs:
+                        imageio.write_image(video.output_path(job, plan, written), out, jpeg_q=job.jpeg_q)
+                        written += 1
                 finally:
                     release()
-                written += 1
         finally:
             with self.videos_lock:
                 sess.leave(token)

@@ -21,6 +21,7 @@ bit-comparable with the reference's -- parity at this seam is unpinned (no ffmpe
 import os
 import re
 import subprocess
+import time
 import tempfile
 import threading
 from dataclasses import dataclass
@@ -178,6 +179,13 @@ class SharedBudget:
             self.used += n
 
 
+# View jobs take the frames of a video in WINDOWS of this many (one batched launch per window and device: ring families -- the
+# `full360coverage` preset, PC:616-680 -- reach the source-major kernel from four frames per call, csrc/gs360_capi.hip); frames are dealt to
+# the devices in blocks of a window, so that a window's frames sit on one device.  GS360_VIDEO_WINDOW=1: one frame per launch (A/B).
+_WINDOW = max(1, min(16, int(os.environ.get("GS360_VIDEO_WINDOW", "4"))))
+_WINDOW_WAIT_S = 0.05                             # longest a view job waits for the frames behind the first one of its window
+
+
 class VideoSession:
     """Decoded frames of one video on the engine's devices, streamed: the reader keeps at most `budget` bytes resident, view
     jobs walk the frames with a cursor each, and a frame every registered job has passed is retired when the reader needs
@@ -265,6 +273,7 @@ class VideoSession:
 
     def _reader(self):
         pinned = {}                               # (device, nbytes) -> [two pinned blocks]
+        turn = {}                                 # device -> which of its two blocks the next frame takes
         pending = None                            # (state, event index, publish args) of the upload still in flight
         errlog = None
         try:
@@ -290,12 +299,13 @@ class VideoSession:
                     raise PpmError("decoder delivered {}-level samples; the engine takes 8- or 16-bit frames".format(maxval + 1))
                 fdtype = np.uint16 if maxval == 65535 else np.uint8
                 nbytes = w * h * 3 * np.dtype(fdtype).itemsize
-                st = self.states[k % len(self.states)]
+                st = self.state_for(k)
                 # two pinned staging blocks per device: the pipe read of frame k overlaps the H2D copy of frame k-1
                 pair = pinned.get((id(st), nbytes))
                 if pair is None:
                     pair = pinned[(id(st), nbytes)] = [st.ctx.pinned(nbytes), st.ctx.pinned(nbytes)]
-                which = (k // len(self.states)) & 1
+                which = turn.get(id(st), 0)        # the device's two staging blocks in turn
+                turn[id(st)] = which ^ 1
                 stage = pair[which]
                 host = np.frombuffer(stage.view, dtype=np.uint8, count=nbytes)      # the pinned block as an array
                 read_exact_into(out, memoryview(host))
@@ -375,6 +385,43 @@ class VideoSession:
                 self.active_jobs -= 1
                 self.done_jobs += 1
             self.cond.notify_all()
+
+    def state_for(self, k: int):
+        """the device frame k is (or will be) resident on: blocks of _WINDOW frames round-robin"""
+        return self.states[(k // _WINDOW) % len(self.states)]
+
+    def advance(self, token, k: int):
+        """the job `token` declares frames < k done (without asking for one)"""
+        with self.cond:
+            if token in self.cursors and k > self.cursors[token]:
+                self.cursors[token] = k
+                self.cond.notify_all()
+
+    def window(self, token, k0: int, limit: int = _WINDOW):
+        """frames k0, k0 + 1, ... of ONE device for one batched launch: waits for frame k0 like frame(), then takes its successors -- at
+        most `limit`, never past the end of k0's block -- as (state, [DeviceBuffer], H, W, dtype); None after the last frame.  For the
+        rest of the window it waits only while the decoder is still delivering, and at most _WINDOW_WAIT_S in all: the reader may be
+        blocked at its budget until this very job moves on (a bounded wait cannot deadlock; a decoder slower than that is the
+        bottleneck whatever the window)."""
+        first = self.frame(token, k0)
+        if first is None:
+            return None
+        st, buf, h, w, dt = first
+        end = min(k0 + max(1, limit), (k0 // _WINDOW + 1) * _WINDOW)
+        bufs = [buf]
+        deadline = time.monotonic() + _WINDOW_WAIT_S
+        with self.cond:
+            while self.count < end and not self.finished and not self.closing:
+                left = deadline - time.monotonic()
+                if left <= 0 or (self.stop_event is not None and self.stop_event.is_set()):
+                    break
+                self.cond.wait(timeout=left)
+            for k in range(k0 + 1, min(end, self.count)):
+                fr = self.frames.get(k)
+                if fr is None or fr[0] is not st or fr[2:] != (h, w, dt):
+                    break
+                bufs.append(fr[1])
+        return st, bufs, h, w, dt
 
     def frame(self, token, k: int):
         """k-th decoded frame as (state, DeviceBuffer, H, W, dtype) for the job `token`, which thereby declares frames < k

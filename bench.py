@@ -64,9 +64,44 @@ LINE_BYTES_PER_FRAME = 718_080 * 128 + 11_520_000
 # ... and the bound of the source-major kernel (round 5), which pulls each distinct line ONCE for all six views: the union of the views'
 # line sets is 413,172 lines per frame (tests/test_oracle_equirect.py), + the stores
 UNION_LINE_BYTES_PER_FRAME = 413_172 * 128 + 11_520_000
+# SURVEY 8(d)'s STRICTER figure: the union over the six views of a frame, every distinct texel once (11,685,864 texels, counted by the oracle:
+# tests/test_oracle_equirect.py) + the stores.  The honest yardstick for a kernel that shares reads between views (`roofline.frac_union`).
+UNION_BYTES_PER_FRAME = 11_520_000 + 11_685_864 * 3
 HBM_STREAM_GBS = 6290.0
 LAUNCHES_PER_STEP = 16             # a step = 16 launches of `--frames` frames at EVERY N (round-4 verdict: same step semantics at N = 1 and N > 1)
 EQ_KERNEL_NAMES = {0: "eq_views_kernel<3>", 1: "eq_staged_kernel", 2: "eq_srcmajor_kernel"}
+
+
+def device_state(bus_id):
+    """clocks / power / partition modes of the GPU a rank sits on, read from the amdgpu driver's sysfs files (no child process: a process
+    that has initialised the GPU must not exec): sclk and mclk as the driver reports them RIGHT NOW -- call it while the device is busy."""
+    base = pathlib.Path("/sys/bus/pci/devices") / bus_id.lower()
+    out = {}
+
+    def rd(p):
+        try:
+            return p.read_text().strip()
+        except OSError:
+            return None
+    for key, name in (("product", "product_name"), ("compute_partition", "current_compute_partition"), ("memory_partition", "current_memory_partition"),
+                      ("perf_level", "power_dpm_force_performance_level")):
+        v = rd(base / name)
+        if v is not None:
+            out[key] = v
+    try:
+        hw = sorted((base / "hwmon").glob("hwmon*"))[0]
+    except (OSError, IndexError):
+        hw = None
+    if hw is not None:
+        for key, name, scale in (("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6), ("power_w", "power1_input", 1e-6),
+                                 ("power_cap_w", "power1_cap", 1e-6), ("temp_c", "temp2_input", 1e-3)):
+            v = rd(hw / name)
+            if v is not None:
+                try:
+                    out[key] = round(float(v) * scale, 1)
+                except ValueError:
+                    pass
+    return out
 
 
 def norm_yaw(a):
@@ -461,8 +496,10 @@ def main():
     # settle: the same launches, untimed, until the device has been busy for --settle-ms (clocks ramp over the first ~100 ms of
     # load: with 5 warm-up steps = 1.6 ms alone the 20 timed steps that follow run 6 % slower than in steady state), then the
     # caller's W warm-up steps
-    step()                                     # (first call apart: it builds the source-major plan on the host)
+    t_plan = time.perf_counter()
+    step()                                     # (first call apart: it builds the source-major plan; config.plan_build_ms = this call - a steady one)
     ctx.sync(0)
+    first_call_ms = (time.perf_counter() - t_plan) * 1e3
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         for _ in range(8):
@@ -470,12 +507,15 @@ def main():
         ctx.sync(0)
     for _ in range(args.warmup):
         step()
+    clocks = {"before": device_state(info["rank_devices"][rank if use_dist else 0])} if rank == 0 else None      # (the warm-up launches are still running)
     barrier()
     ctx.event_record(0, 0)
     t0 = time.perf_counter()
     for _ in range(n_launches):
         step()
     ctx.event_record(0, 1)
+    if clocks is not None:
+        clocks["during"] = device_state(info["rank_devices"][rank if use_dist else 0])      # (queued launches still running: sysfs reads, ~0.1 ms)
     ctx.sync(-1)
     local = time.perf_counter() - t0
     barrier()
@@ -560,6 +600,9 @@ def main():
                               f"launches dealt round-robin to {world} rank(s)",
                        "frames_rank0": n_mine, "per_rank_seconds": per_rank, "seconds_incl_closing_barrier": round(with_barrier, 6),
                        "settle_ms": args.settle_ms,
+                       # the first call of the geometry (plan built once per context and geometry, outside the timed region) minus one steady launch
+                       "plan_build_ms": round(max(0.0, first_call_ms - kernel_ms), 2),
+                       "clocks": clocks,
                        "parity_vs_oracle": parity},
             "roofline": None if not baseline_shape else {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -567,6 +610,9 @@ def main():
                          "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                          "kernel": EQ_KERNEL_NAMES.get(eq_kernel, str(eq_kernel)), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         # SURVEY 8(d)'s stricter figure (union of the views' texels, each once, + stores): what a kernel that shares reads across views is held to
+                         "union_bytes_per_launch": UNION_BYTES_PER_FRAME * nf,
+                         "frac_union": round(UNION_BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          # the reachable bound next to the algorithmic one: distinct 128-B lines per view + stores at the
                          # measured streaming rate; frac = launch time at that bound / measured launch time
                          "line_bound": {"bytes_per_launch": line_bytes * nf, "peak": HBM_STREAM_GBS, "unit": "GB/s",

@@ -90,15 +90,18 @@ def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LI
     got = ctx.download(d_out[k], (specs[k][5], specs[k][4], 3))
     want = orc.equirect_views_u8(frames[0], [orc.make_view(*specs[k])], threads=0, interp=2 if interp == 2 else 1,
                                  mask=masks[0] if masks else None)[0]
-    uv = sum(orc.equirect_distinct_texels(orc.make_view(*s), W, H) for s in specs)
+    union = np.zeros((H, W), np.uint8)          # SURVEY 8(d)'s stricter figure: every distinct texel of the frame ONCE for all views
+    uv = sum(orc.equirect_distinct_texels(orc.make_view(*s), W, H, union) for s in specs)
     out_px = sum(s[4] * s[5] for s in specs)
     algo = (out_px * 3 + uv * 3) * n_frames
+    algo_union = (out_px * 3 + int(union.sum()) * 3) * n_frames
     for b in d_fr + d_out + (d_masks or []):
         ctx.free(b)
     return {"config": name, "frames_per_launch": n_frames, "views": len(specs), "out_MPix_per_frame": round(out_px / 1e6, 2),
             "ms_per_launch": round(ms, 4), "us_per_frame": round(ms / n_frames * 1e3, 1),
             "MPix_per_s": round(out_px * n_frames / ms / 1e3, 0), "algorithmic_MB_per_frame": round(algo / n_frames / 1e6, 1),
             "achieved_GB_per_s": round(algo / ms / 1e6, 0), "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 3),
+            "union_MB_per_frame": round(algo_union / n_frames / 1e6, 1), "frac_union": round(algo_union / ms / 1e6 / 8000, 3),
             "eq_kernel": eq_kernel, "parity_vs_oracle": bool(np.array_equal(got, want))}
 
 
@@ -398,7 +401,8 @@ def secondary_rows(ctx, steps=20):
         # frames per launch as in the full rows of main(): 8 for the 5.7K / 6 x 800^2 shapes, 4 for the 8K large-view presets
         r = equirect_cfg(ctx, name, w, h, specs, 8 if key in ("cfg1", "cfg1-cubic", "cfg2-cubic") else 4, steps, interp=interp, with_mask=with_mask)
         out.append({"config": key, "workload": name, "unit": "frame", "us_per_unit": r["us_per_frame"], "frac": r["frac_of_8TBps"],
-                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "eq_kernel": r["eq_kernel"], "parity_vs_oracle": r["parity_vs_oracle"]})
+                    "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "frac_union": r["frac_union"], "union_MB_per_unit": r["union_MB_per_frame"],
+                    "eq_kernel": r["eq_kernel"], "parity_vs_oracle": r["parity_vs_oracle"]})
     for key, name, interp in (("cfg2-u16", "8K rgb48 (uint16) -> 6x800^2, linear", gs360.INTERP_LINEAR),
                               ("cfg2-u16-cubic", "8K rgb48 (uint16) -> 6x800^2, cubic", gs360.INTERP_CUBIC)):
         r = equirect_u16_cfg(ctx, name, 7680, 3840, ring_views(6, 800, HFOV_12MM), 4, steps, interp)
