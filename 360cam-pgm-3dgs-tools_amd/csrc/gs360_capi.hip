@@ -30,7 +30,6 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-constexpr size_t kSmPlanCap = 8;          // source-major plans a context keeps (a geometry may hold two: full- and half-height tiles)
 constexpr size_t kSmLdsPerGroup = 80 * 1024;   // two workgroups of the source-major kernel per CU (160 KiB of LDS)
 constexpr double kSmMinPixels = 3.5e6;           // automatic selection of the source-major kernel: output pixels of the call (smaller calls are launch-bound)
 constexpr int kSmFamilyMinFrames = 4;          // automatic selection of the source-major kernel for calls of several rings: frames per call ...
@@ -104,8 +103,7 @@ struct gs360_ctx {
     std::atomic<int> last_table_kernel{-1};   // read-only option "last_table_kernel": jobs of the last 8-bit table call that took the LDS-staged kernel (-1 none yet)
     std::atomic<int> last_table_slow{0};      // read-only option "last_table_stage_slow_tiles": tiles of those jobs' stage plans without a box (redone from memory)
     // source-major plans of this context (gs360_srcmajor.hip), most recent calls' geometries
-    std::mutex sm_mutex;
-    std::vector<gs360::SmPlan*> sm_plans;
+    gs360::SmCache sm;
 };
 
 namespace {
@@ -434,7 +432,7 @@ int gs360_ctx_destroy(gs360_ctx* c) {
     if (c->d_lanczos) (void)hipFree(c->d_lanczos);
     if (c->d_coef1d) (void)hipFree(c->d_coef1d);
     if (c->d_lz_cen) (void)hipFree(c->d_lz_cen);
-    for (gs360::SmPlan* p : c->sm_plans) gs360::sm_plan_free(p);
+    gs360::sm_cache_destroy(c->sm);
     delete c;
     return GS360_OK;
 }
@@ -465,6 +463,11 @@ int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
     }
     if (!std::strcmp(key, "last_table_stage_slow_tiles")) {
         *value = c->last_table_slow.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
+    if (!std::strcmp(key, "srcmajor_plan_builds") || !std::strcmp(key, "srcmajor_inline_frees") || !std::strcmp(key, "srcmajor_plans")) {
+        std::lock_guard<std::mutex> lock(c->sm.mu);
+        *value = !std::strcmp(key, "srcmajor_plan_builds") ? (int)c->sm.builds : (!std::strcmp(key, "srcmajor_inline_frees") ? (int)c->sm.inline_frees : (int)c->sm.plans.size());
         return GS360_OK;
     }
     if (!std::strcmp(key, "last_srcmajor_box_pct")) {
@@ -583,6 +586,7 @@ int gs360_sync(gs360_ctx* c, int slot) {
     HIP_TRY(hipSetDevice(c->device));
     if (slot < 0) {
         for (int s = 0; s < c->n_slots; ++s) HIP_TRY(hipStreamSynchronize(c->stream[s]));
+        gs360::sm_cache_drain(c->sm);             // every stream is idle: plans the cache evicted since the last time are released here
         return GS360_OK;
     }
     if (int rc = check_ctx_slot(c, slot)) return rc;
@@ -796,27 +800,38 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
             if (shape.n_rings == 1) ring = out_px >= kSmMinPixels && (shape.N >= 6 ? step >= 1.5 : shape.N == 5 && n_frames >= 2 && step >= 2.25);
             else ring = n_frames >= kSmFamilyMinFrames && n_views >= 8 && step >= 1.75;
         }
+        // the plan is decided ONCE per call (first chunk) and held until the last chunk is launched: a tail chunk of another size must not pick
+        // another plan -- or find its plan evicted -- after earlier chunks have rendered
+        gs360::SmPlan* plan = nullptr;
+        if (ring) {
+            hipError_t he = hipSuccess;
+            int seen_box_pct = 0;
+            const int rc = sm_prepare(Ls[0], shape, c->sm, mask_frames != nullptr, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed), c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed),
+                                      c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), c->opt[kOptSrcMajorAdapt].load(std::memory_order_relaxed) != 0,
+                                      opt_srcmajor < 0 ? kSmMaxBoxPct : 0, kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he, &plan, &seen_box_pct);
+            c->last_sm_box_pct.store(seen_box_pct, std::memory_order_relaxed);
+            if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major plan failed: %s", hipGetErrorString(he));
+            if (rc == 1) ring = false;                   // the geometry does not fit the plan format: the gather kernels (nothing launched yet)
+        }
         for (size_t i = 0; i < Ls.size() && ring; ++i) {
             hipError_t he = hipSuccess;
-            int rc, info[3] = {0, 0, 0};
+            int info[3] = {0, 0, 0};
             if (mask_frames) {                           // (packed per chunk of frames: the staging images are reused)
-                if (int prc = pack_masks((int)i * GS360_MAX_FRAMES, Ls[i].n_frames)) return prc;
+                if (int prc = pack_masks((int)i * GS360_MAX_FRAMES, Ls[i].n_frames)) { sm_release(c->sm, plan); return prc; }
                 for (int f = 0; f < Ls[i].n_frames; ++f) Ls[i].mask[f] = (const uint8_t*)c->stage[slot].d_maskbits + mask_bits_bytes * (size_t)f;
                 Ls[i].mask_stride = (int64_t)mask_pitch_dw * 4;
             }
-            {
-                std::lock_guard<std::mutex> lock(c->sm_mutex);
-                rc = sm_launch(Ls[i], shape, c->sm_plans, kSmPlanCap, c->opt[kOptSrcMajorBx].load(std::memory_order_relaxed),
-                               c->opt[kOptSrcMajorRows].load(std::memory_order_relaxed), c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), c->opt[kOptSrcMajorAdapt].load(std::memory_order_relaxed) != 0,
-                               opt_srcmajor < 0 ? kSmMaxBoxPct : 0, kSmLdsPerGroup, c->prop.multiProcessorCount, c->stream[slot], &he, info);
-                c->last_sm_box_pct.store(info[0], std::memory_order_relaxed);
-                c->last_sm_rows.store(info[1], std::memory_order_relaxed);
-                c->last_sm_images.store(info[2], std::memory_order_relaxed);
+            const int rc = sm_launch(Ls[i], shape, plan, c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), kSmLdsPerGroup, c->prop.multiProcessorCount,
+                                     c->stream[slot], &he, info);
+            c->last_sm_box_pct.store(info[0], std::memory_order_relaxed);
+            c->last_sm_rows.store(info[1], std::memory_order_relaxed);
+            c->last_sm_images.store(info[2], std::memory_order_relaxed);
+            if (rc < 0) {
+                sm_release(c->sm, plan);
+                return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));
             }
-            if (rc < 0) return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));
-            if (rc == 1 && i == 0) ring = false;         // the geometry does not fit the plan format (decided by the first chunk: nothing launched yet)
-            else if (rc == 1) return fail(GS360_ERR_HIP, "source-major plan vanished between frame chunks");
         }
+        sm_release(c->sm, plan);
         if (ring) {
             c->last_eq_kernel.store(2, std::memory_order_relaxed);
             return GS360_OK;

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/gs360.h"
@@ -211,9 +212,23 @@ struct SmShape {                         // how a call's views fall into yaw rin
     int partner[GS360_MAX_VIEWS];        // ring -> the ring at minus its pitch (itself for a level ring)
     int qmap[GS360_MAX_VIEWS];           // ring * N + position -> view index
 };
+// the context's source-major plans: most recent geometries (a geometry may hold two: full- and half-height tiles); plans that were
+// evicted wait in the graveyard for a moment at which the caller waits for the device anyway (hipFree synchronises it)
+struct SmCache {
+    std::mutex mu;
+    std::vector<SmPlan*> plans, graveyard;
+    size_t cap = 16;
+    uint64_t builds = 0;                 // plans built by this context (hits build nothing: tests count instead of timing)
+    uint64_t inline_frees = 0;           // plans released inside a call because nobody synchronised for 64 evictions
+};
+void sm_cache_drain(SmCache& cache);     // releases the graveyard (gs360_sync, gs360_ctx_destroy)
+void sm_cache_destroy(SmCache& cache);
 bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, SmShape* S);
-int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, bool adapt, int max_box_pct,
-              size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* info /* [3]: box overhead %, tile rows, images per workgroup */);
+int sm_prepare(const EqLaunch& L, const SmShape& S, SmCache& cache, bool masked, int Bx, int R, int G_opt, bool adapt, int max_box_pct, size_t lds_limit, int n_cu,
+               hipStream_t s, hipError_t* herr, SmPlan** out, int* box_pct);
+int sm_launch(const EqLaunch& L, const SmShape& S, const SmPlan* plan, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr,
+              int* info /* [3]: box overhead %, tile rows, images per workgroup */);
+void sm_release(SmCache& cache, SmPlan* plan);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64
 void build_coef1d(float* out);             // host: the float32 1-D phase tables (linear, cubic, lanczos4) of the CV_16U samplers, 448

@@ -35,6 +35,7 @@
 // 58-63 us against 75-79 (LDS-staged kernel), cfg1 32-36 against 41-48: copies, stores, LDS and vector ALU each 55-70 % busy.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -271,6 +272,7 @@ struct SmPlan {
     int rows = 0;                          // tile rows the builder ended with (R, or a half / quarter of it when R did not fit)
     int box_pct = 0;                       // bytes of all tile boxes in percent of the tile grid cells they stand for (halos, cut tiles)
     uint64_t stamp = 0;
+    int pins = 0;                          // calls that hold this plan between sm_prepare and sm_release (guarded by the cache's lock): never evicted
 };
 
 void sm_plan_free(SmPlan* p) {
@@ -299,10 +301,14 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool mask
     // A quad belongs to the plan when its first pixel looks at or above the equator (sy <= 16 H - 16): the upside-down images then render
     // exactly the others (sy' = 32 H - 32 - sy is the mirror ring's pixel (i, h - 1 - j)); quads ON the equator are rendered twice, same
     // bytes to the same place.  For a level ring that is the upper half of its rows.
-    int2* d_xy = nullptr;
+    struct DevBuf {                                      // (freed on every path out of this function, a std::bad_alloc from the vectors below included)
+        int2* p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } dxy;
     std::vector<int2> xy((size_t)h * w);
     std::vector<Quad> quads;
-    if ((*herr = hipMalloc((void**)&d_xy, xy.size() * sizeof(int2))) != hipSuccess) return -1;
+    if ((*herr = hipMalloc((void**)&dxy.p, xy.size() * sizeof(int2))) != hipSuccess) return -1;
+    int2* const d_xy = dxy.p;
     int ytop = 1 << 30, fit = 0;
     for (int c = 0; c < S.n_rings && fit == 0; ++c) {
         const bool level = L0.view[S.ref[c]].level != 0;
@@ -335,16 +341,32 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool mask
                 quads.push_back(Q);
             }
     }
-    (void)hipFree(d_xy);
     if (*herr != hipSuccess) return -1;
     if (fit || ytop < 0 || quads.empty()) return 1;      // (a view that reaches the pole row: the gather kernels' clamp path)
-    for (Quad& Q : quads) Q.tid = ((Q.iy[0] - ytop) / R) * ntx + Q.xr[0] / Bx;
-    std::sort(quads.begin(), quads.end(), [](const Quad& a, const Quad& b) {
-        if (a.tid != b.tid) return a.tid < b.tid;
-        if (a.vslot != b.vslot) return a.vslot < b.vslot;
-        if (a.j != b.j) return a.j < b.j;
-        return a.i0 < b.i0;
-    });
+    // Order (tile, view slot, row, column).  The quads were generated ring by ring in (row, column) order, so two STABLE counting sorts
+    // -- by view slot, then by tile -- give it in O(n): cfg3's 0.96 M quads took 0.1-0.2 s through std::sort (3-5x the kernel time of the
+    // whole 600-frame job), and that on the calling thread of the first call of a geometry.
+    int max_tid = 0;
+    for (Quad& Q : quads) {
+        Q.tid = ((Q.iy[0] - ytop) / R) * ntx + Q.xr[0] / Bx;
+        max_tid = std::max(max_tid, Q.tid);
+    }
+    std::vector<uint32_t> order(quads.size()), tmp(quads.size());
+    {
+        std::vector<uint32_t> cnt((size_t)std::max(max_tid + 2, S.n_rings * N + 2));
+        auto pass = [&](const std::vector<uint32_t>* in, std::vector<uint32_t>& out, const int n_keys, auto key) {
+            std::fill(cnt.begin(), cnt.begin() + n_keys + 1, 0u);
+            for (size_t i = 0; i < quads.size(); ++i) ++cnt[(size_t)key(quads[in ? (*in)[i] : i]) + 1];
+            for (int k = 0; k < n_keys; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+            for (size_t i = 0; i < quads.size(); ++i) {
+                const uint32_t q = in ? (*in)[i] : (uint32_t)i;
+                out[cnt[(size_t)key(quads[q])]++] = q;
+            }
+        };
+        pass(nullptr, tmp, S.n_rings * N, [](const Quad& Q) { return Q.vslot; });
+        pass(&tmp, order, max_tid + 1, [](const Quad& Q) { return Q.tid; });
+    }
+    auto qat = [&](const size_t i) -> const Quad& { return quads[order[i]]; };
     std::vector<SmTile> tiles;
     std::vector<uint32_t> ent;
     std::vector<const Quad*> list;
@@ -352,15 +374,15 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool mask
     long long box_sum = 0;
     for (size_t a = 0; a < quads.size();) {
         size_t b = a;
-        while (b < quads.size() && quads[b].tid == quads[a].tid) ++b;
+        while (b < quads.size() && qat(b).tid == qat(a).tid) ++b;
         // entries in (view, row, column) order, every VIEW GROUP padded to whole wavefront turns (16 quads = 64 pixels) with copies of its
         // last quad -- same values to the same addresses -- so that a turn never mixes views (the consumers keep the destination base in
         // scalar registers)
         list.clear();
         for (size_t q = a; q < b; ++q) {
-            list.push_back(&quads[q]);
-            if (q + 1 == b || quads[q + 1].vslot != quads[q].vslot)
-                while (list.size() % 16) list.push_back(&quads[q]);
+            list.push_back(&qat(q));
+            if (q + 1 == b || qat(q + 1).vslot != qat(q).vslot)
+                while (list.size() % 16) list.push_back(&qat(q));
         }
         ++n_boxes;
         // a tile many views look at closely (weak minification, or a pitched ring's rows near the pole) is cut into plan tiles of at most
@@ -504,46 +526,71 @@ bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, S
 
 namespace {
 
-// The plan of (launch geometry, tile shape) from the context's cache (`cache`: at most `cap`, least recently used evicted), built on a miss.
-// Returns nullptr with *herr == hipSuccess for a geometry that does not fit (remembered as an empty plan, or every call would plan again:
-// tens of ms), nullptr with *herr set on a HIP error.
-SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, bool masked, size_t lds_limit,
+bool sm_key_matches(const SmPlan* p, const EqLaunch& L, const SmShape& S, int Bx, int R, bool masked, const uint32_t (*key)[4]) {
+    const EqView& V = L.view[0];
+    return p->W == L.W && p->H == L.H && p->N == S.N && p->n_rings == S.n_rings && p->w == V.out_w && p->h == V.out_h && p->Bx == Bx && p->R == R &&
+           p->masked == masked && p->sxu == fbits(V.sxu) && p->syv == fbits(V.syv) && std::memcmp(p->ring_key, key, sizeof(key[0]) * S.n_rings) == 0;
+}
+
+// The plan of (launch geometry, tile shape) from the context's cache, built on a miss.  Called with `lk` held; the lock is RELEASED while a
+// plan is built (a coordinate kernel per ring, a device -> host copy, the host-side ordering: 6 ms for cfg2, tens of ms for cfg3 -- other
+// slots' calls must not queue behind that) and two threads that miss on the same geometry at once both build, the second result is
+// dropped.  Evicted and dropped plans go to the cache's graveyard: hipFree synchronises the device, so they are released where the caller
+// waits for the device anyway (gs360_sync, context destruction).  Returns nullptr with *herr == hipSuccess for a geometry that does not
+// fit (remembered as an empty plan, or every call would plan again), nullptr with *herr set on a HIP error.
+SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, SmCache& cache, std::unique_lock<std::mutex>& lk, int Bx, int R, bool masked, size_t lds_limit,
                     hipStream_t s, hipError_t* herr) {
     const EqView& V = L.view[0];
     const int N = S.N;
     uint32_t key[GS360_MAX_VIEWS][4];
     sm_ring_key(L, S, key);
-    SmPlan* plan = nullptr;
-    for (SmPlan* p : cache)
-        if (p->W == L.W && p->H == L.H && p->N == N && p->n_rings == S.n_rings && p->w == V.out_w && p->h == V.out_h && p->Bx == Bx && p->R == R &&
-            p->masked == masked && p->sxu == fbits(V.sxu) && p->syv == fbits(V.syv) && std::memcmp(p->ring_key, key, sizeof(key[0]) * S.n_rings) == 0) { plan = p; break; }
+    auto find = [&]() -> SmPlan* {
+        for (SmPlan* p : cache.plans)
+            if (sm_key_matches(p, L, S, Bx, R, masked, key)) return p;
+        return nullptr;
+    };
+    SmPlan* plan = find();
     if (!plan) {
+        lk.unlock();
         int rr = R, rc = 1, built = R;
-        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt, rr = std::max(8, rr / 2)) {
+        SmPlan* fresh = nullptr;
+        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt) {
             built = rr;
-            rc = sm_build_plan(L, S, Bx, rr, masked, attempt == 2 || rr == 8, lds_limit, s, &plan, herr);
+            rc = sm_build_plan(L, S, Bx, rr, masked, attempt == 2 || rr == 8, lds_limit, s, &fresh, herr);
+            const int next = std::max(8, rr / 2);
+            if (next == rr) break;                       // (tiles of 8 rows did not fit either: nothing smaller to try)
+            rr = next;
         }
+        if (rc == 1) fresh = new (std::nothrow) SmPlan();
+        lk.lock();
+        ++cache.builds;
         if (rc < 0) return nullptr;
-        if (rc == 1) {
-            plan = new (std::nothrow) SmPlan();
-            if (!plan) { *herr = hipErrorOutOfMemory; return nullptr; }
+        if (!fresh) { *herr = hipErrorOutOfMemory; return nullptr; }
+        fresh->W = L.W; fresh->H = L.H; fresh->N = N; fresh->n_rings = S.n_rings; fresh->w = V.out_w; fresh->h = V.out_h; fresh->Bx = Bx; fresh->R = R;
+        fresh->rows = built; fresh->masked = masked;
+        fresh->sxu = fbits(V.sxu); fresh->syv = fbits(V.syv);
+        std::memset(fresh->ring_key, 0, sizeof(fresh->ring_key));
+        std::memcpy(fresh->ring_key, key, sizeof(key[0]) * S.n_rings);
+        plan = find();
+        if (plan) {
+            cache.graveyard.push_back(fresh);            // another thread built the same geometry meanwhile: theirs is in use, ours goes
+        } else {
+            plan = fresh;
+            if (cache.plans.size() >= cache.cap) {       // evict the least recently used plan no call holds (all held: the cache grows for now)
+                size_t lru = cache.plans.size();
+                for (size_t i = 0; i < cache.plans.size(); ++i)
+                    if (cache.plans[i]->pins == 0 && (lru == cache.plans.size() || cache.plans[i]->stamp < cache.plans[lru]->stamp)) lru = i;
+                if (lru < cache.plans.size()) {
+                    cache.graveyard.push_back(cache.plans[lru]);
+                    cache.plans.erase(cache.plans.begin() + (long)lru);
+                }
+            }
+            cache.plans.push_back(plan);
         }
-        plan->W = L.W; plan->H = L.H; plan->N = N; plan->n_rings = S.n_rings; plan->w = V.out_w; plan->h = V.out_h; plan->Bx = Bx; plan->R = R;
-        plan->rows = built; plan->masked = masked;
-        plan->sxu = fbits(V.sxu); plan->syv = fbits(V.syv);
-        std::memset(plan->ring_key, 0, sizeof(plan->ring_key));
-        std::memcpy(plan->ring_key, key, sizeof(key[0]) * S.n_rings);
-        if (cache.size() >= cap) {                       // evict the least recently used plan (its last launch is ordered before this free by hipFree's sync)
-            size_t lru = 0;
-            for (size_t i = 1; i < cache.size(); ++i) if (cache[i]->stamp < cache[lru]->stamp) lru = i;
-            sm_plan_free(cache[lru]);
-            cache.erase(cache.begin() + (long)lru);
-        }
-        cache.push_back(plan);
     }
     uint64_t newest = 0;
-    for (SmPlan* p : cache) newest = std::max(newest, p->stamp);
-    plan->stamp = newest + 1;      // (the caller holds the context's plan lock)
+    for (SmPlan* p : cache.plans) newest = std::max(newest, p->stamp);
+    plan->stamp = newest + 1;
     return plan->n_tiles ? plan : nullptr;
 }
 
@@ -569,35 +616,82 @@ SmPick sm_pick_images(const SmPlan& plan, int N, int n_frames, int n_cu) {
 
 }  // namespace
 
-// Renders the launch through the source-major kernel.  `cache` holds the context's plans.
-// Returns 0 (launched), 1 (geometry does not fit: caller takes the gather kernels) or -1 with *herr set.
-int sm_launch(const EqLaunch& L, const SmShape& S, std::vector<SmPlan*>& cache, size_t cap, int Bx, int R, int G_opt, bool adapt, int max_box_pct,
-              size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* info) {
-    int* const box_pct = info;                           // info[0..2]: the plan's box overhead in percent, its tile rows, images per workgroup
-    const EqView& V = L.view[0];
-    const int N = S.N, NV = L.n_views;
+void sm_cache_drain(SmCache& cache) {
+    std::vector<SmPlan*> dead;
+    {
+        std::lock_guard<std::mutex> lock(cache.mu);
+        dead.swap(cache.graveyard);
+    }
+    for (SmPlan* p : dead) sm_plan_free(p);
+}
+
+void sm_cache_destroy(SmCache& cache) {
+    sm_cache_drain(cache);
+    std::lock_guard<std::mutex> lock(cache.mu);
+    for (SmPlan* p : cache.plans) sm_plan_free(p);
+    cache.plans.clear();
+}
+
+// The plan a CALL renders with -- decided ONCE, before its first chunk of frames, and held (never evicted) until sm_release: a call of more
+// than GS360_MAX_FRAMES frames must not change plan -- or lose it -- between chunks after earlier chunks were launched.  `L` = the first
+// chunk.  Returns 0 with *out set, 1 (the geometry does not fit, or its boxes outgrow their grid cells: the caller takes the gather
+// kernels) or -1 with *herr set.
+int sm_prepare(const EqLaunch& L, const SmShape& S, SmCache& cache, bool masked, int Bx, int R, int G_opt, bool adapt, int max_box_pct, size_t lds_limit, int n_cu,
+               hipStream_t s, hipError_t* herr, SmPlan** out, int* box_pct) {
     *herr = hipSuccess;
-    const bool masked = L.mask[0] != nullptr;
-    SmPlan* plan = sm_get_plan(L, S, cache, cap, Bx, R, masked, lds_limit, s, herr);
+    *out = nullptr;
+    std::unique_lock<std::mutex> lk(cache.mu);
+    if (cache.graveyard.size() > 64) {                   // nobody called gs360_sync for a long time: release here (hipFree waits for the device)
+        std::vector<SmPlan*> dead;
+        dead.swap(cache.graveyard);
+        cache.inline_frees += dead.size();
+        lk.unlock();
+        for (SmPlan* p : dead) sm_plan_free(p);
+        lk.lock();
+    }
+    SmPlan* plan = sm_get_plan(L, S, cache, lk, Bx, R, masked, lds_limit, s, herr);
     if (!plan) return *herr == hipSuccess ? 1 : -1;
-    SmPick pick = sm_pick_images(*plan, N, L.n_frames, n_cu);
+    *box_pct = plan->box_pct;
+    if (max_box_pct > 0 && plan->box_pct > max_box_pct) return 1;     // (automatic selection only) boxes far larger than their grid cells: views stretched towards a pole
     // A job that cannot fill the GPU once even with the longest workgroups (cfg2: 188 tiles x 12 images / 12 = 188 workgroups per frame for
     // 512 places) runs faster on tiles of half the height -- twice the workgroups, each half as long, and the smaller LDS footprint lets
     // three of them share a CU: cfg2 19.2 -> 16.0 us for one frame per call, 16.1 -> 13.3 for two; from three frames on the tall tiles
     // win again (16.1 against 16.5, four: 15.0 against 17.2: the boxes' halo bytes), and 16-row tiles are never halved (8K -> 6 x 1200^2,
     // 8 x 1600^2, 12 x 800^2 at one frame: +8 .. +22 %).  profiles/r05/srcmajor_small_jobs.txt
     if (adapt && G_opt == 0 && plan->rows >= 32) {
+        const SmPick pick = sm_pick_images(*plan, S.N, L.n_frames, n_cu);
         int gmax = 1;
-        for (int g = 1; g <= kSmMaxImages; ++g) if ((2 * N) % g == 0) gmax = g;
-        const long long coarsest = (long long)plan->n_tiles * 2 * N * L.n_frames / gmax;
+        for (int g = 1; g <= kSmMaxImages; ++g) if ((2 * S.N) % g == 0) gmax = g;
+        const long long coarsest = (long long)plan->n_tiles * 2 * S.N * L.n_frames / gmax;
         if (coarsest * 10 < pick.resident * 9) {
-            SmPlan* half = sm_get_plan(L, S, cache, cap, Bx, plan->rows / 2, masked, lds_limit, s, herr);
+            ++plan->pins;                                // (the lock is released while the half-height plan is built)
+            SmPlan* half = sm_get_plan(L, S, cache, lk, Bx, plan->rows / 2, masked, lds_limit, s, herr);
+            --plan->pins;
             if (!half && *herr != hipSuccess) return -1;
-            if (half) { plan = half; pick = sm_pick_images(*half, N, L.n_frames, n_cu); }
+            // (halo rows weigh more in the half-height boxes: one that outgrows the limit leaves the call on the full-height plan)
+            if (half && !(max_box_pct > 0 && half->box_pct > max_box_pct)) plan = half;
         }
     }
+    ++plan->pins;
+    *out = plan;
+    return 0;
+}
+
+void sm_release(SmCache& cache, SmPlan* plan) {
+    if (!plan) return;
+    std::lock_guard<std::mutex> lock(cache.mu);
+    --plan->pins;
+}
+
+// Renders one chunk of frames through the source-major kernel with the call's plan.  Returns 0 or -1 with *herr set.
+int sm_launch(const EqLaunch& L, const SmShape& S, const SmPlan* plan, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* info) {
+    int* const box_pct = info;                           // info[0..2]: the plan's box overhead in percent, its tile rows, images per workgroup
+    const EqView& V = L.view[0];
+    const int N = S.N, NV = L.n_views;
+    *herr = hipSuccess;
+    const bool masked = L.mask[0] != nullptr;
+    const SmPick pick = sm_pick_images(*plan, N, L.n_frames, n_cu);
     box_pct[0] = plan->box_pct; box_pct[1] = plan->rows; box_pct[2] = pick.G;
-    if (max_box_pct > 0 && plan->box_pct > max_box_pct) return 1;     // (automatic selection only) boxes far larger than their grid cells: views stretched towards a pole
     SmArgs P;
     std::memset(&P, 0, sizeof(P));
     for (int f = 0; f < L.n_frames; ++f) P.src[f] = L.src[f];

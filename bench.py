@@ -300,8 +300,16 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
     for b0 in range(0, len(d_frames), batch):
         fr = d_frames[b0:b0 + batch]
         calls.append(ctx.make_equirect_call(fr, W, H, C, views, d_out[:len(fr) * len(views)], slot=0))
-    for c in calls[:2]:
-        c()
+    first_call_ms = steady_call_ms = 0.0
+    if calls:                                             # the first call builds the geometry's plan (once per context), the second is a steady one
+        t_first = time.perf_counter()
+        calls[0]()
+        ctx.sync(0)
+        first_call_ms = (time.perf_counter() - t_first) * 1e3
+        t_first = time.perf_counter()
+        calls[0]()
+        ctx.sync(0)
+        steady_call_ms = (time.perf_counter() - t_first) * 1e3
     barrier()
     ctx.event_record(0, 0)
     t0 = time.perf_counter()
@@ -344,6 +352,8 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
                        "frames_per_s": round(args.job_frames / elapsed, 1), "per_rank_seconds": per_rank,
                        "seconds_incl_closing_barrier": round(with_barrier, 6),
                        "rank0_kernel_us_per_frame": round(kernel_ms * 1e3 / max(1, len(mine)), 2),
+                       # outside the timed region: the plan of the geometry is built by the first call of a context, every later call reuses it
+                       "plan_build_ms": round(max(0.0, first_call_ms - steady_call_ms), 2),
                        "rank0_eq_kernel": EQ_KERNEL_NAMES.get(ctx.get_option("last_eq_kernel"), "?")},
             "roofline": None, "cpu_baseline": None,
         })

@@ -94,7 +94,7 @@ int gs360_device_pci_bus_id(gs360_ctx *ctx, char *buf, size_t buf_len);
 /* Context options: kernel-selection switches for tests, probes and A/B runs (the defaults are the measured optima; results never depend
  * on them).  The reference has no counterpart (it shells out to ffmpeg / calls cv2.remap: PC:310-314, DF:2001); a binding needs them
  * only to pin a kernel variant.  gs360_ctx_create seeds the documented user switches ONCE from the environment (GS360_STAGE,
- * GS360_LANEMAP, GS360_SRCMAJOR, GS360_COLOR_CUBE); after that the library never reads the environment -- set options here instead.
+ * GS360_LANEMAP, GS360_SRCMAJOR, GS360_COLOR_CUBE, GS360_TABLE_STAGE); after that the library never reads the environment -- set options here instead.
  *   "lanemap"        -1 auto | 0 rows | 1 blocked       gather kernels' lane map
  *   "stage"          -1 auto | 0 never | 1 always       LDS-staged equirect kernel
  *   "srcmajor"       -1 auto | 0 never | 1 always       source-major equirect kernel (yaw rings of one size, level or in +/- pitch pairs:
@@ -107,9 +107,17 @@ int gs360_device_pci_bus_id(gs360_ctx *ctx, char *buf, size_t buf_len);
  *   "eq_persist", "table_persist"                       grid caps of the persistent kernels (table_persist: -1 auto)
  *   "lanczos_table", "table_rows"                       0 | 1: A/B references of the Lanczos-4 weight rebuild and the flat spans
  *   "color_cube"     -1 / 1 tabulate | 0 per pixel      8-bit colour stage (read by gs360_color_plan_create)
+ *   "table_stage"    -1 auto | 0 never | 1 always       LDS-staged table kernel (bilinear RGB through map plans; auto: plans whose tiles have boxes);
+ *                                                       "table_stage_rows" (8 | 16 | 32: rows of its 64-pixel tiles), "table_stage_wgs" (0 auto | 1..4
+ *                                                       workgroups per CU)
  * Read-only (get): "last_eq_kernel" -- which kernel the last equirect call launched: 0 gather, 1 LDS-staged, 2 source-major, -1 none yet;
  * "last_srcmajor_box_pct" -- tile-box bytes of the last source-major plan in percent of the grid cells they stand for;
- * "last_srcmajor_rows", "last_srcmajor_images" -- tile rows and images per workgroup of the last source-major launch.
+ * "last_srcmajor_rows", "last_srcmajor_images" -- tile rows and images per workgroup of the last source-major launch;
+ * "srcmajor_plan_builds" -- source-major plans this context has built so far (a call on a cached geometry builds none), "srcmajor_plans" -- plans
+ * it holds, "srcmajor_inline_frees" -- evicted plans it had to release inside a call (normally they wait for gs360_sync(ctx, -1) /
+ * gs360_ctx_destroy: hipFree synchronises the device);
+ * "last_table_kernel" -- jobs of the last 8-bit table call that took the LDS-staged kernel, "last_table_stage_slow_tiles" -- tiles of their
+ * stage plans whose box exceeded the LDS budget.
  * Unknown keys and out-of-range values are GS360_ERR_ARG.  Thread-safe; a change applies to calls that start after it. */
 int gs360_ctx_set_option(gs360_ctx *ctx, const char *key, int value);
 int gs360_ctx_get_option(gs360_ctx *ctx, const char *key, int *value);

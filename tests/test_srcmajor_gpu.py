@@ -123,12 +123,12 @@ def test_geometry_that_does_not_fit_is_remembered(ctx, orc):
         d_out = [ctx.alloc(512 * 512 * 3) for _ in specs]
         ctx.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
         ctx.sync(0)
-        t0 = time.perf_counter()
+        builds = ctx.get_option("srcmajor_plan_builds")
         for _ in range(5):
             ctx.equirect_views_dev([d_src], 2048, 1024, 3, views, d_out)
         ctx.sync(0)
-        per_call = (time.perf_counter() - t0) / 5
-        assert ctx.get_option("last_eq_kernel") == 0 and per_call < 0.01, per_call
+        # (a counter, not a clock: the refused geometry is remembered as an empty plan, later calls plan nothing)
+        assert ctx.get_option("last_eq_kernel") == 0 and ctx.get_option("srcmajor_plan_builds") == builds
     for b in [d_src] + d_out:
         ctx.free(b)
 
@@ -206,6 +206,76 @@ def test_more_frames_than_one_launch_holds(forced, orc, shape):
             assert np.array_equal(forced.download(d_out[f * NV + k], (64, 64, 3)), want[k]), (f, k)
     for b in d_src + d_out:
         forced.free(b)
+
+
+def test_seventeen_frames_in_auto_mode_keep_one_plan(ctx, orc):
+    """a call of 16 + 1 frames with the library's own choices (option srcmajor = -1): the plan is decided once, before the first chunk, and
+    held to the last -- the one-frame tail chunk must not pick the half-height plan (whose boxes may exceed the automatic limit) after the
+    first sixteen frames have been rendered; every frame of the call against the oracle"""
+    W, H = 3840, 1920
+    specs = _family(PRESET_FULL360, HFOV_14MM, 400)       # 4K -> full360coverage at 400^2: 2.0 texels per pixel, a ring family
+    NV, nf = len(specs), 17
+    base = rand_image(H, W, seed=530)
+    frames = [np.ascontiguousarray(np.roll(base, 131 * f, axis=1)) for f in range(nf)]
+    d_src = [ctx.to_device(f) for f in frames]
+    d_out = [ctx.alloc(400 * 400 * 3) for _ in range(nf * NV)]
+    with ctx.options(srcmajor=-1):
+        ctx.equirect_views_dev(d_src, W, H, 3, [gs360.View.make(*s) for s in specs], d_out)
+        ctx.sync(0)
+        assert ctx.get_option("last_eq_kernel") == 2
+    for f in (0, 7, 15, 16):
+        want = orc.equirect_views_u8(frames[f], [orc.make_view(*s) for s in specs], threads=0)
+        for k in range(NV):
+            assert np.array_equal(ctx.download(d_out[f * NV + k], (400, 400, 3)), want[k]), (f, k)
+    for b in d_src + d_out:
+        ctx.free(b)
+
+
+def test_rotating_twelve_geometries_from_four_threads(orc):
+    """the GUI case: the geometry changes from call to call (a preview slider), from several host threads on their own stream slots, more
+    geometries than the cache keeps: evicted plans wait in the graveyard for gs360_sync(ctx, -1) instead of a hipFree (a device-wide
+    synchronisation) inside the call -- counted by the read-only option srcmajor_inline_frees -- and every result stays bit-exact"""
+    import threading
+    ctx4 = gs360.Context(0, n_slots=4)
+    src = rand_image(480, 960, seed=540)
+    d_src = ctx4.to_device(src)
+    geoms = [[(i * 60.0 + 2.5 * t, 0.0, 80.0 + 3 * t, 85.0, 64 + 8 * (t % 5), 72) for i in range(6)] for t in range(24)]
+    wants = [orc.equirect_views_u8(src, [orc.make_view(*s) for s in g], threads=0) for g in geoms]
+    errors = []
+    barrier = threading.Barrier(4)
+
+    def work(t):
+        try:
+            for rnd in range(3):
+                for gi in range(t, len(geoms), 4):
+                    g = geoms[gi]
+                    d_out = [ctx4.alloc(s[4] * s[5] * 3) for s in g]
+                    ctx4.equirect_views_dev([d_src], 960, 480, 3, [gs360.View.make(*s) for s in g], d_out, slot=t)
+                    ctx4.sync(t)
+                    for k, s in enumerate(g):
+                        if not np.array_equal(ctx4.download(d_out[k], (s[5], s[4], 3), slot=t), wants[gi][k]):
+                            errors.append((t, gi, k))
+                    for b in d_out:
+                        ctx4.free(b)
+                barrier.wait()
+                if t == 0:
+                    ctx4.sync(-1)                          # every stream idle: the graveyard is released here
+                barrier.wait()
+        except Exception as e:      # noqa: BLE001
+            errors.append((t, repr(e)))
+            barrier.abort()
+    with ctx4.options(srcmajor=1):
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        builds, inline, held = ctx4.get_option("srcmajor_plan_builds"), ctx4.get_option("srcmajor_inline_frees"), ctx4.get_option("srcmajor_plans")
+    ctx4.close()
+    assert not errors, errors
+    assert inline == 0, inline                             # no plan was released inside a call
+    assert held <= 16 + 4                                  # the cache's size (+ plans held by calls in flight when it was full)
+    assert 24 <= builds <= 3 * 2 * 24, builds              # (each geometry may hold two plans: full- and half-height tiles)
 
 
 def test_concurrent_callers_share_the_plan_cache(orc):
