@@ -215,8 +215,9 @@ def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
     specs = [(float(y), float(p), hf, hf, size, size) for y, p in layout]
     views = [gs360.View.make(*v) for v in specs]
     mine = frames_for_rank(args.stream_frames, world, rank)
-    n_slots = 3
-    pipe = FramePipeline(ctx, W, H, C, views, n_slots=n_slots, copy_out=False)   # results alias pinned memory
+    n_slots = 6
+    # (four frames per launch: the ring family takes the source-major kernel, as in the resident job; the copies are per frame as before)
+    pipe = FramePipeline(ctx, W, H, C, views, n_slots=n_slots, copy_out=False, batch=4)   # results alias pinned memory
     # every slot's pinned input holds its own synthetic frame; a decoder would write the next frame in place
     # (FramePipeline.acquire()/commit(), what gs360/video.py's reader does), so no host-side copy sits in the timed loop
     for k in range(n_slots):

@@ -509,6 +509,34 @@ def test_frame_pipeline_pinned_streams(ctx, orc):
         _assert_same(got[k], want, f"pipeline frame {k}")
 
 
+def test_frame_pipeline_batches_the_kernel_for_ring_families(ctx, orc):
+    """batch = 4: frames are uploaded as they arrive, four of them are rendered by one launch -- the `full360coverage` ring family then
+    takes the source-major kernel -- and their views come back per frame; 11 frames through 6 slots (a last batch of three)"""
+    from gs360.stream import FramePipeline
+    from util import PRESET_FULL360, HFOV_14MM
+    H, W = 512, 1024
+    specs = [(float(y), float(p), HFOV_14MM, HFOV_14MM, 128, 128) for y, p in PRESET_FULL360]
+    views = [gs360.View.make(*s) for s in specs]
+    with ctx.options(srcmajor=-1):
+        pipe = FramePipeline(ctx, W, H, 3, views, n_slots=6, batch=4)
+        frames = [rand_image(H, W, seed=320 + k) for k in range(11)]
+        got, kernels = {}, set()
+        for k, f in enumerate(frames):
+            done = pipe.submit(f, tag=k)
+            if k % 4 == 3:
+                kernels.add(ctx.get_option("last_eq_kernel"))
+            if done:
+                got[done[0]] = done[1]
+        for tag, outs in pipe.drain():
+            got[tag] = outs
+        pipe.close()
+    assert kernels == {2}                                  # every four-frame launch ran eq_srcmajor_kernel
+    assert sorted(got) == list(range(11))
+    for k, f in enumerate(frames):
+        want = orc.equirect_views_u8(f, [orc.make_view(*s) for s in specs], threads=0)
+        _assert_same(got[k], want, f"batched pipeline frame {k}")
+
+
 # ---- full BASELINE sizes: bit-exact where the oracle is fast enough, size-independent properties otherwise -------
 def test_full_size_cfg3_full360coverage_checks(ctx, orc):
     """BASELINE cfg3 frame: 7680x3840 -> 12 x 1600^2 (full360coverage).  Every byte of all 12 views against the oracle."""
