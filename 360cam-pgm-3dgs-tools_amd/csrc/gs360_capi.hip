@@ -146,9 +146,6 @@ void make_eq_view(const gs360_view& v, int W, bool fisheye_out, int lanemap, EqV
     o->out_h = v.height;
     // The kernel computes the left half of every row and mirrors it; level views also mirror top/bottom.
     o->level = (o->sp == 0.0f && o->cp == 1.0f) ? 1 : 0;
-#ifdef GS360_FORCE_GENERAL   // probe builds: every view takes the general (non-level) path
-    o->level = 0;
-#endif
     // Lane map (gs360_kernels.hip): source pixels stepped per output pixel at the view centre.  Above ~3 the view
     // bends across so many source rows per 64-pixel output row that compact 4x16 gather patches touch fewer cache
     // lines (cfg2: 4.6 -> blocked, -3 %); below it full rows coalesce better and need less arithmetic (cfg1 1.7,

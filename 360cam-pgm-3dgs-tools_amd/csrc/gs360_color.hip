@@ -170,11 +170,9 @@ __global__ __launch_bounds__(kColorThreads) void color_lut_bytes_kernel(ColorArg
 // Rows that start on a dword boundary: one thread per 4 pixels = C dwords in, C dwords out, so a wavefront moves
 // 768 (C=3) or 1024 (C=4) contiguous bytes per row segment.  Blocks are persistent (the LDS tables are loaded once
 // per block) and walk 1024-pixel row segments in row-major order.
-#ifndef GS360_COLOR_WAVES
-#define GS360_COLOR_WAVES 5
-#endif
+constexpr int kColorWaves = 5;
 template <int C, int FIX>
-__global__ __launch_bounds__(kColorThreads) __attribute__((amdgpu_waves_per_eu(GS360_COLOR_WAVES, GS360_COLOR_WAVES))) void color_lut_quad_kernel(ColorArgs A) {
+__global__ __launch_bounds__(kColorThreads) __attribute__((amdgpu_waves_per_eu(kColorWaves, kColorWaves))) void color_lut_quad_kernel(ColorArgs A) {
     __shared__ Lds S;
     load_tables(A, S);
     const int iR = A.red, iB = 2 - A.red;

@@ -15,14 +15,8 @@ namespace gs360 {
 // Output tile of one 256-thread workgroup: 64 px wide (one wavefront = 64 consecutive pixels of a row),
 // 16 rows tall (4 wavefronts x 4 rows each).
 constexpr int kTileW = 64;
-#ifndef GS360_ROWS_PER_WAVE
-#define GS360_ROWS_PER_WAVE 4
-#endif
-#ifndef GS360_WAVES
-#define GS360_WAVES 4
-#endif
-constexpr int kRowsPerWave = GS360_ROWS_PER_WAVE;
-constexpr int kWaves = GS360_WAVES;              // wavefronts per workgroup
+constexpr int kRowsPerWave = 4;
+constexpr int kWaves = 4;                        // wavefronts per workgroup
 constexpr int kTileH = kWaves * kRowsPerWave;
 constexpr int kHalfRows = kRowsPerWave / 2;   // level views: half of a wavefront's rows are horizon mirrors
 

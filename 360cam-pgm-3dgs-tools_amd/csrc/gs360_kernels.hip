@@ -29,33 +29,15 @@
 
 namespace gs360 {
 
-#ifndef GS360_EQ_WAVES
-#define GS360_EQ_WAVES 5     // wavefronts per SIMD of the bilinear equirect kernel (measured optimum, see the kernel comment)
-#endif
-#ifndef GS360_EQ_ROWS_KERNEL
-#define GS360_EQ_ROWS_KERNEL 1
-#endif
-#ifndef GS360_EQR_WAVES
-#define GS360_EQR_WAVES 5    // bilinear RGB kernel of launches without blocked views (pipelined member loop only)
-#endif
-#ifndef GS360_EQS_WAVES
-#define GS360_EQS_WAVES 4    // LDS-staged bilinear RGB kernel: 40 KiB of LDS per workgroup = four workgroups per CU
-#endif
-#ifndef GS360_STAGE_ENABLE
-#define GS360_STAGE_ENABLE 1 // 0: every pass of eq_staged_kernel takes the gather form (A/B of the lane map alone)
-#endif
-#ifndef GS360_EQC_WAVES
-#define GS360_EQC_WAVES 4    // wavefronts per SIMD of the cubic equirect kernel (124 registers; 40 KiB of LDS = four workgroups per CU)
-#endif
-#ifndef GS360_RING_PARK
-#define GS360_RING_PARK 0    // bilinear kernel: ring-shared coordinates that wait in LDS between members (0 none, 1 latitude, 3 all)
-#endif
-#ifndef GS360_RING_PARK_CUBIC
-#define GS360_RING_PARK_CUBIC 1
-#endif
-#ifndef GS360_EQ_LEAN
-#define GS360_EQ_LEAN 1      // bilinear RGB row-per-slot views: the lean, software-pipelined member loop (0: the round-3 loop, A/B reference)
-#endif
+constexpr int kEqWaves = 5;     // wavefronts per SIMD of the bilinear equirect kernel (measured optimum, see the kernel comment)
+constexpr int kEqRowsKernel = 1;
+constexpr int kEqRowsWaves = 5;    // bilinear RGB kernel of launches without blocked views (pipelined member loop only)
+constexpr int kEqStagedWaves = 4;    // LDS-staged bilinear RGB kernel: 40 KiB of LDS per workgroup = four workgroups per CU
+constexpr int kStageEnable = 1; // 0: every pass of eq_staged_kernel takes the gather form (A/B of the lane map alone)
+constexpr int kEqCubicWaves = 4;    // wavefronts per SIMD of the cubic equirect kernel (124 registers; 40 KiB of LDS = four workgroups per CU)
+constexpr int kRingPark = 0;    // bilinear kernel: ring-shared coordinates that wait in LDS between members (0 none, 1 latitude, 3 all)
+constexpr int kRingParkCubic = 1;
+constexpr int kEqLean = 1;      // bilinear RGB row-per-slot views: the lean, software-pipelined member loop (0: the round-3 loop, A/B reference)
 
 
 // Store for the blocked lane map (RGB).  A wavefront holds a patch of 4 rows x (16 NS) columns in NS slots -- lane l of
@@ -590,7 +572,7 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
 // changes sign before the final fma/rint.  Level views (pitch 0) are also symmetric about the horizon:
 // yv(h-1-j) = -yv(j) exactly, latitude flips sign (rint is odd) -> one atan2 serves four pixels, and the
 // longitude term depends on the column only.  All of this is bit-identical to evaluating EQ-SPEC v1 per pixel.
-// Occupancy is pinned (GS360_EQ_WAVES wavefronts per SIMD): with more resident wavefronts their gathers evict each
+// Occupancy is pinned (kEqWaves wavefronts per SIMD): with more resident wavefronts their gathers evict each
 // other's lines from the 32 KiB vector L1, with fewer the miss queue runs dry.  Measured on cfg2, us per frame --
 // row-per-slot lane map: 3 / 4 / 6 wavefronts: 27.4 / 23.1 / 24.3; blocked lane map: 3 / 4 / 5 / 6: 22.1 / 20.8 / 20.3 /
 // 23.3 (6 spills).  5 is also the better choice for the arithmetic-bound large-view configs (cfg1/3/5; re-measured on the
@@ -602,13 +584,13 @@ __device__ __forceinline__ void eq_pass16(const EqSrc& L, const uint8_t* __restr
 template <int C, bool CUBIC, int ES, bool ROWS = false, bool MASKED = false>     // ROWS: instantiation for launches without blocked views
 struct EqLds {
     static constexpr bool kBlocked = !ROWS && (C == 3) && (ES == 1) && (kRowsPerWave == 4) && (kWaves == 4);   // blocked lane map available
-    static constexpr int kParkN = (CUBIC && ES == 2) ? 3 : (CUBIC ? GS360_RING_PARK_CUBIC : GS360_RING_PARK);     // 0 none, 1 latitude only, 3 all three
+    static constexpr int kParkN = (CUBIC && ES == 2) ? 3 : (CUBIC ? kRingParkCubic : kRingPark);     // 0 none, 1 latitude only, 3 all three
     static constexpr int kBlkDw = kBlocked ? kWaves * 256 : 0;
     static constexpr int kParkDw = kParkN * kRowsPerWave * 64 * kWaves;
     // the pipelined bilinear member loop keeps ALL ring-shared coordinates in LDS (three 16-byte entries per thread)
     // lean member loop (bilinear RGB, row-per-slot map): six int4 entries per thread -- latitude, left / mirrored longitude, the two
     // tap rows' byte offsets and the vertical phase of the current pitch sign
-    static constexpr bool kLean = GS360_EQ_LEAN && C == 3 && !CUBIC && ES == 1 && kRowsPerWave == 4;
+    static constexpr bool kLean = kEqLean && C == 3 && !CUBIC && ES == 1 && kRowsPerWave == 4;
     static constexpr int kPipeDw = kLean ? (MASKED ? 7 : 6) * kRowsPerWave * 64 * kWaves : 0;   // masked: + the keep-bit image's row offsets
     static constexpr int kDwords = kBlkDw + (kParkDw + kPipeDw ? kParkDw + kPipeDw : 4);
 };
@@ -964,7 +946,7 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
                 }
                 return;
             }
-            if (GS360_SHIFTED_STORE && !(mirror && centre_dup) && ofs32_ok) {
+            if (kShiftedStore && !(mirror && centre_dup) && ofs32_ok) {
                 // Row segments that start off a dword boundary (widths that are not multiples of four: 5250-byte rows of a 1750-pixel
                 // view): the same two shuffles per slot, with the byte stream of the segment re-sliced at the row's own misalignment.
                 // Lanes 0..47 write the aligned dwords inside the segment, lanes 48..50 its 0-3 head bytes, lanes 52..54 its 0-3 tail
@@ -1113,9 +1095,9 @@ __device__ __forceinline__ void eq_views_tile(const EqLaunch& L, const int b, co
 // slower than one tile per workgroup, see equirect_views_impl.
 // ROWS: the bilinear RGB instantiation for launches in which no view uses the blocked lane map (every preset-shaped view): without
 // the two blocked loop bodies the pipelined member loop alone sets the register budget (65-73 registers), so its occupancy can be
-// chosen on its own (GS360_EQR_WAVES).
+// chosen on its own (kEqRowsWaves).
 template <int C, bool CUBIC, bool ES2, bool ROWS>
-constexpr int eq_kernel_waves() { return (CUBIC || ES2) ? GS360_EQC_WAVES : (ROWS ? GS360_EQR_WAVES : GS360_EQ_WAVES); }
+constexpr int eq_kernel_waves() { return (CUBIC || ES2) ? kEqCubicWaves : (ROWS ? kEqRowsWaves : kEqWaves); }
 template <int C, bool CUBIC, bool MASKED, int ES = 1, bool ROWS = false>      // ES: bytes per sample (1: uint8, 2: uint16 -- row-per-slot lane map, no mask)
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(eq_kernel_waves<C, CUBIC, ES == 2, ROWS>(), eq_kernel_waves<C, CUBIC, ES == 2, ROWS>()))) void eq_views_kernel(const EqLaunch L) {
     __shared__ __attribute__((aligned(16))) int16_t s_wtab[CUBIC ? 32 * 32 * 16 : 8];
@@ -1147,13 +1129,9 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(eq_
 // blend): the two paths are bit-identical by construction, both read the same source bytes.
 // Ring-shared coordinates wait in LDS as in the lean loop (latitude, left / mirrored longitude); per pitch sign one more
 // entry holds each pixel's row offset inside the box with the vertical phase in its low five bits (the pitch is a multiple of 32).
-#ifndef GS360_STAGE_BYTES
-#define GS360_STAGE_BYTES 6144
-#endif
-constexpr int kStageBytes = GS360_STAGE_BYTES;                         // per wavefront: 24 KiB + 16 KiB of parked coordinates = four workgroups per CU
-#ifndef GS360_STAGE_BYTES_MASKED
-#define GS360_STAGE_BYTES_MASKED 5120   // 20 KiB of slices + 20 KiB of parked entries = four workgroups per CU (6144: three; cfg3 + mask 108 -> 100 us)
-#endif
+constexpr int kStageBytesPlain = 6144;
+constexpr int kStageBytes = kStageBytesPlain;                         // per wavefront: 24 KiB + 16 KiB of parked coordinates = four workgroups per CU
+constexpr int kStageBytesMasked = 5120;   // 20 KiB of slices + 20 KiB of parked entries = four workgroups per CU (6144: three; cfg3 + mask 108 -> 100 us)
 // s_waitcnt immediates (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]); issued through the builtin so that the
 // compiler's own wait-count bookkeeping sees them (it does not look into inline assembly)
 #define GS360_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)      /* vmcnt(0) */
@@ -1173,8 +1151,8 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 }
 
 template <bool MASKED>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS360_EQS_WAVES, GS360_EQS_WAVES))) void eq_staged_kernel(const EqLaunch L) {
-    constexpr int kSliceBytes = MASKED ? GS360_STAGE_BYTES_MASKED : kStageBytes;   // masked: one more parked entry per pixel
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kEqStagedWaves, kEqStagedWaves))) void eq_staged_kernel(const EqLaunch L) {
+    constexpr int kSliceBytes = MASKED ? kStageBytesMasked : kStageBytes;   // masked: one more parked entry per pixel
     constexpr int kSliceRounds = kSliceBytes / 16 / 64;
     static_assert(kSliceBytes % 1024 == 0, "a slice is whole DMA rounds");
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWaves * kSliceBytes / 4];
@@ -1247,7 +1225,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(GS3
     const int ny_max = ((symax - symin) >> 5) + 3;
     // (pitch <= stride: a box row that starts inside row y ends inside row y + 1 at the latest, and the last row a box may hold is
     // H - 2 -- the copy never leaves the frame)
-    const bool tile_fits = ny_max * pitch <= kSliceBytes && (stride & 3u) == 0 && (uint32_t)pitch <= stride && GS360_STAGE_ENABLE;
+    const bool tile_fits = ny_max * pitch <= kSliceBytes && (stride & 3u) == 0 && (uint32_t)pitch <= stride && kStageEnable;
     const int nchp = pitch >> 4;                          // 16-byte chunks per box row
     // DMA lane map, fixed for the tile: round k moves chunks 64 k + lane; chunk c = (row c / nchp, piece c % nchp)
     uint32_t voff[kSliceRounds];
@@ -1589,7 +1567,7 @@ hipError_t launch_equirect_staged(const EqLaunch& L, hipStream_t s) {
 hipError_t launch_equirect(const EqLaunch& L, int C, hipStream_t s) {
     dim3 grid(eq_grid_blocks(L)), block(64 * kWaves);
     const bool masked = L.mask[0] != nullptr;             // all frames or none (checked by the C ABI)
-    bool rows_only = GS360_EQ_ROWS_KERNEL != 0;
+    bool rows_only = kEqRowsKernel != 0;
     for (int k = 0; k < L.n_views; ++k) rows_only = rows_only && !L.view[k].blocked;
     switch (C) {
         case 1: if (masked) hipLaunchKernelGGL((eq_views_kernel<1, false, true>), grid, block, 0, s, L);

@@ -62,9 +62,7 @@ __device__ __forceinline__ uint2 ld_u64_via_aligned96(const uint8_t* p) {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define GS360_AB(o) (o)   // v_alignbyte_b32 shifts by S2[1:0] bytes: a byte offset's upper bits need not be masked off
-#ifndef GS360_SHIFTED_STORE
-#define GS360_SHIFTED_STORE 1   // dword stores for row segments that start off a dword boundary (0: byte stores, A/B reference)
-#endif
+constexpr bool kShiftedStore = true;   // dword stores for row segments that start off a dword boundary (false: byte stores, the A/B reference)
 
 // The 8 tap bytes (two RGB pixels + 2) of rows y0 and y1 of one pixel, at byte offsets o0 / o1 from `src`.
 // Row-paired gathers: issued naively, one instruction reads row y0 of all 64 pixels and the next one row y1; where the
@@ -135,7 +133,7 @@ __device__ __forceinline__ void store_row(uint8_t* row, const uint32_t (&px)[4],
                 for (int k = 0; k < rem; ++k) row[4 * full + k] = (uint8_t)(dw >> (8 * k));
             return;
         }
-        if (SHIFTED && GS360_SHIFTED_STORE && !skip_first) {
+        if (SHIFTED && kShiftedStore && !skip_first) {
             // a segment that starts off a dword boundary (widths that are not multiples of four): the same two shuffles, the segment's
             // byte stream re-sliced at its own misalignment -- lanes 0..47 write the aligned dwords inside it, lanes 48..50 its 0-3 head
             // bytes, lanes 52..54 its 0-3 tail bytes (one dword store + one byte store instead of three byte stores per pixel)
@@ -240,16 +238,9 @@ __device__ __forceinline__ EqCubicTaps eq_cubic_fetch(const EqSrc& L, const uint
 // The LDS copy of the 32 x 32-phase weight table is kept as TWO half tables -- window rows 0-1 of every phase (16 bytes each), then
 // rows 2-3 -- instead of 1024 entries of 32 bytes: a lane's two 16-byte reads then collide with another lane's only when their
 // phases differ by a multiple of 16 instead of 8 (round 3: 59 % of the cubic kernels' LDS-active cycles were bank conflicts).
-#ifndef GS360_CUBIC_SPLIT
-#define GS360_CUBIC_SPLIT 1
-#endif
 __device__ __forceinline__ void cubic_lds_weights(const int16_t* wtab, int phase, uint32_t (&wpk)[8]) {
     const uint4* wq = reinterpret_cast<const uint4*>(wtab);
-#if GS360_CUBIC_SPLIT
     const uint4 wa = wq[phase], wb = wq[1024 + phase];
-#else
-    const uint4 wa = wq[2 * phase], wb = wq[2 * phase + 1];
-#endif
     wpk[0] = wa.x; wpk[1] = wa.y; wpk[2] = wa.z; wpk[3] = wa.w; wpk[4] = wb.x; wpk[5] = wb.y; wpk[6] = wb.z; wpk[7] = wb.w;
 }
 // fill: thread t copies 16-byte piece i of the global table ([phase][2] pieces) to its place in the LDS layout
@@ -257,11 +248,7 @@ __device__ __forceinline__ void cubic_lds_fill(int16_t* s_wtab, const int16_t* g
     const uint4* g = reinterpret_cast<const uint4*>(g_tab);
     uint4* l = reinterpret_cast<uint4*>(s_wtab);
     for (int i = threadIdx.x; i < 2048; i += n_threads) {
-#if GS360_CUBIC_SPLIT
         l[(i & 1) * 1024 + (i >> 1)] = g[i];
-#else
-        l[i] = g[i];
-#endif
     }
 }
 

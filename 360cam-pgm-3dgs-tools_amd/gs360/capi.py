@@ -69,6 +69,7 @@ class RemapJob(C.Structure):
                 ("fill_value", C.c_int32), ("dst", C.c_void_p), ("dst_stride", C.c_size_t)]
 
 
+ABI_VERSION = 2          # GS360_ABI_VERSION of include/gs360.h this binding was written against
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -84,6 +85,15 @@ def load_library(path=None):
             raise Gs360Error(-3, f"{p} is missing -- build it with `python __graft_entry__.py` "
                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         L = C.CDLL(str(p))
+        # the version first: a stale library should say so, not fail on a symbol it does not have yet
+        try:
+            L.gs360_abi_version.argtypes = []
+            have = int(L.gs360_abi_version())
+        except AttributeError:
+            have = -1
+        if have != ABI_VERSION:
+            raise Gs360Error(-4, f"{p} has C-ABI version {have}, this binding needs {ABI_VERSION} (include/gs360.h): rebuild it with "
+                                 "`python __graft_entry__.py`")
         vp, i, sz, u32 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint32
         pvp = C.POINTER(C.c_void_p)
         L.gs360_abi_version.argtypes = []

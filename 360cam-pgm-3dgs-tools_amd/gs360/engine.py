@@ -428,7 +428,16 @@ class Engine:
             for k, n in counts.items():           # deal the sources to the devices in job-list order (Counter keeps it)
                 rec = self._source(k)
                 rec.expected = min(n, workers) if workers else n
-                rec.remaining = (rec.remaining or 0) + n
+                if rec.run != run and rec.run != 0 and rec.active == 0:
+                    # listed again by a NEW run while no job of the earlier one is inside: what that run still had announced will never
+                    # arrive (a cancelled export started again within the stale window) -- adding to it would leave a count that never
+                    # reaches zero, the frame resident and, if it was decoded ahead, its read-ahead permit held for good
+                    rec.remaining = n
+                    if rec.ahead:
+                        rec.ahead = False
+                        self._prefetch_permits.release()
+                else:
+                    rec.remaining = (rec.remaining or 0) + n
                 rec.run, rec.stamp = run, time.monotonic()
         self._start_prefetch([j.src for j in jobs if j.is_still_image], run)
         return run

@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define GS360_ABI_VERSION 1
+/* 2 (round 6): + gs360_ctx_set_option / _get_option / gs360_device_pci_bus_id (added in round 5 without a bump), the table_stage* options; the
+ * library no longer reads GS360_RING, GS360_XCD_GROUP, GS360_EQ_PERSIST, GS360_TABLE_PERSIST, GS360_LANCZOS_TABLE, GS360_TABLE_ROWS from
+ * the environment (context options of the same names do that: INTEGRATION.md section 2.1).  A binding checks gs360_abi_version() first. */
+#define GS360_ABI_VERSION 2
 
 typedef enum gs360_status {
     GS360_OK = 0,

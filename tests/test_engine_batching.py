@@ -238,6 +238,36 @@ def test_a_cancelled_run_hands_its_read_ahead_permits_back(monkeypatch):
     assert permits.acquire(timeout=1) and permits.acquire(timeout=1)      # both permits are back
 
 
+def test_a_cancelled_run_started_again_does_not_strand_counts_or_permits(monkeypatch):
+    """round-5 ADVICE (engine.py:398): a run that was cancelled and is announced AGAIN within the stale window (the GUI: cancel, run export
+    once more) lists the same sources; their `remaining` must restart at the new run's count -- added to the cancelled run's it never
+    reaches zero, the frames stay resident and the read-ahead permits of frames decoded ahead stay out"""
+    eng = bare_engine(2)
+    monkeypatch.setattr(engine, "_PREFETCH_FRAMES", 2)
+    monkeypatch.setattr(engine, "_PREFETCH_THREADS", 2)
+    eng._prefetch_permits = permits = _CountingPermits(2)
+    decoded = []
+    monkeypatch.setattr(eng, "resident_frame", lambda st, src: decoded.append(src) or [None, 0, 0, 0, 1, None], raising=False)
+    monkeypatch.setattr(eng, "release_frame", lambda st, entry: None, raising=False)
+    srcs = [f"/r/{k}.png" for k in range(4)]
+    mk = lambda: [type("J", (), {"src": s, "is_still_image": True})() for s in srcs for _v in range(3)]   # noqa: E731
+    eng.announce(mk(), workers=3)
+    wait_until(lambda: len(decoded) >= 2)
+    assert permits.starved.wait(10)                           # two frames decoded ahead, both permits out; the run is cancelled here (no retire)
+    run2 = eng.announce(mk(), workers=3)                      # ... and started again at once
+    with eng._announce_lock:
+        assert all(eng._sources[s].remaining == 3 and eng._sources[s].run == run2 for s in srcs)
+        assert not any(eng._sources[s].ahead for s in srcs)   # the stranded permits came back with the re-listing
+    for s in srcs:                                            # the second run's jobs all arrive and finish
+        for _v in range(3):
+            eng._job_touches(s)
+            eng._job_leaves(s)
+    wait_until(lambda: not eng._prefetch_threads)
+    eng.retire(run2)
+    assert eng.bookkeeping() == {"sources": 0, "inflight": [0, 0], "queue": 0}
+    assert permits.acquire(timeout=1) and permits.acquire(timeout=1)
+
+
 def test_overlapping_runs_keep_each_others_queued_sources(monkeypatch):
     """round-4 ADVICE (engine.py:377): a second announce() while the first run is still working must not discard the first run's queued
     sources (their `expected` / `remaining` counts, their place in the read-ahead queue); retire(run) ends ONE run; what a cancelled run
