@@ -413,7 +413,8 @@ def secondary_rows(ctx, steps=20):
                     "us_per_unit": round(r["ms_per_pair"] * 1e3, 1), "frac": r["frac_of_8TBps"],
                     "algorithmic_MB_per_unit": r["algorithmic_MB_per_pair"], "overhead_MB_per_unit": r["overhead_MB_per_pair"],
                     "frac_incl_overhead": r["frac_incl_map_bytes"], "kernel": r["kernel"], "parity_vs_oracle": r["parity_vs_oracle"]})
-XX if "uint16" in r["config"] else ("color-noise" if "noise" in r["config"] else "color-smooth")
+    for r in color_cfg(ctx, steps):
+        kind = "color-u16" if "uint16" in r["config"] else ("color-noise" if "noise" in r["config"] else "color-smooth")
         out.append({"config": kind, "workload": r["config"], "unit": "4000^2 image", "us_per_unit": round(r["ms_per_image"] * 1e3, 1),
                     "frac": r["frac_of_8TBps"], "algorithmic_MB_per_unit": r["algorithmic_MB_per_image"], "parity_vs_oracle": r["parity_vs_oracle"]})
     # The arithmetic-bound rows (cubic: the reference tools' default interpolation, PC:730 / DF:229-234; cfg5) carry the vector-ALU busy
