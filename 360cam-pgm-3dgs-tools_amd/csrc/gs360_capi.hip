@@ -50,7 +50,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 // context options: name, default, range, environment seed (user switches only)
 enum Opt { kOptLanemap, kOptStage, kOptRing, kOptXcdGroup, kOptEqPersist, kOptTablePersist, kOptLanczosTable, kOptTableRows, kOptColorCube,
-           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptSrcMajorAdapt, kOptTableStage, kOptTableStageRows,
+           kOptSrcMajor, kOptSrcMajorBx, kOptSrcMajorRows, kOptSrcMajorImages, kOptSrcMajorAdapt, kOptSrcMajorStage, kOptTableStage, kOptTableStageRows,
            kOptTableStageWgs, kOptCount };
 struct OptDesc { const char* key; int def, lo, hi; const char* env; };
 const OptDesc kOpts[kOptCount] = {
@@ -68,6 +68,7 @@ const OptDesc kOpts[kOptCount] = {
     {"srcmajor_rows", 32, 8, 128, nullptr},           // ... and source rows
     {"srcmajor_images", 0, 0, 12, nullptr},           // images of a tile one workgroup walks (0 auto; must divide twice the ring size)
     {"srcmajor_adapt", 1, 0, 1, nullptr},             // 1: jobs that do not fill the GPU take tiles of half the height; 0: srcmajor_rows as given (probes)
+    {"srcmajor_stage", 0, 0, 1, nullptr},             // 0: a loader wavefront copies tiles with global_load_lds; 1: the consumers stage them through registers
     {"table_stage", -1, -1, 1, "GS360_TABLE_STAGE"},  // LDS-staged table kernel (bilinear RGB through map plans): -1 auto, 0 never, 1 every job that can
     {"table_stage_rows", 32, 8, 32, nullptr},         // its output tile: rows (multiple of 8) of 64 pixels
     {"table_stage_wgs", 0, 0, 4, nullptr},            // workgroups per CU (0 auto: what the LDS holds, at most three)
@@ -97,6 +98,7 @@ struct gs360_ctx {
     // Options (gs360_ctx_set_option; seeded ONCE from the environment by gs360_ctx_create for the documented user switches).  The hot
     // path reads these atomics, never the environment: getenv racing a host thread's putenv is undefined behaviour.
     std::atomic<int> opt[kOptCount];
+    std::atomic<int> last_sm_stage{0};        // read-only "last_srcmajor_stage": 1 = that launch staged its tiles through registers
     std::atomic<int> last_sm_rows{0}, last_sm_images{0};   // read-only "last_srcmajor_rows" / "last_srcmajor_images": tile rows and images per workgroup of that launch
     std::atomic<int> last_sm_box_pct{0};      // read-only option "last_srcmajor_box_pct": tile-box bytes of the last source-major plan in % of its grid cells
     std::atomic<int> last_eq_kernel{-1};      // read-only option "last_eq_kernel": 0 gather, 1 LDS-staged, 2 source-major (which kernel the last equirect call launched)
@@ -471,6 +473,10 @@ int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
         *value = c->last_sm_box_pct.load(std::memory_order_relaxed);
         return GS360_OK;
     }
+    if (!std::strcmp(key, "last_srcmajor_stage")) {
+        *value = c->last_sm_stage.load(std::memory_order_relaxed);
+        return GS360_OK;
+    }
     if (!std::strcmp(key, "last_srcmajor_rows")) {
         *value = c->last_sm_rows.load(std::memory_order_relaxed);
         return GS360_OK;
@@ -812,17 +818,19 @@ int equirect_views_impl(gs360_ctx* c, const void* const* src_frames, const void*
         }
         for (size_t i = 0; i < Ls.size() && ring; ++i) {
             hipError_t he = hipSuccess;
-            int info[3] = {0, 0, 0};
+            int info[4] = {0, 0, 0, 0};
             if (mask_frames) {                           // (packed per chunk of frames: the staging images are reused)
                 if (int prc = pack_masks((int)i * GS360_MAX_FRAMES, Ls[i].n_frames)) { sm_release(c->sm, plan); return prc; }
                 for (int f = 0; f < Ls[i].n_frames; ++f) Ls[i].mask[f] = (const uint8_t*)c->stage[slot].d_maskbits + mask_bits_bytes * (size_t)f;
                 Ls[i].mask_stride = (int64_t)mask_pitch_dw * 4;
             }
-            const int rc = sm_launch(Ls[i], shape, plan, c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed), kSmLdsPerGroup, c->prop.multiProcessorCount,
+            const int rc = sm_launch(Ls[i], shape, plan, c->opt[kOptSrcMajorImages].load(std::memory_order_relaxed),
+                                     c->opt[kOptSrcMajorStage].load(std::memory_order_relaxed) != 0, kSmLdsPerGroup, c->prop.multiProcessorCount,
                                      c->stream[slot], &he, info);
             c->last_sm_box_pct.store(info[0], std::memory_order_relaxed);
             c->last_sm_rows.store(info[1], std::memory_order_relaxed);
             c->last_sm_images.store(info[2], std::memory_order_relaxed);
+            c->last_sm_stage.store(info[3], std::memory_order_relaxed);
             if (rc < 0) {
                 sm_release(c->sm, plan);
                 return fail(he == hipErrorOutOfMemory ? GS360_ERR_NOMEM : GS360_ERR_HIP, "source-major launch failed: %s", hipGetErrorString(he));

@@ -220,8 +220,8 @@ void sm_cache_destroy(SmCache& cache);
 bool sm_eligible(const EqLaunch& L, int C, int esize, int interp, bool masked, SmShape* S);
 int sm_prepare(const EqLaunch& L, const SmShape& S, SmCache& cache, bool masked, int Bx, int R, int G_opt, bool adapt, int max_box_pct, size_t lds_limit, int n_cu,
                hipStream_t s, hipError_t* herr, SmPlan** out, int* box_pct);
-int sm_launch(const EqLaunch& L, const SmShape& S, const SmPlan* plan, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr,
-              int* info /* [3]: box overhead %, tile rows, images per workgroup */);
+int sm_launch(const EqLaunch& L, const SmShape& S, const SmPlan* plan, int G_opt, bool stage_regs, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr,
+              int* info /* [4]: box overhead %, tile rows, images per workgroup, 1 = the register-staging kernel */);
 void sm_release(SmCache& cache, SmPlan* plan);
 void build_cubic_table(int16_t* out);      // host: OpenCV initInterTab2D(INTER_CUBIC, fixpt) restated, 32*32*16
 void build_lanczos4_table(int16_t* out);   // host: initInterTab2D(INTER_LANCZOS4, fixpt) restated, 32*32*64

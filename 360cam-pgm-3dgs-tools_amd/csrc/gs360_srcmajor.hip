@@ -92,8 +92,15 @@ static_assert(sizeof(SmArgs) <= 4096, "SmArgs travels as a kernel argument");
 constexpr int kSmMaskedPitch = 1024;                    // masked plans: at most this many bytes per box row (the pixel word holds row and byte apart)
 constexpr int kSmMaskRowBytes = 64;                     // ... and per row of the keep-bit box (16 dwords = 512 texels)
 
-template <int CW, bool MASKED>
-__global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs P) {
+// RS ("register staging", unmasked calls whose boxes are at most kSmRsRows x CW rows of at most 1 KiB): NO loader wavefront and no LDS
+// copies -- every consumer wavefront loads its rows of image g + 1 (16 bytes per lane, one box row per instruction) into registers before it
+// renders image g and writes them to the other buffer afterwards.  A CU takes LDS copies (global_load_lds) at ~25 GB/s whatever issues them
+// (profiles/r06/table_stage/README.md) -- cfg2's copies alone are at 22.6 GB/s per CU -- ordinary loads go through the L1 at 64 B per cycle.
+constexpr int kSmRsRows = 5;
+
+template <int CW, bool MASKED, bool RS>
+__global__ __launch_bounds__(64 * (CW + (RS ? 0 : 1))) void eq_srcmajor_kernel(const SmArgs P) {
+    constexpr int NL = RS ? 0 : 1;                       // loader wavefronts in front of the consumers
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
     __shared__ uint8_t* s_dst[kSmMaxImages * GS360_MAX_VIEWS];
     // XCD-aware order: XCD x (= block % 8) walks a contiguous chunk of the (frame, tile, image group) order, so the images of a tile,
@@ -160,14 +167,54 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
             }
         }
     };
+    // (RS) this wavefront's rows of an image, in registers between their loads and their LDS writes
+    struct Stage { uint4 a, b, c, d, e; };
+    static_assert(kSmRsRows == 5, "five staged rows per wavefront");
+    auto rs_load = [&](const int img) {
+        const int k = img >> 1;
+        const bool flip = img & 1;
+        int x = T.x0 + k * P.PB + lane * 16;             // the box may run across the 360-degree seam
+        if (x >= rowbytes) x -= rowbytes;
+        const uint8_t* const colp = src + (uint32_t)x;
+        auto row_of = [&](const int i) {
+            const int row = wave + CW * i;
+            const int y = flip ? P.H - 1 - T.y0 - row : T.y0 + row;          // a flipped image takes the mirrored rows in reverse order
+            const int yc = min(max(y, 0), P.H - 1);                         // EQ-SPEC clamps tap rows to [0, H - 1]
+            return *reinterpret_cast<const uint4*>(__builtin_assume_aligned(colp + (size_t)yc * P.src_stride, 16));
+        };
+        Stage o;
+        o.a = o.b = o.c = o.d = o.e = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < T.wch) {
+            o.a = row_of(0);                             // (nrows >= CW for every tile the host sends here)
+            if (wave + CW < T.nrows) o.b = row_of(1);
+            if (wave + 2 * CW < T.nrows) o.c = row_of(2);
+            if (wave + 3 * CW < T.nrows) o.d = row_of(3);
+            if (wave + 4 * CW < T.nrows) o.e = row_of(4);
+        }
+        return o;
+    };
+    auto rs_store = [&](const Stage& o, uint8_t* const buf) {
+        if (lane < T.wch) {
+            uint8_t* const p = buf + wave * pitch + lane * 16;
+            *reinterpret_cast<uint4*>(p) = o.a;
+            if (wave + CW < T.nrows) *reinterpret_cast<uint4*>(p + CW * pitch) = o.b;
+            if (wave + 2 * CW < T.nrows) *reinterpret_cast<uint4*>(p + 2 * CW * pitch) = o.c;
+            if (wave + 3 * CW < T.nrows) *reinterpret_cast<uint4*>(p + 3 * CW * pitch) = o.d;
+            if (wave + 4 * CW < T.nrows) *reinterpret_cast<uint4*>(p + 4 * CW * pitch) = o.e;
+        }
+    };
     if (wave == 0) {
         const uint8_t* ge = reinterpret_cast<const uint8_t*>(P.entries + T.eoff);
         const int eb = 20 * nq;                          // a multiple of 64 bytes (nq % 16 == 0)
         for (int o = 0; o < eb; o += 1024)
             if (o + lane * 16 < eb)
                 __builtin_amdgcn_global_load_lds((global_void_t*)(ge + o + lane * 16), (lds_void_t*)(s_ent + o), 16, 0, 0);
-        dma(g0, s_tile);
+        if constexpr (!RS) dma(g0, s_tile);
         __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): entries and first image have landed
+    }
+    if constexpr (RS) {
+        rs_store(rs_load(g0), s_tile);
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wavefront's rows are in LDS
     }
     __builtin_amdgcn_s_barrier();
     const int k4 = lane & 3;
@@ -178,7 +225,12 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
     const int dstride = (int)P.dst_stride;               // bytes per output row (a multiple of 4)
     for (int g = 0; g < G; ++g) {
         uint8_t* const cur_buf = s_tile + (g & 1) * P.buf_bytes;
-        if (wave == 0) {
+        Stage nxt;
+        nxt.a = nxt.b = nxt.c = nxt.d = nxt.e = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (RS) {
+            if (g + 1 < G) nxt = rs_load(g0 + g + 1);
+        }
+        if (!RS && wave == 0) {
             if (g + 1 < G) dma(g0 + g + 1, s_tile + ((g + 1) & 1) * P.buf_bytes);
             __builtin_amdgcn_s_waitcnt(0x0F70);
         } else {
@@ -243,14 +295,18 @@ __global__ __launch_bounds__(64 * (CW + 1)) void eq_srcmajor_kernel(const SmArgs
                 *(__attribute__((address_space(1))) uint32_t*)(dbase + off) = dwq;                 // global store, scalar base + 32-bit offset
             };
             // two turns per trip: the second one's entry addresses are immediate offsets of the first one's
-            const uint8_t* pxp = reinterpret_cast<const uint8_t*>(e_px) + ((wave - 1) * 64 + lane) * 4;
-            const uint8_t* hdp = reinterpret_cast<const uint8_t*>(e_hdr) + (((wave - 1) * 64 + lane) >> 2) * 4;
-            int i0 = (wave - 1) * 64;
+            const uint8_t* pxp = reinterpret_cast<const uint8_t*>(e_px) + ((wave - NL) * 64 + lane) * 4;
+            const uint8_t* hdp = reinterpret_cast<const uint8_t*>(e_hdr) + (((wave - NL) * 64 + lane) >> 2) * 4;
+            int i0 = (wave - NL) * 64;
             for (; i0 + 64 * CW < npx; i0 += 128 * CW, pxp += 512 * CW, hdp += 128 * CW) {
                 turn(pxp, hdp);
                 turn(pxp + 256 * CW, hdp + 64 * CW);
             }
             if (i0 < npx) turn(pxp, hdp);
+        }
+        if constexpr (RS) {
+            if (g + 1 < G) rs_store(nxt, s_tile + ((g + 1) & 1) * P.buf_bytes);
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the rows are in LDS before anybody passes the barrier
         }
         __builtin_amdgcn_s_barrier();                    // image g + 1 has landed AND every consumer is done with image g's buffer
     }
@@ -270,6 +326,7 @@ struct SmPlan {
     uint32_t* d_entries = nullptr;
     int n_tiles = 0, buf_bytes = 0, ent_bytes = 0, mbuf_bytes = 0, PB = 0;
     int rows = 0;                          // tile rows the builder ended with (R, or a half / quarter of it when R did not fit)
+    int max_wch = 0, max_nrows = 0, min_nrows = 1 << 30;   // over the plan's tiles (the register-staging kernel takes rows of <= 64 chunks, kSmConsumers .. 5 kSmConsumers rows)
     int box_pct = 0;                       // bytes of all tile boxes in percent of the tile grid cells they stand for (halos, cut tiles)
     uint64_t stamp = 0;
     int pins = 0;                          // calls that hold this plan between sm_prepare and sm_release (guarded by the cache's lock): never evicted
@@ -439,6 +496,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool mask
     if (!p) { *herr = hipErrorOutOfMemory; return -1; }
     p->n_tiles = (int)tiles.size(); p->buf_bytes = buf_bytes; p->ent_bytes = ent_bytes; p->mbuf_bytes = mbuf_bytes; p->PB = PB;
     p->box_pct = (int)(100 * box_sum / ((long long)n_boxes * std::min(Bx, PB) * R));
+    for (const SmTile& T : tiles) { p->max_wch = std::max(p->max_wch, T.wch); p->max_nrows = std::max(p->max_nrows, T.nrows); p->min_nrows = std::min(p->min_nrows, T.nrows); }
     *herr = hipMalloc((void**)&p->d_tiles, tiles.size() * sizeof(SmTile));
     if (*herr == hipSuccess) *herr = hipMalloc((void**)&p->d_entries, ent.size() * 4 + 1024);      // (slack: the entry copy reads whole 16-byte chunks)
     if (*herr == hipSuccess) *herr = hipMemcpyAsync(p->d_tiles, tiles.data(), tiles.size() * sizeof(SmTile), hipMemcpyHostToDevice, s);
@@ -684,8 +742,8 @@ void sm_release(SmCache& cache, SmPlan* plan) {
 }
 
 // Renders one chunk of frames through the source-major kernel with the call's plan.  Returns 0 or -1 with *herr set.
-int sm_launch(const EqLaunch& L, const SmShape& S, const SmPlan* plan, int G_opt, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* info) {
-    int* const box_pct = info;                           // info[0..2]: the plan's box overhead in percent, its tile rows, images per workgroup
+int sm_launch(const EqLaunch& L, const SmShape& S, const SmPlan* plan, int G_opt, bool stage_regs, size_t lds_limit, int n_cu, hipStream_t s, hipError_t* herr, int* info) {
+    int* const box_pct = info;                           // info[0..3]: the plan's box overhead in percent, its tile rows, images per workgroup, register staging
     const EqView& V = L.view[0];
     const int N = S.N, NV = L.n_views;
     *herr = hipSuccess;
@@ -713,12 +771,16 @@ int sm_launch(const EqLaunch& L, const SmShape& S, const SmPlan* plan, int G_opt
         for (int f = 0; f < L.n_frames; ++f) P.mask[f] = L.mask[f];
         P.mask_stride = (int32_t)L.mask_stride; P.mask_dw = L.W / 32; P.mbuf_bytes = plan->mbuf_bytes;
     }
-    const void* const kernel = masked ? (const void*)eq_srcmajor_kernel<kSmConsumers, true> : (const void*)eq_srcmajor_kernel<kSmConsumers, false>;
+    const bool rs = stage_regs && !masked && plan->max_wch <= 64 && plan->min_nrows >= kSmConsumers && plan->max_nrows <= kSmRsRows * kSmConsumers &&
+                    L.src_stride % 16 == 0;
+    box_pct[3] = rs ? 1 : 0;
+    const void* const kernel = masked ? (const void*)eq_srcmajor_kernel<kSmConsumers, true, false>
+                                      : (rs ? (const void*)eq_srcmajor_kernel<kSmConsumers, false, true> : (const void*)eq_srcmajor_kernel<kSmConsumers, false, false>);
     *herr = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);   // (per device: cheap, host side)
     if (*herr != hipSuccess) return -1;
-    if (masked) hipLaunchKernelGGL((eq_srcmajor_kernel<kSmConsumers, true>), dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
-    else hipLaunchKernelGGL((eq_srcmajor_kernel<kSmConsumers, false>), dim3((unsigned)(P.gchunk * 8)), dim3(64 * (kSmConsumers + 1)), lds, s, P);
-    *herr = hipGetLastError();
+    void* args[] = {(void*)&P};
+    *herr = hipLaunchKernel(kernel, dim3((unsigned)(P.gchunk * 8)), dim3((unsigned)(64 * (kSmConsumers + (rs ? 0 : 1)))), args, lds, s);
+    if (*herr == hipSuccess) *herr = hipGetLastError();
     return *herr == hipSuccess ? 0 : -1;
 }
 

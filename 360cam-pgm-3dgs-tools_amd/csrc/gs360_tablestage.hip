@@ -43,6 +43,7 @@ namespace {
 
 constexpr int kTsWaves = 8;                             // wavefronts per workgroup
 constexpr int kTsRecHead = 64;                          // bytes of a tile record in front of its plan words (TsTile + padding)
+constexpr int kTsRecBytes = kTsRecHead + 8 * 64 * 4 * 4;   // ... and of the record: 8 wavefronts x 64 lanes x 4 row slots x one dword
 constexpr uint32_t kTsSpecial = 0x80000000u;            // plan word: bit 31 = not served by the loop; bits 29-30 = kind
 constexpr uint32_t kTsFill = 0u << 29, kTsBorder = 1u << 29, kTsSlow = 2u << 29;
 
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void table_stage_plan_kernel(const uint32_t* _
             if (threadIdx.x == 0) atomicMax(&stats[0], T.chunks * 16);
         }
     }
-    uint8_t* const rec = recs + (size_t)tile * (size_t)(kTsRecHead + R * 256);
+    uint8_t* const rec = recs + (size_t)tile * (size_t)kTsRecBytes;
     if (threadIdx.x == 0) *reinterpret_cast<TsTile*>(rec) = T;
     const int pitch = T.wch * 16;
     uint32_t* const wt = reinterpret_cast<uint32_t*>(rec + kTsRecHead);
@@ -131,8 +132,11 @@ __global__ __launch_bounds__(256) void table_stage_plan_kernel(const uint32_t* _
             else if (!boxed) word = kTsSpecial | kTsSlow;
             else word = (uint32_t)((q.iy - T.y0) * pitch + 3 * q.ix - T.x0b) | ((uint32_t)q.fx << 17) | ((uint32_t)q.fy << 22);
         }
-        wt[r * 64 + lane] = word;
+        // a wavefront's four row slots (rows r, r + 8, r + 16, r + 24) side by side per lane: ONE 16-byte load per lane and tile
+        wt[(((r % kTsWaves) * 64 + lane) << 2) + r / kTsWaves] = word;
     }
+    for (int i = threadIdx.x; i < kTsWaves * 64 * 4; i += 256)       // slots past the tile's rows (R < 32): nothing to render
+        if ((i & 3) * kTsWaves + ((i >> 2) >> 6) >= R) wt[i] = kTsSpecial | kTsFill;
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------------------------
@@ -171,7 +175,8 @@ __global__ __launch_bounds__(64 * NW) void table_staged_kernel(const TsArgs P) {
     const int t0 = xcd * P.chunk + (b >> 3);
     if (t0 >= t_end) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int R = P.R, rec_bytes = kTsRecHead + R * 256;
+    const int R = P.R;
+    constexpr int rec_bytes = kTsRecBytes;
     // The job of a tile: the tile order runs job by job and a workgroup's tiles only move forward, so each of the three places that ask
     // (this tile, the next one, the one after it) keeps its own cursor.
     struct Where { int j, lt; };
@@ -200,12 +205,9 @@ __global__ __launch_bounds__(64 * NW) void table_staged_kernel(const TsArgs P) {
     struct Words { uint32_t a, b, c, d; };
     auto words_load = [&](const int tg) {
         const Where q = locate(tg, cj1);
-        const uint32_t* wp = reinterpret_cast<const uint32_t*>(P.job[q.j].recs + (size_t)q.lt * (size_t)rec_bytes + kTsRecHead) + lane;
+        const uint4 v = reinterpret_cast<const uint4*>(P.job[q.j].recs + (size_t)q.lt * (size_t)rec_bytes + kTsRecHead)[wave * 64 + lane];
         Words o;
-        o.a = wp[wave * 64];                             // (R >= NW: the first slot always exists)
-        o.b = wave + NW < R ? wp[(wave + NW) * 64] : (kTsSpecial | kTsFill);
-        o.c = wave + 2 * NW < R ? wp[(wave + 2 * NW) * 64] : (kTsSpecial | kTsFill);
-        o.d = wave + 3 * NW < R ? wp[(wave + 3 * NW) * 64] : (kTsSpecial | kTsFill);
+        o.a = v.x; o.b = v.y; o.c = v.z; o.d = v.w;      // (slots past the tile's rows hold the fill word)
         return o;
     };
     struct Head { int x0b, y0, wch, magic, chunks, ty, tx; };
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) void table_staged_kernel(const TsArgs P) {
     Words pwn = words_load(t0);
     Head T = unpack(hv0);
     box_store(T, box_load(locate(t0, cj0).j, T), s_lds);
-    __syncthreads();
+    __syncthreads();                                     // (prologue)
     // the current job's constants in scalar registers, re-read only when a tile belongs to the next job
     int jj = -1, h = 0, w = 0, tight = 0, dstride = 0;
     uint32_t fillpk = 0;
@@ -344,6 +346,13 @@ __global__ __launch_bounds__(64 * NW) void table_staged_kernel(const TsArgs P) {
             }
             pk[0] = p0; pk[1] = p1; pk[2] = p2; pk[3] = p3;
         }
+        // The next tile's box into the other buffer (last read before the previous barrier) -- BEFORE this tile's stores are issued: the
+        // wait for the box loads then has nothing younger in the wavefront's memory queue (a wait behind the four stores became
+        // s_waitcnt vmcnt(0): 1-2 us per tile until the stores had left).  The next tile's words and the head after it are pinned here
+        // as well, so that the top of the next iteration does not wait for this one's stores either.
+        if (more) box_store(Tn, st, s_lds + ((g + 1) & 1) * P.buf_bytes);
+        asm volatile("" : "+v"(pwn.a), "+v"(pwn.b), "+v"(pwn.c), "+v"(pwn.d), "+v"(hv2));
+        __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks the LDS writes below the stores again)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             // lanes 4m .. 4m + 3 hold a quad: lane k cuts dword k of its 12 bytes out of pixels k and k + 1; lane 3 repeats lane 2's store
@@ -354,11 +363,10 @@ __global__ __launch_bounds__(64 * NW) void table_staged_kernel(const TsArgs P) {
             const uint32_t loff = nq1[k] < 15 ? (uint32_t)(12 * min(lane >> 2, nq1[k]) + k4off) : lane_off;
             if (live[k]) *reinterpret_cast<uint32_t*>(__builtin_assume_aligned(dstp + (seg[k] + loff), 4)) = dwq;
         }
-        // the next tile's box into the other buffer (last read before the previous barrier)
-        if (more) box_store(Tn, st, s_lds + ((g + 1) & 1) * P.buf_bytes);
         T = Tn;
         hv1 = hv2;
-        __syncthreads();                                 // tile g + 1's box is in LDS AND every wavefront is done with tile g's
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wavefront's box rows are in LDS (NOT vmcnt: the stores drain on their own)
+        __builtin_amdgcn_s_barrier();                    // tile g + 1's box is in LDS AND every wavefront is done with tile g's
     }
 }
 
@@ -382,7 +390,7 @@ TsPlan* ts_build_plan(const uint32_t* d_packed, const uint8_t* d_hi, int h, int 
     p->tiles_x = (w + 3 + 63) / 64;                      // (a span may be three pixels longer than a row)
     p->n_tiles = p->tiles_x * ((h + R - 1) / R);
     int* d_stats = nullptr;
-    *herr = hipMalloc((void**)&p->d_recs, (size_t)p->n_tiles * (size_t)(kTsRecHead + R * 256) + 1024);      // (slack: a record is copied in whole 16-byte chunks)
+    *herr = hipMalloc((void**)&p->d_recs, (size_t)p->n_tiles * (size_t)kTsRecBytes + 1024);      // (slack: a record is copied in whole 16-byte chunks)
     if (*herr == hipSuccess) *herr = hipMalloc((void**)&d_stats, 2 * sizeof(int));
     if (*herr == hipSuccess) *herr = hipMemsetAsync(d_stats, 0, 2 * sizeof(int), s);
     if (*herr == hipSuccess) {

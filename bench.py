@@ -366,6 +366,8 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--frames", type=int, default=16, help="distinct HBM-resident frames per step (one launch; <= 16)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
+                    help="context option for an A/B run (e.g. srcmajor_stage=1); results never depend on options")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed launches before the warm-up steps until the device has been busy this long (clock ramp); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -446,6 +448,9 @@ def main():
     import gs360
 
     ctx = gs360.Context(device=local_rank if use_dist else 0, n_slots=3 if args.mode == "stream" else 2)
+    for kv in args.option:                                # kernel-selection switches for A/B runs (include/gs360.h: gs360_ctx_set_option)
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     info = ctx.info()
     # which GPU each rank really sits on: every rank's PCI bus id is gathered into config.rank_devices (+ the world size the process
     # group reports), and a job whose RCCL ranks share a device is refused (exit 3) -- N ranks over RCCL must mean N distinct GPUs.

@@ -23,9 +23,11 @@ def _check(ctx, orc, src, specs, what, expect_kernel=2, **kw):
             raise AssertionError(f"{what}: view {k}: {len(bad)} mismatching bytes of {g.size}, first at {bad[0].tolist()}")
 
 
-@pytest.fixture
-def forced(ctx):
-    with ctx.options(srcmajor=1, srcmajor_bx=768, srcmajor_rows=32):
+@pytest.fixture(params=["lds-copies", "registers"])
+def forced(ctx, request):
+    """the source-major kernel forced onto every call whose geometry fits it, in both of its staging forms: a loader wavefront copying
+    tiles with global_load_lds, and the consumers staging them through registers (option srcmajor_stage)"""
+    with ctx.options(srcmajor=1, srcmajor_bx=768, srcmajor_rows=32, srcmajor_stage=1 if request.param == "registers" else 0):
         yield ctx
 
 
