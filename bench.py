@@ -88,6 +88,15 @@ def device_state(bus_id):
         v = rd(base / name)
         if v is not None:
             out[key] = v
+    for key, name in (("fclk_mhz", "pp_dpm_fclk"), ("socclk_mhz", "pp_dpm_socclk")):      # the level marked '*': fabric / SoC clocks (HBM traffic crosses the fabric)
+        v = rd(base / name)
+        if v:
+            for ln in v.splitlines():
+                if ln.rstrip().endswith("*"):
+                    try:
+                        out[key] = float(ln.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+                    except (IndexError, ValueError):
+                        pass
     try:
         hw = sorted((base / "hwmon").glob("hwmon*"))[0]
     except (OSError, IndexError):
