@@ -464,6 +464,11 @@ int gs360_ctx_get_option(gs360_ctx* c, const char* key, int* value) {
         *value = c->last_table_slow.load(std::memory_order_relaxed);
         return GS360_OK;
     }
+    if (!std::strcmp(key, "srcmajor_plan_build_us")) {
+        std::lock_guard<std::mutex> lock(c->sm.mu);
+        *value = (int)std::min<uint64_t>(c->sm.build_us, 0x7fffffffu);
+        return GS360_OK;
+    }
     if (!std::strcmp(key, "srcmajor_plan_builds") || !std::strcmp(key, "srcmajor_inline_frees") || !std::strcmp(key, "srcmajor_plans")) {
         std::lock_guard<std::mutex> lock(c->sm.mu);
         *value = !std::strcmp(key, "srcmajor_plan_builds") ? (int)c->sm.builds : (!std::strcmp(key, "srcmajor_inline_frees") ? (int)c->sm.inline_frees : (int)c->sm.plans.size());

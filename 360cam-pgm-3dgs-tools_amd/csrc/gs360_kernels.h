@@ -213,6 +213,7 @@ struct SmCache {
     std::vector<SmPlan*> plans, graveyard;
     size_t cap = 16;
     uint64_t builds = 0;                 // plans built by this context (hits build nothing: tests count instead of timing)
+    uint64_t build_us = 0;               // ... and the wall time those builds took in all (coordinate kernels, copy back, ordering, upload)
     uint64_t inline_frees = 0;           // plans released inside a call because nobody synchronised for 64 evictions
 };
 void sm_cache_drain(SmCache& cache);     // releases the graveyard (gs360_sync, gs360_ctx_destroy)

@@ -34,6 +34,7 @@
 // ~64 read requests per CU in flight at ~1,000 cycles each; 70 MB per frame move where the union of lines + the stores is 64 MB); cfg3
 // 58-63 us against 75-79 (LDS-staged kernel), cfg1 32-36 against 41-48: copies, stores, LDS and vector ALU each 55-70 % busy.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -348,43 +349,65 @@ struct Quad { int32_t tid, vslot, j, i0; int32_t xr[4], iy[4], ph[4]; };
 constexpr int kSmQuadCap = 1632;                        // quads of one plan tile (32 KiB of entries); a denser tile is cut into several
 
 // 0: plan built; 1: this geometry does not fit the kernel (caller falls back to the gather kernels); < 0: HIP error in *herr
-int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool masked, bool smallest, size_t lds_limit, hipStream_t s, SmPlan** out, hipError_t* herr) {
+// The quads of a geometry's plan, collected ONCE however many tile heights are tried afterwards: EQ-SPEC coordinates of one member per ring from
+// the GPU (copied back through a pinned block: 60 MB for cfg3's three rings), the quads whose first pixel looks at or above the equator
+// (sy <= 16 H - 16: the upside-down images then render exactly the others -- sy' = 32 H - 32 - sy is the mirror ring's pixel (i, h - 1 - j);
+// quads ON the equator are rendered twice, same bytes to the same place; for a level ring that is the upper half of its rows).
+struct SmQuads {
+    std::vector<Quad> quads;
+    int ytop = 1 << 30;
+};
+// 0: collected; 1: the geometry does not fit (a view over a pole: quads that are not monotone in longitude); < 0: HIP error in *herr
+int sm_collect_quads(const EqLaunch& L0, const SmShape& S, hipStream_t s, SmQuads* out, hipError_t* herr) {
     const EqView& V = L0.view[0];
     const int W = L0.W, H = L0.H, N = S.N, w = V.out_w, h = V.out_h;
     const int PB = 3 * (W / N), rowbytes = 3 * W;
-    const int ntx = (PB + Bx - 1) / Bx;
     const int nqx = w / 4;
     const int centre = 16 * H - 16;
-    // A quad belongs to the plan when its first pixel looks at or above the equator (sy <= 16 H - 16): the upside-down images then render
-    // exactly the others (sy' = 32 H - 32 - sy is the mirror ring's pixel (i, h - 1 - j)); quads ON the equator are rendered twice, same
-    // bytes to the same place.  For a level ring that is the upper half of its rows.
-    struct DevBuf {                                      // (freed on every path out of this function, a std::bad_alloc from the vectors below included)
-        int2* p = nullptr;
-        ~DevBuf() { if (p) (void)hipFree(p); }
-    } dxy;
-    std::vector<int2> xy((size_t)h * w);
-    std::vector<Quad> quads;
-    if ((*herr = hipMalloc((void**)&dxy.p, xy.size() * sizeof(int2))) != hipSuccess) return -1;
-    int2* const d_xy = dxy.p;
+    struct Bufs {                                        // (released on every path out of this function, a std::bad_alloc from the vector included)
+        int2* dev = nullptr;
+        int2* host = nullptr;
+        ~Bufs() { if (dev) (void)hipFree(dev); if (host) (void)hipHostFree(host); }
+    } bufs;
+    const size_t n_xy = (size_t)h * w;
+    if ((*herr = hipMalloc((void**)&bufs.dev, n_xy * sizeof(int2))) != hipSuccess) return -1;
+    // small maps come back into an ordinary vector (pinning a block costs more than copying 2.5 MB: cfg2), large ones through a pinned block
+    std::vector<int2> pageable;
+    int2* xy_host;
+    if (n_xy * sizeof(int2) <= ((size_t)8 << 20)) {
+        pageable.resize(n_xy);
+        xy_host = pageable.data();
+    } else {
+        if ((*herr = hipHostMalloc((void**)&bufs.host, n_xy * sizeof(int2), hipHostMallocDefault)) != hipSuccess) return -1;
+        xy_host = bufs.host;
+    }
+    const int2* const xy = xy_host;
+    const double inv_pb = 1.0 / (double)PB;
+    std::vector<Quad>& quads = out->quads;
     int ytop = 1 << 30, fit = 0;
+    size_t want = 1024;
+    for (int c = 0; c < S.n_rings; ++c) want += (size_t)(L0.view[S.ref[c]].level ? (h + 1) / 2 : h / 2 + 1) * nqx;
+    quads.reserve(want);
     for (int c = 0; c < S.n_rings && fit == 0; ++c) {
         const bool level = L0.view[S.ref[c]].level != 0;
         const int rows = level ? (h + 1) / 2 : h;
-        hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, rows), dim3(256), 0, s, L0, S.ref[c], d_xy, rows);
+        hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, rows), dim3(256), 0, s, L0, S.ref[c], bufs.dev, rows);
         *herr = hipGetLastError();
-        if (*herr == hipSuccess) *herr = hipMemcpyAsync(xy.data(), d_xy, (size_t)rows * w * sizeof(int2), hipMemcpyDeviceToHost, s);
+        if (*herr == hipSuccess) *herr = hipMemcpyAsync(xy_host, bufs.dev, (size_t)rows * w * sizeof(int2), hipMemcpyDeviceToHost, s);
         if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
-        if (*herr != hipSuccess) break;
-        quads.reserve(quads.size() + (size_t)rows * nqx / (level ? 1 : 2) + 1024);
+        if (*herr != hipSuccess) return -1;
         for (int j = 0; j < rows && fit == 0; ++j)
             for (int qx = 0; qx < nqx; ++qx) {
                 const int2* p = &xy[(size_t)j * w + 4 * qx];
                 if (p[0].y > centre) continue;
                 Quad Q;
-                const int xb0 = 3 * (p[0].x >> 5);
-                const int p0 = xb0 / PB;
-                Q.vslot = c * N + (N - p0 % N) % N;
+                const int xb0 = 3 * (p[0].x >> 5);      // in [0, 3 W): the period p0 = xb0 / PB is in [0, N) (a multiply and a fix-up instead of a division)
+                int p0 = (int)((double)xb0 * inv_pb);
+                if (p0 * PB > xb0) --p0;
+                else if ((p0 + 1) * PB <= xb0) ++p0;
+                Q.vslot = c * N + (p0 ? N - p0 : 0);
                 Q.j = j; Q.i0 = 4 * qx;
+                Q.tid = 0;
                 for (int k = 0; k < 4; ++k) {
                     int dx = 3 * (p[k].x >> 5) - xb0;        // longitude grows with the column; unwrap across the seam
                     if (dx < 0) dx += rowbytes;
@@ -398,32 +421,65 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool mask
                 quads.push_back(Q);
             }
     }
-    if (*herr != hipSuccess) return -1;
-    if (fit || ytop < 0 || quads.empty()) return 1;      // (a view that reaches the pole row: the gather kernels' clamp path)
+    out->ytop = ytop;
+    return (fit || ytop < 0 || quads.empty()) ? 1 : 0;   // (a view that reaches the pole row: the gather kernels' clamp path)
+}
+
+// 0: plan built; 1: these tiles do not fit the kernel (the caller tries smaller ones, or falls back to the gather kernels); < 0: HIP error in *herr
+int sm_build_plan(const EqLaunch& L0, const SmShape& S, const SmQuads& QS, int Bx, int R, bool masked, bool smallest, size_t lds_limit, hipStream_t s, SmPlan** out,
+                  hipError_t* herr) {
+    const EqView& V = L0.view[0];
+    const int W = L0.W, N = S.N;
+    const int PB = 3 * (W / N), rowbytes = 3 * W;
+    const int ntx = (PB + Bx - 1) / Bx;
+    const std::vector<Quad>& quads = QS.quads;
+    const int ytop = QS.ytop;
+    (void)V;
     // Order (tile, view slot, row, column).  The quads were generated ring by ring in (row, column) order, so two STABLE counting sorts
-    // -- by view slot, then by tile -- give it in O(n): cfg3's 0.96 M quads took 0.1-0.2 s through std::sort (3-5x the kernel time of the
-    // whole 600-frame job), and that on the calling thread of the first call of a geometry.
+    // -- by view slot, then by tile -- give it in O(n) (cfg3's 0.96 M quads took 0.1-0.2 s through std::sort).  The keys live in their own
+    // arrays: the passes then stream 4-byte keys instead of striding through 64-byte quads.
+    const size_t nq_all = quads.size();
+    std::vector<int32_t> tid(nq_all);
     int max_tid = 0;
-    for (Quad& Q : quads) {
-        Q.tid = ((Q.iy[0] - ytop) / R) * ntx + Q.xr[0] / Bx;
-        max_tid = std::max(max_tid, Q.tid);
+    const double inv_r = 1.0 / (double)R, inv_bx = 1.0 / (double)Bx;
+    auto div_small = [](const int v, const int d, const double inv) {      // v / d for 0 <= v < 2^24 without a division
+        int q = (int)((double)v * inv);
+        if (q * d > v) --q;
+        else if ((q + 1) * d <= v) ++q;
+        return q;
+    };
+    for (size_t i = 0; i < nq_all; ++i) {
+        tid[i] = div_small(quads[i].iy[0] - ytop, R, inv_r) * ntx + div_small(quads[i].xr[0], Bx, inv_bx);
+        max_tid = std::max(max_tid, tid[i]);
     }
-    std::vector<uint32_t> order(quads.size()), tmp(quads.size());
+    std::vector<uint32_t> order(nq_all), tmp(nq_all);
     {
         std::vector<uint32_t> cnt((size_t)std::max(max_tid + 2, S.n_rings * N + 2));
-        auto pass = [&](const std::vector<uint32_t>* in, std::vector<uint32_t>& out, const int n_keys, auto key) {
-            std::fill(cnt.begin(), cnt.begin() + n_keys + 1, 0u);
-            for (size_t i = 0; i < quads.size(); ++i) ++cnt[(size_t)key(quads[in ? (*in)[i] : i]) + 1];
-            for (int k = 0; k < n_keys; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
-            for (size_t i = 0; i < quads.size(); ++i) {
-                const uint32_t q = in ? (*in)[i] : (uint32_t)i;
-                out[cnt[(size_t)key(quads[q])]++] = q;
-            }
-        };
-        pass(nullptr, tmp, S.n_rings * N, [](const Quad& Q) { return Q.vslot; });
-        pass(&tmp, order, max_tid + 1, [](const Quad& Q) { return Q.tid; });
+        std::fill(cnt.begin(), cnt.begin() + S.n_rings * N + 1, 0u);
+        for (size_t i = 0; i < nq_all; ++i) ++cnt[(size_t)quads[i].vslot + 1];
+        for (int k = 0; k < S.n_rings * N; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+        for (size_t i = 0; i < nq_all; ++i) tmp[cnt[(size_t)quads[i].vslot]++] = (uint32_t)i;
+        std::fill(cnt.begin(), cnt.begin() + max_tid + 2, 0u);
+        for (size_t i = 0; i < nq_all; ++i) ++cnt[(size_t)tid[i] + 1];
+        for (int k = 0; k <= max_tid; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+        for (size_t i = 0; i < nq_all; ++i) order[cnt[(size_t)tid[tmp[i]]]++] = tmp[i];
     }
     auto qat = [&](const size_t i) -> const Quad& { return quads[order[i]]; };
+    auto tat = [&](const size_t i) -> int { return tid[order[i]]; };
+    // Too tall for this geometry?  (The test at the end of this function: most boxes cut in two or more.)  A tile is cut at least
+    // ceil(quads / kSmQuadCap) times whatever its view groups' padding adds, so the count below is a lower bound of the tiles the loop
+    // would produce: when it already exceeds the limit the 15-20 ms of tiling are not spent (cfg3 tries 32 rows first and ends at 16).
+    if (!smallest) {
+        size_t boxes = 0, pieces = 0;
+        for (size_t a = 0; a < nq_all;) {
+            size_t b = a;
+            while (b < nq_all && tat(b) == tat(a)) ++b;
+            ++boxes;
+            pieces += (b - a + kSmQuadCap - 1) / kSmQuadCap;
+            a = b;
+        }
+        if (pieces > boxes + boxes / 4) return 1;
+    }
     std::vector<SmTile> tiles;
     std::vector<uint32_t> ent;
     std::vector<const Quad*> list;
@@ -431,7 +487,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, int Bx, int R, bool mask
     long long box_sum = 0;
     for (size_t a = 0; a < quads.size();) {
         size_t b = a;
-        while (b < quads.size() && qat(b).tid == qat(a).tid) ++b;
+        while (b < quads.size() && tat(b) == tat(a)) ++b;
         // entries in (view, row, column) order, every VIEW GROUP padded to whole wavefront turns (16 quads = 64 pixels) with copies of its
         // last quad -- same values to the same addresses -- so that a turn never mixes views (the consumers keep the destination base in
         // scalar registers)
@@ -610,18 +666,28 @@ SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, SmCache& cache, std::un
     SmPlan* plan = find();
     if (!plan) {
         lk.unlock();
+        const auto t_build = std::chrono::steady_clock::now();
         int rr = R, rc = 1, built = R;
         SmPlan* fresh = nullptr;
-        for (int attempt = 0; attempt < 3 && rc == 1; ++attempt) {
-            built = rr;
-            rc = sm_build_plan(L, S, Bx, rr, masked, attempt == 2 || rr == 8, lds_limit, s, &fresh, herr);
-            const int next = std::max(8, rr / 2);
-            if (next == rr) break;                       // (tiles of 8 rows did not fit either: nothing smaller to try)
-            rr = next;
+        try {
+            SmQuads QS;                                  // coordinates and quads once; only the tiling is redone for smaller tiles
+            rc = sm_collect_quads(L, S, s, &QS, herr);
+            for (int attempt = 0; rc == 0; ++attempt) {
+                built = rr;
+                rc = sm_build_plan(L, S, QS, Bx, rr, masked, attempt == 2 || rr == 8, lds_limit, s, &fresh, herr);
+                const int next = std::max(8, rr / 2);
+                if (rc != 1 || attempt == 2 || next == rr) break;        // built, failed, or nothing smaller left to try (rc stays 1: remembered as not fitting)
+                rr = next;
+                rc = 0;
+            }
+        } catch (const std::bad_alloc&) {
+            rc = -1;
+            *herr = hipErrorOutOfMemory;
         }
         if (rc == 1) fresh = new (std::nothrow) SmPlan();
         lk.lock();
         ++cache.builds;
+        cache.build_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build).count();
         if (rc < 0) return nullptr;
         if (!fresh) { *herr = hipErrorOutOfMemory; return nullptr; }
         fresh->W = L.W; fresh->H = L.H; fresh->N = N; fresh->n_rings = S.n_rings; fresh->w = V.out_w; fresh->h = V.out_h; fresh->Bx = Bx; fresh->R = R;

@@ -116,7 +116,8 @@ int gs360_device_pci_bus_id(gs360_ctx *ctx, char *buf, size_t buf_len);
  * Read-only (get): "last_eq_kernel" -- which kernel the last equirect call launched: 0 gather, 1 LDS-staged, 2 source-major, -1 none yet;
  * "last_srcmajor_box_pct" -- tile-box bytes of the last source-major plan in percent of the grid cells they stand for;
  * "last_srcmajor_rows", "last_srcmajor_images" -- tile rows and images per workgroup of the last source-major launch;
- * "srcmajor_plan_builds" -- source-major plans this context has built so far (a call on a cached geometry builds none), "srcmajor_plans" -- plans
+ * "srcmajor_plan_builds" -- source-major plans this context has built so far (a call on a cached geometry builds none), "srcmajor_plan_build_us"
+ * -- the wall time those builds took in all, "srcmajor_plans" -- plans
  * it holds, "srcmajor_inline_frees" -- evicted plans it had to release inside a call (normally they wait for gs360_sync(ctx, -1) /
  * gs360_ctx_destroy: hipFree synchronises the device);
  * "last_table_kernel" -- jobs of the last 8-bit table call that took the LDS-staged kernel, "last_table_stage_slow_tiles" -- tiles of their
