@@ -208,8 +208,16 @@ struct SmShape {                         // how a call's views fall into yaw rin
 };
 // the context's source-major plans: most recent geometries (a geometry may hold two: full- and half-height tiles); plans that were
 // evicted wait in the graveyard for a moment at which the caller waits for the device anyway (hipFree synchronises it)
+struct SmScratch {                       // the plan builder's device and pinned blocks, kept between builds (grow only)
+    std::mutex mu;
+    void *dev = nullptr, *host = nullptr;
+    size_t dev_cap = 0, host_cap = 0;
+    SmScratch() = default;
+    SmScratch& operator=(const SmScratch& o) { dev = o.dev; host = o.host; dev_cap = o.dev_cap; host_cap = o.host_cap; return *this; }
+};
 struct SmCache {
     std::mutex mu;
+    SmScratch scratch;
     std::vector<SmPlan*> plans, graveyard;
     size_t cap = 16;
     uint64_t builds = 0;                 // plans built by this context (hits build nothing: tests count instead of timing)

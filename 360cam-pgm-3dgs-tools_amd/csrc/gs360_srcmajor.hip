@@ -40,6 +40,8 @@
 #include <new>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "gs360_blend.h"
 #include "gs360_eqspec.h"
 #include "gs360_kernels.h"
@@ -353,148 +355,227 @@ constexpr int kSmQuadCap = 1632;                        // quads of one plan til
 // the GPU (copied back through a pinned block: 60 MB for cfg3's three rings), the quads whose first pixel looks at or above the equator
 // (sy <= 16 H - 16: the upside-down images then render exactly the others -- sy' = 32 H - 32 - sy is the mirror ring's pixel (i, h - 1 - j);
 // quads ON the equator are rendered twice, same bytes to the same place; for a level ring that is the upper half of its rows).
-struct SmQuads {
-    std::vector<Quad> quads;
-    int ytop = 1 << 30;
+// ---- plan building on the GPU: the quads of a geometry, generated and ordered on the device ---------------------------------------------
+// Round 5 copied the coordinates back and generated, sorted and tiled ~1 M quads on the calling thread (cfg3: 0.13-0.2 s).  Now the quads are
+// generated on the device in the host loop's own order (ring, row, column: a block per row, ranks by a block-wide prefix sum), their sort
+// keys (tile << 5 | view slot) go through hipCUB's stable radix sort, the quads are gathered into that order and come back ONCE, ordered;
+// only the tile assembly (boxes, cut tiles, padded view groups) remains on the host.
+// A quad belongs to the plan when its first pixel looks at or above the equator (sy <= 16 H - 16: the upside-down images then render exactly
+// the others -- sy' = 32 H - 32 - sy is the mirror ring's pixel (i, h - 1 - j); quads ON the equator are rendered twice, same bytes to the
+// same place; for a level ring that is the upper half of its rows).
+__global__ __launch_bounds__(256) void sm_quad_count_kernel(const int2* __restrict__ xy, const int w, const int nqx, const int centre, int* __restrict__ rowcnt) {
+    __shared__ int s_n;
+    const int j = blockIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int n = 0;
+    for (int qx = threadIdx.x; qx < nqx; qx += 256) n += xy[(size_t)j * w + 4 * qx].y <= centre ? 1 : 0;
+    atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) rowcnt[j] = s_n;
+}
+// exclusive prefix over the rows of one ring (at most 4095 rows: one wavefront walks them), continuing at *total
+__global__ void sm_row_scan_kernel(const int* __restrict__ rowcnt, const int rows, int* __restrict__ rowoff, int* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = *total;
+        for (int j = 0; j < rows; ++j) { rowoff[j] = acc; acc += rowcnt[j]; }
+        *total = acc;
+    }
+}
+// flags[0] = smallest tap row over the plan's quads (atomicMin), flags[1] = a quad that is not monotone in longitude was seen (a view over a pole)
+__global__ __launch_bounds__(256) void sm_quad_emit_kernel(const int2* __restrict__ xy, const int w, const int nqx, const int centre, const int c, const int N,
+                                                           const int PB, const int rowbytes, const int* __restrict__ rowoff, Quad* __restrict__ out,
+                                                           int* __restrict__ flags) {
+    __shared__ int s_wave[4], s_base;
+    const int j = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = rowoff[j];
+    __syncthreads();
+    for (int q0 = 0; q0 < nqx; q0 += 256) {
+        const int qx = q0 + (int)threadIdx.x;
+        const int2* p = &xy[(size_t)j * w + 4 * min(qx, nqx - 1)];
+        const int2 p0v = p[0];
+        const bool keep = qx < nqx && p0v.y <= centre;
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int base = s_base;
+        for (int k = 0; k < wv; ++k) base += s_wave[k];
+        if (keep) {
+            Quad Q;
+            const int xb0 = 3 * (p0v.x >> 5);            // in [0, 3 W): the period p0 = xb0 / PB is in [0, N)
+            const int pp = xb0 / PB;
+            Q.tid = 0;
+            Q.vslot = c * N + (pp ? N - pp : 0);
+            Q.j = j; Q.i0 = 4 * qx;
+            int ymin = 1 << 30, bad = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int2 pk = p[k];
+                int dx = 3 * (pk.x >> 5) - xb0;              // longitude grows with the column; unwrap across the seam
+                if (dx < 0) dx += rowbytes;
+                if (dx > rowbytes / 2) bad = 1;              // (not a monotone quad: a view over a pole; refuse rather than trust)
+                Q.xr[k] = xb0 - pp * PB + dx;                // relative to the QUAD's period (may run past its end: the copy wraps)
+                Q.iy[k] = pk.y >> 5;
+                Q.ph[k] = (pk.x & 31) | ((pk.y & 31) << 5);
+                ymin = min(ymin, Q.iy[k]);
+            }
+            out[base + before] = Q;
+            atomicMin(&flags[0], ymin);
+            if (bad) atomicOr(&flags[1], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void sm_quad_keys_kernel(const Quad* __restrict__ quads, const int n, const int ytop, const int R, const int Bx, const int ntx,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int tid = ((quads[i].iy[0] - ytop) / R) * ntx + quads[i].xr[0] / Bx;
+    keys[i] = ((uint32_t)tid << 5) | (uint32_t)quads[i].vslot;
+    idx[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void sm_quad_gather_kernel(const Quad* __restrict__ quads, const uint32_t* __restrict__ idx, const int n, Quad* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = quads[idx[i]];
+}
+
+// Device and pinned scratch of the builder, kept by the cache between builds (a build holds scratch.mu: builds are serialised among
+// themselves, never against launches); grows only.
+bool sm_scratch_fit(SmScratch& sc, size_t dev_bytes, size_t host_bytes, hipError_t* herr) {
+    if (sc.dev_cap < dev_bytes) {
+        if (sc.dev) (void)hipFree(sc.dev);
+        sc.dev = nullptr; sc.dev_cap = 0;
+        if ((*herr = hipMalloc(&sc.dev, dev_bytes)) != hipSuccess) return false;
+        sc.dev_cap = dev_bytes;
+    }
+    if (sc.host_cap < host_bytes) {
+        if (sc.host) (void)hipHostFree(sc.host);
+        sc.host = nullptr; sc.host_cap = 0;
+        if ((*herr = hipHostMalloc(&sc.host, host_bytes, hipHostMallocDefault)) != hipSuccess) return false;
+        sc.host_cap = host_bytes;
+    }
+    return true;
+}
+
+struct SmQuads {                                         // the geometry's quads on the device (in the scratch block), generation order
+    Quad* d_quads = nullptr;                             // [n]
+    Quad* d_sorted = nullptr;                            // [n]
+    uint32_t *d_keys = nullptr, *d_keys_out = nullptr, *d_idx = nullptr, *d_idx_out = nullptr;
+    void* d_cub = nullptr;
+    size_t cub_bytes = 0;
+    int n = 0, ytop = 1 << 30;
 };
 // 0: collected; 1: the geometry does not fit (a view over a pole: quads that are not monotone in longitude); < 0: HIP error in *herr
-int sm_collect_quads(const EqLaunch& L0, const SmShape& S, hipStream_t s, SmQuads* out, hipError_t* herr) {
+int sm_collect_quads(const EqLaunch& L0, const SmShape& S, SmScratch& sc, hipStream_t s, SmQuads* out, hipError_t* herr) {
     const EqView& V = L0.view[0];
     const int W = L0.W, H = L0.H, N = S.N, w = V.out_w, h = V.out_h;
     const int PB = 3 * (W / N), rowbytes = 3 * W;
     const int nqx = w / 4;
     const int centre = 16 * H - 16;
-    struct Bufs {                                        // (released on every path out of this function, a std::bad_alloc from the vector included)
-        int2* dev = nullptr;
-        int2* host = nullptr;
-        ~Bufs() { if (dev) (void)hipFree(dev); if (host) (void)hipHostFree(host); }
-    } bufs;
-    const size_t n_xy = (size_t)h * w;
-    if ((*herr = hipMalloc((void**)&bufs.dev, n_xy * sizeof(int2))) != hipSuccess) return -1;
-    // small maps come back into an ordinary vector (pinning a block costs more than copying 2.5 MB: cfg2), large ones through a pinned block
-    std::vector<int2> pageable;
-    int2* xy_host;
-    if (n_xy * sizeof(int2) <= ((size_t)8 << 20)) {
-        pageable.resize(n_xy);
-        xy_host = pageable.data();
-    } else {
-        if ((*herr = hipHostMalloc((void**)&bufs.host, n_xy * sizeof(int2), hipHostMallocDefault)) != hipSuccess) return -1;
-        xy_host = bufs.host;
-    }
-    const int2* const xy = xy_host;
-    const double inv_pb = 1.0 / (double)PB;
-    std::vector<Quad>& quads = out->quads;
-    int ytop = 1 << 30, fit = 0;
-    size_t want = 1024;
-    for (int c = 0; c < S.n_rings; ++c) want += (size_t)(L0.view[S.ref[c]].level ? (h + 1) / 2 : h / 2 + 1) * nqx;
-    quads.reserve(want);
-    for (int c = 0; c < S.n_rings && fit == 0; ++c) {
+    size_t cand = 0;                                     // candidate quads: an upper bound of the plan's
+    for (int c = 0; c < S.n_rings; ++c) cand += (size_t)(L0.view[S.ref[c]].level ? (h + 1) / 2 : h) * nqx;
+    size_t cub_bytes = 0;
+    *herr = hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)cand, 0, 32, s);
+    if (*herr != hipSuccess) return -1;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t b_xy = up((size_t)h * w * sizeof(int2)), b_rows = up((size_t)h * 4), b_q = up(cand * sizeof(Quad)), b_k = up(cand * 4), b_cub = up(cub_bytes);
+    const size_t dev_bytes = b_xy + 2 * b_rows + 256 + 2 * b_q + 4 * b_k + b_cub;
+    if (!sm_scratch_fit(sc, dev_bytes, b_q + b_k + 256, herr)) return -1;
+    uint8_t* d = (uint8_t*)sc.dev;
+    int2* d_xy = (int2*)d; d += b_xy;
+    int* d_rowcnt = (int*)d; d += b_rows;
+    int* d_rowoff = (int*)d; d += b_rows;
+    int* d_flags = (int*)d; d += 256;                    // [0] ytop, [1] bad, [2] total
+    out->d_quads = (Quad*)d; d += b_q;
+    out->d_sorted = (Quad*)d; d += b_q;
+    out->d_keys = (uint32_t*)d; d += b_k;
+    out->d_keys_out = (uint32_t*)d; d += b_k;
+    out->d_idx = (uint32_t*)d; d += b_k;
+    out->d_idx_out = (uint32_t*)d; d += b_k;
+    out->d_cub = d; out->cub_bytes = cub_bytes;
+    const int init[3] = {1 << 30, 0, 0};
+    *herr = hipMemcpyAsync(d_flags, init, sizeof(init), hipMemcpyHostToDevice, s);
+    for (int c = 0; c < S.n_rings && *herr == hipSuccess; ++c) {
         const bool level = L0.view[S.ref[c]].level != 0;
         const int rows = level ? (h + 1) / 2 : h;
-        hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, rows), dim3(256), 0, s, L0, S.ref[c], bufs.dev, rows);
+        hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, rows), dim3(256), 0, s, L0, S.ref[c], d_xy, rows);
+        hipLaunchKernelGGL(sm_quad_count_kernel, dim3(rows), dim3(256), 0, s, d_xy, w, nqx, centre, d_rowcnt);
+        hipLaunchKernelGGL(sm_row_scan_kernel, dim3(1), dim3(64), 0, s, d_rowcnt, rows, d_rowoff, d_flags + 2);
+        hipLaunchKernelGGL(sm_quad_emit_kernel, dim3(rows), dim3(256), 0, s, d_xy, w, nqx, centre, c, N, PB, rowbytes, d_rowoff, out->d_quads, d_flags);
         *herr = hipGetLastError();
-        if (*herr == hipSuccess) *herr = hipMemcpyAsync(xy_host, bufs.dev, (size_t)rows * w * sizeof(int2), hipMemcpyDeviceToHost, s);
-        if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
-        if (*herr != hipSuccess) return -1;
-        for (int j = 0; j < rows && fit == 0; ++j)
-            for (int qx = 0; qx < nqx; ++qx) {
-                const int2* p = &xy[(size_t)j * w + 4 * qx];
-                if (p[0].y > centre) continue;
-                Quad Q;
-                const int xb0 = 3 * (p[0].x >> 5);      // in [0, 3 W): the period p0 = xb0 / PB is in [0, N) (a multiply and a fix-up instead of a division)
-                int p0 = (int)((double)xb0 * inv_pb);
-                if (p0 * PB > xb0) --p0;
-                else if ((p0 + 1) * PB <= xb0) ++p0;
-                Q.vslot = c * N + (p0 ? N - p0 : 0);
-                Q.j = j; Q.i0 = 4 * qx;
-                Q.tid = 0;
-                for (int k = 0; k < 4; ++k) {
-                    int dx = 3 * (p[k].x >> 5) - xb0;        // longitude grows with the column; unwrap across the seam
-                    if (dx < 0) dx += rowbytes;
-                    if (dx > rowbytes / 2) { fit = 1; break; }   // (not a monotone quad: a view over a pole; refuse rather than trust)
-                    Q.xr[k] = xb0 - p0 * PB + dx;            // relative to the QUAD's period (may run past its end: the copy wraps)
-                    Q.iy[k] = p[k].y >> 5;
-                    Q.ph[k] = (p[k].x & 31) | ((p[k].y & 31) << 5);
-                    ytop = std::min(ytop, Q.iy[k]);
-                }
-                if (fit) break;
-                quads.push_back(Q);
-            }
     }
-    out->ytop = ytop;
-    return (fit || ytop < 0 || quads.empty()) ? 1 : 0;   // (a view that reaches the pole row: the gather kernels' clamp path)
+    int flags[3] = {0, 0, 0};
+    if (*herr == hipSuccess) *herr = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, s);
+    if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
+    if (*herr != hipSuccess) return -1;
+    out->ytop = flags[0];
+    out->n = flags[2];
+    return (flags[1] || flags[0] < 0 || flags[2] == 0) ? 1 : 0;      // (a view that reaches the pole row: the gather kernels' clamp path)
 }
 
 // 0: plan built; 1: these tiles do not fit the kernel (the caller tries smaller ones, or falls back to the gather kernels); < 0: HIP error in *herr
-int sm_build_plan(const EqLaunch& L0, const SmShape& S, const SmQuads& QS, int Bx, int R, bool masked, bool smallest, size_t lds_limit, hipStream_t s, SmPlan** out,
-                  hipError_t* herr) {
-    const EqView& V = L0.view[0];
+int sm_build_plan(const EqLaunch& L0, const SmShape& S, const SmQuads& QS, SmScratch& sc, int Bx, int R, bool masked, bool smallest, size_t lds_limit, hipStream_t s,
+                  SmPlan** out, hipError_t* herr) {
     const int W = L0.W, N = S.N;
     const int PB = 3 * (W / N), rowbytes = 3 * W;
     const int ntx = (PB + Bx - 1) / Bx;
-    const std::vector<Quad>& quads = QS.quads;
-    const int ytop = QS.ytop;
-    (void)V;
-    // Order (tile, view slot, row, column).  The quads were generated ring by ring in (row, column) order, so two STABLE counting sorts
-    // -- by view slot, then by tile -- give it in O(n) (cfg3's 0.96 M quads took 0.1-0.2 s through std::sort).  The keys live in their own
-    // arrays: the passes then stream 4-byte keys instead of striding through 64-byte quads.
-    const size_t nq_all = quads.size();
-    std::vector<int32_t> tid(nq_all);
-    int max_tid = 0;
-    const double inv_r = 1.0 / (double)R, inv_bx = 1.0 / (double)Bx;
-    auto div_small = [](const int v, const int d, const double inv) {      // v / d for 0 <= v < 2^24 without a division
-        int q = (int)((double)v * inv);
-        if (q * d > v) --q;
-        else if ((q + 1) * d <= v) ++q;
-        return q;
-    };
-    for (size_t i = 0; i < nq_all; ++i) {
-        tid[i] = div_small(quads[i].iy[0] - ytop, R, inv_r) * ntx + div_small(quads[i].xr[0], Bx, inv_bx);
-        max_tid = std::max(max_tid, tid[i]);
-    }
-    std::vector<uint32_t> order(nq_all), tmp(nq_all);
-    {
-        std::vector<uint32_t> cnt((size_t)std::max(max_tid + 2, S.n_rings * N + 2));
-        std::fill(cnt.begin(), cnt.begin() + S.n_rings * N + 1, 0u);
-        for (size_t i = 0; i < nq_all; ++i) ++cnt[(size_t)quads[i].vslot + 1];
-        for (int k = 0; k < S.n_rings * N; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
-        for (size_t i = 0; i < nq_all; ++i) tmp[cnt[(size_t)quads[i].vslot]++] = (uint32_t)i;
-        std::fill(cnt.begin(), cnt.begin() + max_tid + 2, 0u);
-        for (size_t i = 0; i < nq_all; ++i) ++cnt[(size_t)tid[i] + 1];
-        for (int k = 0; k <= max_tid; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
-        for (size_t i = 0; i < nq_all; ++i) order[cnt[(size_t)tid[tmp[i]]]++] = tmp[i];
-    }
-    auto qat = [&](const size_t i) -> const Quad& { return quads[order[i]]; };
-    auto tat = [&](const size_t i) -> int { return tid[order[i]]; };
-    // Too tall for this geometry?  (The test at the end of this function: most boxes cut in two or more.)  A tile is cut at least
-    // ceil(quads / kSmQuadCap) times whatever its view groups' padding adds, so the count below is a lower bound of the tiles the loop
-    // would produce: when it already exceeds the limit the 15-20 ms of tiling are not spent (cfg3 tries 32 rows first and ends at 16).
+    const size_t nq_all = (size_t)QS.n;
+    // Order (tile, view slot, row, column): the quads were generated ring by ring in (row, column) order, so a STABLE sort by
+    // (tile << 5 | view slot) gives it; sorted quads and keys come back through the pinned block.
+    const int nb = (int)((nq_all + 255) / 256);
+    hipLaunchKernelGGL(sm_quad_keys_kernel, dim3(nb), dim3(256), 0, s, QS.d_quads, (int)nq_all, QS.ytop, R, Bx, ntx, QS.d_keys, QS.d_idx);
+    size_t cub_bytes = QS.cub_bytes;
+    *herr = hipcub::DeviceRadixSort::SortPairs(QS.d_cub, cub_bytes, (const uint32_t*)QS.d_keys, QS.d_keys_out, (const uint32_t*)QS.d_idx, QS.d_idx_out, (int)nq_all, 0, 32, s);
+    if (*herr != hipSuccess) return -1;
+    hipLaunchKernelGGL(sm_quad_gather_kernel, dim3(nb), dim3(256), 0, s, QS.d_quads, QS.d_idx_out, (int)nq_all, QS.d_sorted);
+    Quad* const quads = (Quad*)sc.host;
+    uint32_t* const keys = (uint32_t*)((uint8_t*)sc.host + (((nq_all * sizeof(Quad)) + 255) & ~(size_t)255));
+    *herr = hipGetLastError();
+    if (*herr == hipSuccess) *herr = hipMemcpyAsync(keys, QS.d_keys_out, nq_all * 4, hipMemcpyDeviceToHost, s);
+    if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
+    if (*herr != hipSuccess) return -1;
+    auto tat = [&](const size_t i) -> int { return (int)(keys[i] >> 5); };
+    auto vat = [&](const size_t i) -> int { return (int)(keys[i] & 31u); };
+    // Too tall for this geometry?  (The test at the end of this function: most boxes cut in two or more.)  A tile is cut
+    // ceil(padded quads / kSmQuadCap) times, which one pass over the ordered keys counts exactly: when that exceeds the limit the quads
+    // are not even copied back (cfg3 tries 32 rows first and ends at 16).
     if (!smallest) {
         size_t boxes = 0, pieces = 0;
         for (size_t a = 0; a < nq_all;) {
-            size_t b = a;
-            while (b < nq_all && tat(b) == tat(a)) ++b;
+            size_t b = a, padded = 0, run = 0;           // the tile's quads with every view group padded to whole turns of 16, as the loop below does
+            while (b < nq_all && tat(b) == tat(a)) {
+                ++run;
+                if (b + 1 == nq_all || tat(b + 1) != tat(a) || vat(b + 1) != vat(b)) { padded += (run + 15) & ~(size_t)15; run = 0; }
+                ++b;
+            }
             ++boxes;
-            pieces += (b - a + kSmQuadCap - 1) / kSmQuadCap;
+            pieces += (padded + kSmQuadCap - 1) / kSmQuadCap;
             a = b;
         }
         if (pieces > boxes + boxes / 4) return 1;
     }
+    *herr = hipMemcpyAsync(quads, QS.d_sorted, nq_all * sizeof(Quad), hipMemcpyDeviceToHost, s);
+    if (*herr == hipSuccess) *herr = hipStreamSynchronize(s);
+    if (*herr != hipSuccess) return -1;
+    auto qat = [&](const size_t i) -> const Quad& { return quads[i]; };
     std::vector<SmTile> tiles;
     std::vector<uint32_t> ent;
     std::vector<const Quad*> list;
     int buf_bytes = 0, ent_bytes = 0, mbuf_bytes = 0, n_boxes = 0;
     long long box_sum = 0;
-    for (size_t a = 0; a < quads.size();) {
+    for (size_t a = 0; a < nq_all;) {
         size_t b = a;
-        while (b < quads.size() && tat(b) == tat(a)) ++b;
+        while (b < nq_all && tat(b) == tat(a)) ++b;
         // entries in (view, row, column) order, every VIEW GROUP padded to whole wavefront turns (16 quads = 64 pixels) with copies of its
         // last quad -- same values to the same addresses -- so that a turn never mixes views (the consumers keep the destination base in
         // scalar registers)
         list.clear();
         for (size_t q = a; q < b; ++q) {
             list.push_back(&qat(q));
-            if (q + 1 == b || qat(q + 1).vslot != qat(q).vslot)
+            if (q + 1 == b || vat(q + 1) != vat(q))
                 while (list.size() % 16) list.push_back(&qat(q));
         }
         ++n_boxes;
@@ -670,11 +751,12 @@ SmPlan* sm_get_plan(const EqLaunch& L, const SmShape& S, SmCache& cache, std::un
         int rr = R, rc = 1, built = R;
         SmPlan* fresh = nullptr;
         try {
-            SmQuads QS;                                  // coordinates and quads once; only the tiling is redone for smaller tiles
-            rc = sm_collect_quads(L, S, s, &QS, herr);
+            std::lock_guard<std::mutex> build_lock(cache.scratch.mu);      // (builds share the scratch blocks: one at a time; launches are not held up)
+            SmQuads QS;                                  // coordinates and quads once; only keys, sort and tiling are redone for smaller tiles
+            rc = sm_collect_quads(L, S, cache.scratch, s, &QS, herr);
             for (int attempt = 0; rc == 0; ++attempt) {
                 built = rr;
-                rc = sm_build_plan(L, S, QS, Bx, rr, masked, attempt == 2 || rr == 8, lds_limit, s, &fresh, herr);
+                rc = sm_build_plan(L, S, QS, cache.scratch, Bx, rr, masked, attempt == 2 || rr == 8, lds_limit, s, &fresh, herr);
                 const int next = std::max(8, rr / 2);
                 if (rc != 1 || attempt == 2 || next == rr) break;        // built, failed, or nothing smaller left to try (rc stays 1: remembered as not fitting)
                 rr = next;
@@ -751,6 +833,9 @@ void sm_cache_drain(SmCache& cache) {
 
 void sm_cache_destroy(SmCache& cache) {
     sm_cache_drain(cache);
+    if (cache.scratch.dev) (void)hipFree(cache.scratch.dev);
+    if (cache.scratch.host) (void)hipHostFree(cache.scratch.host);
+    cache.scratch = SmScratch();
     std::lock_guard<std::mutex> lock(cache.mu);
     for (SmPlan* p : cache.plans) sm_plan_free(p);
     cache.plans.clear();

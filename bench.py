@@ -310,7 +310,7 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
     for b0 in range(0, len(d_frames), batch):
         fr = d_frames[b0:b0 + batch]
         calls.append(ctx.make_equirect_call(fr, W, H, C, views, d_out[:len(fr) * len(views)], slot=0))
-    first_call_ms = steady_call_ms = 0.0
+    first_call_ms = steady_call_ms = plan_rebuild_ms = plan_build_ms = 0.0
     if calls:                                             # the first call builds the geometry's plan (once per context), the second is a steady one
         t_first = time.perf_counter()
         calls[0]()
@@ -320,6 +320,13 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
         calls[0]()
         ctx.sync(0)
         steady_call_ms = (time.perf_counter() - t_first) * 1e3
+        us0 = ctx.get_option("srcmajor_plan_build_us")    # a later geometry of the same context: the views 0.25 degrees wider, four frames
+        plan_build_ms = us0 / 1e3
+        wider = [gs360.View.make(v[0], v[1], v[2] + 0.25, v[3] + 0.25, v[4], v[5]) for v in specs]
+        nfw = min(4, len(d_frames), batch)
+        ctx.equirect_views_dev(d_frames[:nfw], W, H, C, wider, d_out[:nfw * len(views)], slot=0)
+        ctx.sync(0)
+        plan_rebuild_ms = (ctx.get_option("srcmajor_plan_build_us") - us0) / 1e3
     barrier()
     ctx.event_record(0, 0)
     t0 = time.perf_counter()
@@ -363,8 +370,9 @@ def job_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
                        "seconds_incl_closing_barrier": round(with_barrier, 6),
                        "rank0_kernel_us_per_frame": round(kernel_ms * 1e3 / max(1, len(mine)), 2),
                        # outside the timed region: the plan of the geometry is built by the first call of a context, every later call reuses it
-                       "plan_build_ms": round(ctx.get_option("srcmajor_plan_build_us") / 1e3, 2),      # the library's own clock around its plan builds
+                       "plan_build_ms": round(plan_build_ms, 2),      # the library's own clock around the build (+ the builder's scratch blocks and kernels: first build of the context)
                        "first_call_ms": round(first_call_ms, 2), "steady_call_ms": round(steady_call_ms, 2),
+                       "plan_rebuild_ms": round(plan_rebuild_ms, 2),                                    # a second geometry's plan (scratch and kernels already there)
                        "rank0_eq_kernel": EQ_KERNEL_NAMES.get(ctx.get_option("last_eq_kernel"), "?")},
             "roofline": None, "cpu_baseline": None,
         })
@@ -526,6 +534,14 @@ def main():
     step()                                     # (first call apart: it builds the source-major plan; config.plan_build_ms = this call - a steady one)
     ctx.sync(0)
     first_call_ms = (time.perf_counter() - t_plan) * 1e3
+    # ... and what a LATER geometry of this context costs (the first build also allocates the builder's scratch blocks and loads its
+    # kernels): the same ring with a field of view 0.25 degrees wider, one frame, rendered once into the same outputs
+    us0 = ctx.get_option("srcmajor_plan_build_us")
+    plan_build_ms = us0 / 1e3
+    wider = [gs360.View.make(v[0], v[1], v[2] + 0.25, v[3] + 0.25, v[4], v[5]) for v in view_table()]
+    ctx.equirect_views_dev(d_frames[:1], W, H, C, wider, d_out[:N_VIEWS], slot=0, src_stride=stride if args.stride_pad else 0)
+    ctx.sync(0)
+    plan_rebuild_ms = (ctx.get_option("srcmajor_plan_build_us") - us0) / 1e3
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         for _ in range(8):
@@ -627,8 +643,9 @@ def main():
                        "frames_rank0": n_mine, "per_rank_seconds": per_rank, "seconds_incl_closing_barrier": round(with_barrier, 6),
                        "settle_ms": args.settle_ms,
                        # the first call of the geometry (plan built once per context and geometry, outside the timed region) minus one steady launch
-                       "plan_build_ms": round(ctx.get_option("srcmajor_plan_build_us") / 1e3, 2),      # the library's own clock around its plan builds
+                       "plan_build_ms": round(plan_build_ms, 2),      # the library's own clock around the build (+ the builder's scratch blocks and kernels: first build of the context)
                        "first_call_ms": round(first_call_ms, 2),                                        # ... inside the first call (+ code-object load, first launch)
+                       "plan_rebuild_ms": round(plan_rebuild_ms, 2),                                    # a second geometry's plan (scratch and kernels already there)
                        "clocks": clocks,
                        "parity_vs_oracle": parity},
             "roofline": None if not baseline_shape else {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
