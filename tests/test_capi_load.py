@@ -128,7 +128,11 @@ def test_kernels_keep_their_register_budgets():
     if not res:
         pytest.skip("no kernel_resources.txt next to the library (built without csrc/Makefile)")
     assert len(res) > 60
-    for name, r in res.items():
+    own = {n: r for n, r in res.items() if "rocprim" not in n and "hipcub" not in n}
+    # (the plan builder's stable sort instantiates rocPRIM's radix-sort kernels into the library: they run once per geometry, are not
+    # ours to tune, and the one-sweep kernel keeps 80 bytes of scratch per lane by design)
+    assert len(own) > 60 and len(own) < len(res)
+    for name, r in own.items():
         # (SGPR spills into vector lanes show up as a few dozen bytes of reserved scratch without any scratch instruction)
         assert r["scratch"] <= 64 and r["vgpr_spill"] == 0, (name, r)
     want = {  # mangled-name fragment -> minimum wavefronts per SIMD
