@@ -68,6 +68,11 @@ UNION_LINE_BYTES_PER_FRAME = 413_172 * 128 + 11_520_000
 # tests/test_oracle_equirect.py) + the stores.  The honest yardstick for a kernel that shares reads between views (`roofline.frac_union`).
 UNION_BYTES_PER_FRAME = 11_520_000 + 11_685_864 * 3
 HBM_STREAM_GBS = 6290.0
+# What the memory system delivers for this kernel's traffic SHAPE with no arithmetic at all (profiles/tools/membench.hip, profiles/r06/membench/:
+# 784-byte row pieces at the frame's stride over 16 distinct 8K frames, one 16-byte store per five 16-byte loads): reads alone 6.1-6.3 TB/s,
+# with the stores 4.8-5.2 TB/s whatever the occupancy, the depth or the load instruction (registers or LDS copies).
+MEMSYS_READ_ONLY_GBS = 6320.0
+MEMSYS_MIX_GBS = (4820.0, 5180.0)
 LAUNCHES_PER_STEP = 16             # a step = 16 launches of `--frames` frames at EVERY N (round-4 verdict: same step semantics at N = 1 and N > 1)
 EQ_KERNEL_NAMES = {0: "eq_views_kernel<3>", 1: "eq_staged_kernel", 2: "eq_srcmajor_kernel"}
 
@@ -652,6 +657,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          # same launch time against the bytes the PMC counters saw move (whole 128-B lines), for context
                          "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                         # ... and against what loads and stores of this shape and ratio reach without any arithmetic (membench, round 6)
+                         "memsys": {"what": "784-byte row pieces of 16 distinct 8K frames + one stored byte per five loaded, no arithmetic (profiles/r06/membench/)",
+                                    "read_only": MEMSYS_READ_ONLY_GBS, "mix_5_to_1": list(MEMSYS_MIX_GBS), "unit": "GB/s",
+                                    "traffic_rate": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
+                                    "frac_of_mix": (round(traffic / (kernel_ms * 1e-3) / 1e9 / MEMSYS_MIX_GBS[1], 4) if traffic else None)},
                          "kernel": EQ_KERNEL_NAMES.get(eq_kernel, str(eq_kernel)), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          # SURVEY 8(d)'s stricter figure (union of the views' texels, each once, + stores): what a kernel that shares reads across views is held to

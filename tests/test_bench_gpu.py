@@ -47,6 +47,10 @@ def test_bench_single_rank_line_matches_the_contract():
     # the headline shape takes the source-major kernel: its line bound is the UNION of the six views' lines, each once
     assert d["roofline"]["kernel"] == "eq_srcmajor_kernel"
     assert d["roofline"]["line_bound"]["bytes_per_launch"] == 16 * (413172 * 128 + 11520000)
+    # ... and the counters' traffic of the launch is held against what bare loads + stores of this shape reach (profiles/r06/membench/)
+    m = d["roofline"]["memsys"]
+    assert m["mix_5_to_1"][0] < m["mix_5_to_1"][1] < m["read_only"] < d["roofline"]["peak"]
+    assert m["traffic_rate"] is None or 0.3 < m["frac_of_mix"] < 1.2
 
 
 def test_bench_rccl_world_of_one_prints_exactly_one_json_line():
