@@ -35,7 +35,7 @@ of a video; frames dealt to the ranks the same way, strong scaling.
 
 `--mode stream` is the host-fed STRONG-scaling companion (BASELINE.json configs[2], reference seam
 gs360_360PerspCut.py:1049-1078): 600 8K frames are dealt round-robin to the ranks (gs360/sharding.py), every frame
-goes pinned host -> H2D -> one 12-view `full360coverage` launch -> D2H through gs360/stream.py; the rate is bounded by
+goes pinned host -> H2D, four frames at a time through one 4 x 12-view `full360coverage` launch, -> D2H (gs360/stream.py); the rate is bounded by
 PCIe (88.5 MB in + 92.2 MB out per frame), which the line reports next to the measured value.  It is never the
 headline `value` of the default mode.
 """
@@ -269,7 +269,7 @@ def stream_mode(args, ctx, np, gs360, rank, world, barrier, info, dist, torch):
             "n_gpus": world, "steps": args.stream_frames, "warmup": n_slots, "ms_per_step": round(elapsed * 1e3 / max(1, args.stream_frames), 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"HOST-FED stream (not the headline): {args.stream_frames} 7680x3840x3 frames dealt round-robin to {world} rank(s) -> "
-                                   f"full360coverage 12x{size}x{size}, pinned host -> H2D -> one 12-view launch -> D2H per frame "
+                                   f"full360coverage 12x{size}x{size}, pinned host -> H2D per frame, one launch of 4 frames x 12 views (source-major kernel), D2H per frame "
                                    "(BASELINE.json configs[2]; PC:1049-1078)",
                        "frames_total": args.stream_frames, "frames_rank0": len(mine), "views": len(views), "device": info["name"],
                        "rank_devices": info["rank_devices"], "world_seen": info["world_seen"],

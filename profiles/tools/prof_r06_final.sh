@@ -40,6 +40,7 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_settings.json 2>> $OUT
 python tests/tools/bench_configs.py --steps 40 > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
 python bench.py --mode job > $OUT/bench_job600_1gpu.json 2> $OUT/bench_job.err
 python bench.py --mode stream --no-cpu-baseline > $OUT/bench_stream600_1gpu.json 2>> $OUT/bench_job.err
+python tests/tools/plan_build_times.py > $OUT/plan_build_times.txt 2>&1
 python tests/tools/bench_cfg4_stage.py --steps 40 --variants 0:32:0,1:32:0,1:32:2,1:16:0 > $OUT/cfg4_stage.txt 2>&1
 (for spec in "" "lanemap=0" "lanemap=1" "ring=1" "lanemap=0 stage=1" "srcmajor=1" "srcmajor=1 srcmajor_stage=1" "srcmajor=1 --only srcmajor" "table_stage=1" "table_stage=1 table_stage_rows=16 --only tablestage" "--only tablestage"; do
    args=""; nxt=""; for o in $spec; do if [ "$nxt" = only ]; then args="$args --only $o"; nxt=""; elif [ "$o" = "--only" ]; then nxt=only; else args="$args --option $o"; fi; done
