@@ -350,11 +350,6 @@ struct Quad { int32_t tid, vslot, j, i0; int32_t xr[4], iy[4], ph[4]; };
 
 constexpr int kSmQuadCap = 1632;                        // quads of one plan tile (32 KiB of entries); a denser tile is cut into several
 
-// 0: plan built; 1: this geometry does not fit the kernel (caller falls back to the gather kernels); < 0: HIP error in *herr
-// The quads of a geometry's plan, collected ONCE however many tile heights are tried afterwards: EQ-SPEC coordinates of one member per ring from
-// the GPU (copied back through a pinned block: 60 MB for cfg3's three rings), the quads whose first pixel looks at or above the equator
-// (sy <= 16 H - 16: the upside-down images then render exactly the others -- sy' = 32 H - 32 - sy is the mirror ring's pixel (i, h - 1 - j);
-// quads ON the equator are rendered twice, same bytes to the same place; for a level ring that is the upper half of its rows).
 // ---- plan building on the GPU: the quads of a geometry, generated and ordered on the device ---------------------------------------------
 // Round 5 copied the coordinates back and generated, sorted and tiled ~1 M quads on the calling thread (cfg3: 0.13-0.2 s).  Now the quads are
 // generated on the device in the host loop's own order (ring, row, column: a block per row, ranks by a block-wide prefix sum), their sort
@@ -374,13 +369,26 @@ __global__ __launch_bounds__(256) void sm_quad_count_kernel(const int2* __restri
     __syncthreads();
     if (threadIdx.x == 0) rowcnt[j] = s_n;
 }
-// exclusive prefix over the rows of one ring (at most 4095 rows: one wavefront walks them), continuing at *total
-__global__ void sm_row_scan_kernel(const int* __restrict__ rowcnt, const int rows, int* __restrict__ rowoff, int* __restrict__ total) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int acc = *total;
-        for (int j = 0; j < rows; ++j) { rowoff[j] = acc; acc += rowcnt[j]; }
-        *total = acc;
+// exclusive prefix over the rows of one ring (fewer than 4096 rows: one block, 16 rows per thread), continuing at *total
+__global__ __launch_bounds__(256) void sm_row_scan_kernel(const int* __restrict__ rowcnt, const int rows, int* __restrict__ rowoff, int* __restrict__ total) {
+    __shared__ int s_sum[256];
+    const int t = (int)threadIdx.x, j0 = 16 * t;
+    int cnt[16], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { cnt[k] = j0 + k < rows ? rowcnt[j0 + k] : 0; mine += cnt[k]; }
+    s_sum[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                  // inclusive scan of the threads' sums
+        const int v = t >= d ? s_sum[t - d] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
     }
+    int acc = *total + s_sum[t] - mine;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { if (j0 + k < rows) rowoff[j0 + k] = acc; acc += cnt[k]; }
+    __syncthreads();                                     // (every thread has read *total)
+    if (t == 255) *total = acc;
 }
 // flags[0] = smallest tap row over the plan's quads (atomicMin), flags[1] = a quad that is not monotone in longitude was seen (a view over a pole)
 __global__ __launch_bounds__(256) void sm_quad_emit_kernel(const int2* __restrict__ xy, const int w, const int nqx, const int centre, const int c, const int N,
@@ -503,7 +511,7 @@ int sm_collect_quads(const EqLaunch& L0, const SmShape& S, SmScratch& sc, hipStr
         const int rows = level ? (h + 1) / 2 : h;
         hipLaunchKernelGGL(eq_plan_coords_kernel, dim3((w + 255) / 256, rows), dim3(256), 0, s, L0, S.ref[c], d_xy, rows);
         hipLaunchKernelGGL(sm_quad_count_kernel, dim3(rows), dim3(256), 0, s, d_xy, w, nqx, centre, d_rowcnt);
-        hipLaunchKernelGGL(sm_row_scan_kernel, dim3(1), dim3(64), 0, s, d_rowcnt, rows, d_rowoff, d_flags + 2);
+        hipLaunchKernelGGL(sm_row_scan_kernel, dim3(1), dim3(256), 0, s, d_rowcnt, rows, d_rowoff, d_flags + 2);
         hipLaunchKernelGGL(sm_quad_emit_kernel, dim3(rows), dim3(256), 0, s, d_xy, w, nqx, centre, c, N, PB, rowbytes, d_rowoff, out->d_quads, d_flags);
         *herr = hipGetLastError();
     }
@@ -728,7 +736,7 @@ bool sm_key_matches(const SmPlan* p, const EqLaunch& L, const SmShape& S, int Bx
 }
 
 // The plan of (launch geometry, tile shape) from the context's cache, built on a miss.  Called with `lk` held; the lock is RELEASED while a
-// plan is built (a coordinate kernel per ring, a device -> host copy, the host-side ordering: 6 ms for cfg2, tens of ms for cfg3 -- other
+// plan is built (coordinate, quad and sort kernels, one copy back, the host-side tile assembly: 1-3 ms for cfg2, 15-18 ms for cfg3 -- other
 // slots' calls must not queue behind that) and two threads that miss on the same geometry at once both build, the second result is
 // dropped.  Evicted and dropped plans go to the cache's graveyard: hipFree synchronises the device, so they are released where the caller
 // waits for the device anyway (gs360_sync, context destruction).  Returns nullptr with *herr == hipSuccess for a geometry that does not
