@@ -38,6 +38,10 @@ python bench.py --steps 100 --warmup 10 > $OUT/bench_plain.json 2> $OUT/bench_pl
 for k in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-secondary > $OUT/bench_driver_settings_$k.json 2>> $OUT/bench_plain.err; sleep 20; done
 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_settings.json 2>> $OUT/bench_plain.err
 python tests/tools/bench_configs.py --steps 40 > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
+# the memory system's own rate for the headline's traffic shape on THIS box (profiles/tools/membench.hip), right after the bench lines
+[ -x scratch/membench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scratch/membench profiles/tools/membench.hip
+(for m in rows dma; do scratch/membench $m 4 2 8 15; done; for m in rowsmix dmamix; do for wg in 2 4; do scratch/membench $m 4 $wg 8 15 1; done; done; scratch/membench rowsmix 4 2 8 15 2; scratch/membench copy 4 2 4 15; scratch/membench write 4 2 8 15) > $OUT/membench_same_box.txt 2>&1
+python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $OUT/bench_after_membench.json 2>> $OUT/bench_plain.err
 python bench.py --mode job > $OUT/bench_job600_1gpu.json 2> $OUT/bench_job.err
 python bench.py --mode stream --no-cpu-baseline > $OUT/bench_stream600_1gpu.json 2>> $OUT/bench_job.err
 python tests/tools/plan_build_times.py > $OUT/plan_build_times.txt 2>&1
