@@ -736,7 +736,7 @@ bool sm_key_matches(const SmPlan* p, const EqLaunch& L, const SmShape& S, int Bx
 }
 
 // The plan of (launch geometry, tile shape) from the context's cache, built on a miss.  Called with `lk` held; the lock is RELEASED while a
-// plan is built (coordinate, quad and sort kernels, one copy back, the host-side tile assembly: 1-3 ms for cfg2, 15-18 ms for cfg3 -- other
+// plan is built (coordinate, quad and sort kernels, one copy back, the host-side tile assembly: 1-3 ms for cfg2, 16-20 ms for cfg3 -- other
 // slots' calls must not queue behind that) and two threads that miss on the same geometry at once both build, the second result is
 // dropped.  Evicted and dropped plans go to the cache's graveyard: hipFree synchronises the device, so they are released where the caller
 // waits for the device anyway (gs360_sync, context destruction).  Returns nullptr with *herr == hipSuccess for a geometry that does not
