@@ -8,6 +8,7 @@
 //   rowsmix  rows + one store per five loads                                            (shape + ratio)
 //   dma      `rows` through global_load_lds (LDS copies, nothing reads the LDS)         (the kernel's read instruction)
 //   dmamix   dma + stores
+//   rows5 / dma5  the kernel's own store shape: 768 bytes per five rows, stores 5 dwordx3 | 6 dwordx3 non-temporal | 7 dwordx4 | 8 dwordx4 non-temporal
 //   write    contiguous stores only
 // usage: membench <mode> [waves_per_wg=4] [wgs_per_cu=2..8] [unroll=8] [reps=20] [stores: 1 plain, 2 non-temporal, 3 into a 16 MB window, 4 a box's stores at its end]
 // build: hipcc --offload-arch=gfx950 -O3 -o membench membench.hip
@@ -117,6 +118,51 @@ __global__ void __launch_bounds__(256) rows_kernel(const uint8_t* __restrict__ s
     if (!STORES && acc == 0x9e3779b9u) sink[0] = acc;
 }
 
+// the kernel's own store shape: per five box rows (3,920 bytes read) ONE store instruction of 768 contiguous bytes -- as 64 lanes x 12 bytes
+// (dwordx3 at a 12-byte stride: what the consumers issue) or as 48 lanes x 16 aligned bytes -- plain or non-temporal.  30 rows per box.
+template <int SK, bool DMA>   // SK: 5 dwordx3 plain, 6 dwordx3 non-temporal, 7 dwordx4 plain, 8 dwordx4 non-temporal
+__global__ void __launch_bounds__(256) rows5_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n_boxes, uint32_t* sink) {
+    extern __shared__ uint8_t s_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const int waves = gridDim.x * nwv;
+    const int per_xcd = (gridDim.x + 7) / 8;
+    const int wave0 = ((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * nwv + wv;
+    uint8_t* const my = s_lds + wv * (5 * 1024);
+    size_t o = (size_t)wave0 * 768;
+    for (int b = wave0; b < n_boxes; b += waves) {
+        const int f = b / (kBoxesX * kBoxesY), r = b - f * (kBoxesX * kBoxesY), by = r / kBoxesX, bx = r - by * kBoxesX;
+        const uint8_t* p = src + (size_t)f * kFrame + (size_t)(by * kBoxRows) * kRow + bx * kPiece + lane * 16;
+        for (int row = 0; row < 30; row += 5) {
+            uint4 w = {(uint32_t)row, (uint32_t)b, 0u, 0u};
+            if (lane < kLanes) {
+                if constexpr (DMA) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u)
+                        __builtin_amdgcn_global_load_lds((global_void_t*)(p + (size_t)(row + u) * kRow), (lds_void_t*)(my + u * 1024), 16, 0, 0);
+                } else {
+                    uint4 v[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) v[u] = *(const uint4*)(p + (size_t)(row + u) * kRow);
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { w.x ^= v[u].x; w.y ^= v[u].y; w.z ^= v[u].z; w.w ^= v[u].w; }
+                }
+            }
+            if constexpr (SK == 5 || SK == 6) {
+                uint32_t* q = (uint32_t*)(dst + o + lane * 12);
+                if constexpr (SK == 6) { __builtin_nontemporal_store(w.x, q); __builtin_nontemporal_store(w.y, q + 1); __builtin_nontemporal_store(w.z, q + 2); }
+                else { q[0] = w.x; q[1] = w.y; q[2] = w.z; }
+            } else if (lane < 48) {
+                uint32_t* q = (uint32_t*)(dst + o + lane * 16);
+                if constexpr (SK == 8) { __builtin_nontemporal_store(w.x, q); __builtin_nontemporal_store(w.y, q + 1); __builtin_nontemporal_store(w.z, q + 2); __builtin_nontemporal_store(w.w, q + 3); }
+                else *(uint4*)q = w;
+            }
+            o += (size_t)waves * 768;
+        }
+    }
+    if constexpr (DMA) { __builtin_amdgcn_s_waitcnt(0); }
+    if (n_boxes < 0) sink[0] = 1;
+}
+
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "read";
     const int wpw = argc > 2 ? atoi(argv[2]) : 4, per_cu = argc > 3 ? atoi(argv[3]) : 4, unroll = argc > 4 ? atoi(argv[4]) : 8, reps = argc > 5 ? atoi(argv[5]) : 20, sk = argc > 6 ? atoi(argv[6]) : 1;
@@ -162,6 +208,12 @@ int main(int argc, char** argv) {
             BYU(M); rd = (double)n_boxes * kBoxRows * kPiece;
 #undef M
             wr = (double)n_boxes * (kBoxRows / 4) * kStoreLanes * 16;
+        } else if (!strcmp(mode, "rows5") || !strcmp(mode, "dma5")) {
+            const bool dma = mode[0] == 'd';
+#define R5(S) do { if (dma) hipLaunchKernelGGL((rows5_kernel<S, true>), dim3(blocks), dim3(threads), wpw * 5 * 1024, 0, src, (uint8_t*)dst, n_boxes, sink); \
+                   else hipLaunchKernelGGL((rows5_kernel<S, false>), dim3(blocks), dim3(threads), 0, 0, src, (uint8_t*)dst, n_boxes, sink); } while (0)
+            if (sk == 6) R5(6); else if (sk == 7) R5(7); else if (sk == 8) R5(8); else R5(5);
+            rd = (double)n_boxes * 30 * kPiece; wr = (double)n_boxes * 6 * 768;
         } else if (!strcmp(mode, "write")) {
             hipLaunchKernelGGL(write_kernel, dim3(blocks), dim3(threads), 0, 0, dst, n16); rd = 0; wr = (double)bytes;
         } else { printf("unknown mode %s\n", mode); exit(2); }
