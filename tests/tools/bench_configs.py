@@ -60,12 +60,17 @@ def time_steps(ctx, call, steps, warmup=5):
     return ctx.event_elapsed_ms(0, 0, 1) / steps
 
 
-def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR, with_mask=False, dtype=np.uint8):
+def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LINEAR, with_mask=False, dtype=np.uint8, hot=False):
     if dtype == np.uint16:
         return equirect_u16_cfg(ctx, name, W, H, specs, n_frames, steps, interp)
     base = synth(H, W, 0)                       # frame k = the base image rolled 97 k texels (distinct HBM-resident frames, one synthesis)
-    frames = [base] + [np.ascontiguousarray(np.roll(base, 97 * k, axis=1)) for k in range(1, n_frames)]
-    d_fr = [ctx.to_device(f) for f in frames]
+    if hot:                                     # SURVEY 8(d)(i)'s "hot" number: ONE frame in every slot of the launch (88.5 MB: Infinity-Cache-resident)
+        frames = [base] * n_frames
+        d0 = ctx.to_device(base)
+        d_fr = [d0] * n_frames
+    else:
+        frames = [base] + [np.ascontiguousarray(np.roll(base, 97 * k, axis=1)) for k in range(1, n_frames)]
+        d_fr = [ctx.to_device(f) for f in frames]
     views = [gs360.View.make(*s) for s in specs]
     d_out = [ctx.alloc(s[4] * s[5] * 3) for _ in range(n_frames) for s in specs]
     masks = d_masks = None
@@ -95,7 +100,7 @@ def equirect_cfg(ctx, name, W, H, specs, n_frames, steps, interp=gs360.INTERP_LI
     out_px = sum(s[4] * s[5] for s in specs)
     algo = (out_px * 3 + uv * 3) * n_frames
     algo_union = (out_px * 3 + int(union.sum()) * 3) * n_frames
-    for b in d_fr + d_out + (d_masks or []):
+    for b in (d_fr[:1] if hot else d_fr) + d_out + (d_masks or []):
         ctx.free(b)
     return {"config": name, "frames_per_launch": n_frames, "views": len(specs), "out_MPix_per_frame": round(out_px / 1e6, 2),
             "ms_per_launch": round(ms, 4), "us_per_frame": round(ms / n_frames * 1e3, 1),
@@ -396,10 +401,13 @@ def secondary_rows(ctx, steps=20):
         ("cfg3+mask", "8K -> full360coverage 12x1600^2, linear, fused keep-mask (pack pass inside the timed region)", 7680, 3840,
          full360, gs360.INTERP_LINEAR, True),
     ]
+    plan.append(("cfg2-hot", "8K -> 6x800^2, linear, the SAME frame in all 16 slots of a launch (Infinity-Cache-warm: SURVEY 8(d)'s hot number; "
+                 "the headline is the cold one)", 7680, 3840, ring_views(6, 800, HFOV_12MM), gs360.INTERP_LINEAR, False))
     out = []
     for key, name, w, h, specs, interp, with_mask in plan:
         # frames per launch as in the full rows of main(): 8 for the 5.7K / 6 x 800^2 shapes, 4 for the 8K large-view presets
-        r = equirect_cfg(ctx, name, w, h, specs, 8 if key in ("cfg1", "cfg1-cubic", "cfg2-cubic") else 4, steps, interp=interp, with_mask=with_mask)
+        r = equirect_cfg(ctx, name, w, h, specs, 16 if key == "cfg2-hot" else 8 if key in ("cfg1", "cfg1-cubic", "cfg2-cubic") else 4, steps, interp=interp,
+                         with_mask=with_mask, hot=key == "cfg2-hot")
         out.append({"config": key, "workload": name, "unit": "frame", "us_per_unit": r["us_per_frame"], "frac": r["frac_of_8TBps"],
                     "algorithmic_MB_per_unit": r["algorithmic_MB_per_frame"], "frac_union": r["frac_union"], "union_MB_per_unit": r["union_MB_per_frame"],
                     "eq_kernel": r["eq_kernel"], "parity_vs_oracle": r["parity_vs_oracle"]})
