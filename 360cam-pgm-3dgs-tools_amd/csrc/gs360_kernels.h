@@ -208,7 +208,7 @@ struct SmShape {                         // how a call's views fall into yaw rin
 };
 // the context's source-major plans: most recent geometries (a geometry may hold two: full- and half-height tiles); plans that were
 // evicted wait in the graveyard for a moment at which the caller waits for the device anyway (hipFree synchronises it)
-struct SmScratch {                       // the plan builder's device and pinned blocks, kept between builds (grow only)
+struct SmScratch {                       // the plan builder's device and host blocks, kept between builds (grow only)
     std::mutex mu;
     void *dev = nullptr, *host = nullptr;
     size_t dev_cap = 0, host_cap = 0;

@@ -35,6 +35,7 @@
 // 58-63 us against 75-79 (LDS-staged kernel), cfg1 32-36 against 41-48: copies, stores, LDS and vector ALU each 55-70 % busy.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void sm_quad_gather_kernel(const Quad* __restr
     if (i < n) out[i] = quads[idx[i]];
 }
 
-// Device and pinned scratch of the builder, kept by the cache between builds (a build holds scratch.mu: builds are serialised among
+// Device and host scratch of the builder, kept by the cache between builds (a build holds scratch.mu: builds are serialised among
 // themselves, never against launches); grows only.
 bool sm_scratch_fit(SmScratch& sc, size_t dev_bytes, size_t host_bytes, hipError_t* herr) {
     if (sc.dev_cap < dev_bytes) {
@@ -460,9 +461,12 @@ bool sm_scratch_fit(SmScratch& sc, size_t dev_bytes, size_t host_bytes, hipError
         sc.dev_cap = dev_bytes;
     }
     if (sc.host_cap < host_bytes) {
-        if (sc.host) (void)hipHostFree(sc.host);
+        // ordinary (pageable) host memory: on this platform a copy out of the device into a block that has been touched before runs at the
+        // pinned rate (83 MiB in 1.56 ms either way), and hipHostMalloc of cfg3's 108 MB costs 15 ms of the first build + 8 ms at context
+        // destruction (profiles/r06/alloc_probe.txt)
+        std::free(sc.host);
         sc.host = nullptr; sc.host_cap = 0;
-        if ((*herr = hipHostMalloc(&sc.host, host_bytes, hipHostMallocDefault)) != hipSuccess) return false;
+        if (!(sc.host = std::aligned_alloc(4096, (host_bytes + 4095) & ~(size_t)4095))) { *herr = hipErrorOutOfMemory; return false; }
         sc.host_cap = host_bytes;
     }
     return true;
@@ -532,7 +536,7 @@ int sm_build_plan(const EqLaunch& L0, const SmShape& S, const SmQuads& QS, SmScr
     const int ntx = (PB + Bx - 1) / Bx;
     const size_t nq_all = (size_t)QS.n;
     // Order (tile, view slot, row, column): the quads were generated ring by ring in (row, column) order, so a STABLE sort by
-    // (tile << 5 | view slot) gives it; sorted quads and keys come back through the pinned block.
+    // (tile << 5 | view slot) gives it; sorted quads and keys come back through the host block.
     const int nb = (int)((nq_all + 255) / 256);
     hipLaunchKernelGGL(sm_quad_keys_kernel, dim3(nb), dim3(256), 0, s, QS.d_quads, (int)nq_all, QS.ytop, R, Bx, ntx, QS.d_keys, QS.d_idx);
     size_t cub_bytes = QS.cub_bytes;
@@ -842,7 +846,7 @@ void sm_cache_drain(SmCache& cache) {
 void sm_cache_destroy(SmCache& cache) {
     sm_cache_drain(cache);
     if (cache.scratch.dev) (void)hipFree(cache.scratch.dev);
-    if (cache.scratch.host) (void)hipHostFree(cache.scratch.host);
+    std::free(cache.scratch.host);
     cache.scratch = SmScratch();
     std::lock_guard<std::mutex> lock(cache.mu);
     for (SmPlan* p : cache.plans) sm_plan_free(p);
