@@ -391,7 +391,10 @@ def test_closing_a_blocked_session_releases_the_reader(tmp_path):
     make_clip(tmp_path / "clip.npy", n=8, h=64, w=128)
     sess = video.VideoSession([_FakeState()], _decode_plan(tmp_path), budget=30 << 10)   # one frame fits, nobody consumes
     import time
-    time.sleep(0.5)
+    t0 = time.monotonic()
+    while sess.count < 1 and time.monotonic() - t0 < 30:      # (the decoder double is a python process: its start-up time is the machine's)
+        time.sleep(0.05)
+    time.sleep(0.3)                                           # the reader now sits at its budget with the second frame
     assert not sess.finished and sess.count >= 1
     sess.close()
     assert sess.finished and not sess.thread.is_alive()
