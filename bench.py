@@ -78,6 +78,33 @@ LAUNCHES_PER_STEP = 16             # a step = 16 launches of `--frames` frames a
 EQ_KERNEL_NAMES = {0: "eq_views_kernel<3>", 1: "eq_staged_kernel", 2: "eq_srcmajor_kernel"}
 
 
+def memsys_probe(dev):
+    """The memory-system probe of profiles/tools/membench.hip (built as lib/libgs360probe.so -- measurement aid, not product) run IN-PROCESS on
+    the GPU the bench just used, right after the timed region: bare loads of the headline's 784-byte row pieces, and the same with one stored byte per
+    five loaded (registers / LDS copies).  {mode: GB/s} or None (library absent, or a probe failed).  ~1 s."""
+    import ctypes
+    path = ROOT / "360cam-pgm-3dgs-tools_amd" / "lib" / "libgs360probe.so"
+    if not path.exists():
+        return None
+    try:
+        lib = ctypes.CDLL(str(path))
+        fn = lib.gs360_membench
+        fn.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        fn.restype = ctypes.c_int
+        out = {}
+        for mode in ("rows", "rowsmix", "dmamix"):
+            o = (ctypes.c_double * 7)()
+            rc = fn(mode.encode(), int(dev), 4, 2, 8, 9, 1, o)
+            if rc != 0:
+                print(f"bench.py: memory probe {mode} failed ({rc})", file=sys.stderr)
+                return None
+            out[mode] = round(o[0] * 1e3, 1)
+        return out
+    except Exception as e:      # the headline line must survive a failure here
+        print(f"bench.py: memory probe failed: {e!r}", file=sys.stderr)
+        return None
+
+
 def device_state(bus_id):
     """clocks / power / partition modes of the GPU a rank sits on, read from the amdgpu driver's sysfs files (no child process: a process
     that has initialised the GPU must not exec): sclk and mclk as the driver reports them RIGHT NOW -- call it while the device is busy."""
@@ -396,6 +423,7 @@ def main():
                     help="untimed launches before the warm-up steps until the device has been busy this long (clock ramp); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` array (the other BASELINE configs, N = 1 only)")
+    ap.add_argument("--no-memsys", action="store_true", help="skip the in-process memory-system probe (roofline.memsys.measured_here, N = 1 only)")
     ap.add_argument("--with-torch", action="store_true", help="force the torch.distributed plumbing at N=1 too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (gloo: control-flow tests on a box "
@@ -597,6 +625,11 @@ def main():
         parity = all(np.array_equal(g, w) for g, w in zip(got, want))
         if not parity:
             print("bench.py: GPU output differs from the oracle -- number is INVALID", file=sys.stderr)
+    # this box's own reading of the memory system, seconds after the timed region (N = 1 only; --no-memsys skips it: the profiled runs)
+    memsys_here = None
+    if rank == 0 and world == 1 and not args.no_memsys and args.mode == "resident":
+        ctx.sync(-1)
+        memsys_here = memsys_probe(0)
     # the other BASELINE configs on the same record (N = 1 only, after the headline's timed region and buffers are done with):
     # cfg1 / cfg3 / cfg5 (+ mask), the cubic default, cfg4 -- same timing method, one view of each against the oracle
     secondary = None
@@ -662,7 +695,12 @@ def main():
                          "memsys": {"what": "784-byte row pieces of 16 distinct 8K frames + one stored byte per five loaded, no arithmetic (profiles/r06/membench/)",
                                     "read_only": MEMSYS_READ_ONLY_GBS, "mix_5_to_1": list(MEMSYS_MIX_GBS), "unit": "GB/s",
                                     "traffic_rate": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
-                                    "frac_of_mix": (round(traffic / (kernel_ms * 1e-3) / 1e9 / MEMSYS_MIX_GBS[1], 4) if traffic else None)},
+                                    "frac_of_mix": (round(traffic / (kernel_ms * 1e-3) / 1e9 / MEMSYS_MIX_GBS[1], 4) if traffic else None),
+                                    # ... and THIS box's reading, taken in-process right after the timed region (lib/libgs360probe.so = profiles/tools/membench.hip):
+                                    # row pieces alone / + the 1 : 5 stores through registers / through LDS copies (the kernel's own load instruction)
+                                    "measured_here": memsys_here,
+                                    "frac_of_mix_here": (round(traffic / (kernel_ms * 1e-3) / 1e9 / max(memsys_here["rowsmix"], memsys_here["dmamix"]), 4)
+                                                         if traffic and memsys_here else None)},
                          "kernel": EQ_KERNEL_NAMES.get(eq_kernel, str(eq_kernel)), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          # SURVEY 8(d)'s stricter figure (union of the views' texels, each once, + stores): what a kernel that shares reads across views is held to

@@ -163,18 +163,27 @@ __global__ void __launch_bounds__(256) rows5_kernel(const uint8_t* __restrict__ 
     if (n_boxes < 0) sink[0] = 1;
 }
 
-int main(int argc, char** argv) {
-    const char* mode = argc > 1 ? argv[1] : "read";
-    const int wpw = argc > 2 ? atoi(argv[2]) : 4, per_cu = argc > 3 ? atoi(argv[3]) : 4, unroll = argc > 4 ? atoi(argv[4]) : 8, reps = argc > 5 ? atoi(argv[5]) : 20, sk = argc > 6 ? atoi(argv[6]) : 1;
-    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+// One probe: `mode` as above on device `dev`; out[0..3] = median TB/s (reads + writes), median reads, median writes, best TB/s.
+// Returns 0, or a negative number with nothing left allocated.  Also the entry point of libgs360probe.so (bench.py calls it in-process,
+// after its timed region, so that `roofline.memsys` carries this box's own reading; hipcc ... -shared -fPIC builds it from this file).
+extern "C" int gs360_membench(const char* mode, int dev, int wpw, int per_cu, int unroll, int reps, int sk, double* out) {
+    uint8_t* src = nullptr; uint4* dst = nullptr; uint32_t* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+#define TRY(x) do { if (rc == 0 && (x) != hipSuccess) rc = -__LINE__; } while (0)
+    if (wpw < 1 || wpw > 4 || per_cu < 1 || per_cu > 16 || reps < 1 || reps > 1000) return -1;
+    TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    TRY(hipGetDeviceProperties(&prop, dev));
+    if (rc) return rc;
     const int cus = prop.multiProcessorCount;
     const size_t bytes = kFrame * kFrames, n16 = bytes / 16;
-    uint8_t* src; uint4* dst; uint32_t* sink;
-    CK(hipMalloc(&src, bytes + 4096)); CK(hipMalloc(&dst, bytes + 4096)); CK(hipMalloc(&sink, 64));
-    CK(hipMemset(src, 1, bytes)); CK(hipMemset(dst, 0, bytes));
+    TRY(hipMalloc(&src, bytes + 4096)); TRY(hipMalloc(&dst, bytes + 4096)); TRY(hipMalloc(&sink, 64));
+    TRY(hipMemset(src, 1, bytes)); TRY(hipMemset(dst, 0, bytes));
     const int blocks = cus * per_cu, threads = wpw * 64;
     const int n_boxes = kFrames * kBoxesX * kBoxesY;
     double rd = 0, wr = 0;
+    bool known = true;
     auto launch = [&]() {
 #define STREAM(U, S) hipLaunchKernelGGL((stream_kernel<U, S>), dim3(blocks), dim3(threads), 0, 0, (const uint4*)src, dst, n16, sink)
 #define ROWS(U, S, D) hipLaunchKernelGGL((rows_kernel<U, S, D>), dim3(blocks), dim3(threads), (D) ? wpw * U * 1024 : 0, 0, src, dst, n_boxes, sink)
@@ -216,18 +225,39 @@ int main(int argc, char** argv) {
             rd = (double)n_boxes * 30 * kPiece; wr = (double)n_boxes * 6 * 768;
         } else if (!strcmp(mode, "write")) {
             hipLaunchKernelGGL(write_kernel, dim3(blocks), dim3(threads), 0, 0, dst, n16); rd = 0; wr = (double)bytes;
-        } else { printf("unknown mode %s\n", mode); exit(2); }
+        } else known = false;
     };
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch();                  // settle: ~1 ms per launch; the clocks ramp over ~100 ms of load
-    CK(hipDeviceSynchronize());
-    { CK(hipEventRecord(e0)); int n = 0; float ms = 0; do { launch(); ++n; CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); } while (ms < 150.f); }
-    std::vector<float> t(reps);
-    for (int i = 0; i < reps; ++i) { CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&t[i], e0, e1)); }
-    CK(hipGetLastError());
+    TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
+    std::vector<float> t((size_t)reps, 0.f);
+    if (rc == 0) {
+        for (int i = 0; i < 3 && known; ++i) launch();      // settle: ~1 ms per launch; the clocks ramp over ~100 ms of load
+        if (!known) rc = -2;
+        TRY(hipDeviceSynchronize());
+        if (rc == 0) { TRY(hipEventRecord(e0)); float ms = 0; int n = 0; do { launch(); TRY(hipEventRecord(e1)); TRY(hipEventSynchronize(e1)); TRY(hipEventElapsedTime(&ms, e0, e1)); } while (rc == 0 && ms < 150.f && ++n < 100000); }
+        for (int i = 0; i < reps && rc == 0; ++i) { TRY(hipEventRecord(e0)); launch(); TRY(hipEventRecord(e1)); TRY(hipEventSynchronize(e1)); TRY(hipEventElapsedTime(&t[(size_t)i], e0, e1)); }
+        TRY(hipGetLastError());
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (sink) (void)hipFree(sink);
+#undef TRY
+    if (rc) return rc;
     std::sort(t.begin(), t.end());
-    const double med = t[reps / 2] * 1e-3, best = t[0] * 1e-3;
+    const double med = t[(size_t)reps / 2] * 1e-3, best = t[0] * 1e-3;
+    out[0] = (rd + wr) / med / 1e12; out[1] = rd / med / 1e12; out[2] = wr / med / 1e12; out[3] = (rd + wr) / best / 1e12;
+    out[4] = rd / 1e6; out[5] = wr / 1e6; out[6] = med * 1e3;
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const char* mode = argc > 1 ? argv[1] : "read";
+    const int wpw = argc > 2 ? atoi(argv[2]) : 4, per_cu = argc > 3 ? atoi(argv[3]) : 4, unroll = argc > 4 ? atoi(argv[4]) : 8, reps = argc > 5 ? atoi(argv[5]) : 20, sk = argc > 6 ? atoi(argv[6]) : 1;
+    double o[7];
+    const int rc = gs360_membench(mode, 0, wpw, per_cu, unroll, reps, sk, o);
+    if (rc) { printf("%s: failed (%d)\n", mode, rc); return 1; }
     printf("%-8s waves/wg %d wgs/cu %d unroll %2d stores %d : read %7.1f MB write %7.1f MB  median %.3f ms = %.2f TB/s (reads %.2f, writes %.2f)  best %.2f TB/s\n", mode, wpw, per_cu, unroll, sk,
-           rd / 1e6, wr / 1e6, med * 1e3, (rd + wr) / med / 1e12, rd / med / 1e12, wr / med / 1e12, (rd + wr) / best / 1e12);
+           o[4], o[5], o[6], o[0], o[1], o[2], o[3]);
     return 0;
 }

@@ -5,7 +5,7 @@
 # kernel-selection options, the whole GPU test suite.
 R=$PWD; OUT=$R/gpurun_out/prof_r06_final; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2>$OUT/trace.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-memsys > $OUT/bench_under_rocprof.json 2>$OUT/trace.err
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
@@ -14,7 +14,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/b$i.log 2>&1 || echo "pass $i failed/timeout"
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-memsys > $OUT/b$i.log 2>&1 || echo "pass $i failed/timeout"
 done
 python3 - $OUT <<'PY'
 import csv,glob,collections,json,sys

@@ -4,7 +4,7 @@
 R=$PWD; TAG=${1:-a}; OUT=$R/gpurun_out/trace_only_$TAG; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $OUT/bench_before.json 2> $OUT/err.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2>$OUT/trace.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-memsys > $OUT/bench_under_rocprof.json 2>$OUT/trace.err
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv; rm -rf $OUT/trace
 cd $R
 python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $OUT/bench_after.json 2>> $OUT/err.txt

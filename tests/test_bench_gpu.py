@@ -51,6 +51,10 @@ def test_bench_single_rank_line_matches_the_contract():
     m = d["roofline"]["memsys"]
     assert m["mix_5_to_1"][0] < m["mix_5_to_1"][1] < m["read_only"] < d["roofline"]["peak"]
     assert m["traffic_rate"] is None or 0.3 < m["frac_of_mix"] < 1.2
+    # ... and against THIS box's own reading: the probe library (lib/libgs360probe.so, built by csrc/Makefile) ran in-process after the timed region
+    here = m["measured_here"]
+    assert here is not None and 3000 < here["dmamix"] < 8000 and 3000 < here["rowsmix"] < 8000 and here["rowsmix"] < here["rows"] < 8000, here
+    assert m["traffic_rate"] is None or 0.5 < m["frac_of_mix_here"] < 1.1
 
 
 def test_bench_rccl_world_of_one_prints_exactly_one_json_line():
