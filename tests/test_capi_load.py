@@ -164,3 +164,30 @@ def test_kernels_keep_their_register_budgets():
                          "eq_views_kernelILi3ELb0ELb1ELi1ELb1E": 5}.items():
         r = [r for n, r in res.items() if frag in n][0]
         assert r["lds"] * per_cu <= 160 * 1024, (frag, r)
+
+
+def test_probe_library_is_built_next_to_the_product_and_fails_cleanly_without_a_gpu():
+    """lib/libgs360probe.so (profiles/tools/membench.hip, built by csrc/Makefile): the memory-system probe bench.py runs in-process for
+    roofline.memsys.measured_here -- a measurement aid, not part of the C ABI (include/gs360.h does not declare it).  Without a GPU it must
+    return an error code, and bench.py's wrapper None, instead of taking the process down."""
+    import ctypes
+    path = pathlib.Path(gs360.capi.LIB_PATH).parent / "libgs360probe.so"
+    if not path.exists():
+        pytest.skip("no libgs360probe.so next to the library (built without csrc/Makefile)")
+    fn = ctypes.CDLL(str(path)).gs360_membench
+    fn.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_double)]
+    fn.restype = ctypes.c_int
+    out = (ctypes.c_double * 7)()
+    assert fn(b"rows", 0, 9, 2, 8, 3, 1, out) == -1          # argument check first (at most four wavefronts per workgroup)
+    assert "gs360_membench" not in " ".join(declared_functions())
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        assert fn(b"rows", 0, 4, 2, 8, 3, 1, out) < 0
+        import sys
+        sys.path.insert(0, str(ROOT))
+        import bench
+        assert bench.memsys_probe(0) is None
